@@ -1,0 +1,141 @@
+/*
+ * zkhip.h -- C ABI of libzkhip.so: the MI355X (gfx950) drop-in for the compute loops of the
+ * reference's `dist-primitive` crate (LBruyne/Scalable-Collaborative-zkSNARK).
+ *
+ * The reference has no FFI of its own (it is 100 % Rust on arkworks); these entry points are
+ * what a `#[link(name = "zkhip")] extern "C"` block in dist-primitive would bind to replace
+ *   - `G::msm(b, s)`                         dist-primitive/src/dmsm.rs:23, dpoly_comm.rs:242,274,457
+ *   - the Phase-1 sumcheck loops             dsumcheck.rs:10-21,37-85,107-121,167-219,301-315,377-429
+ *   - fold / fix_variable                    mle.rs:62-70,95-103
+ *   - the open() quotient+fold loop          dpoly_comm.rs:309-323,337-351,418-432
+ *   - the product tree                       dacc_product.rs:31-38,304-313,372-381
+ *   - the element-wise Fr steps              hyperplonk/src/dhyperplonk.rs:233-238,251-256,326-339
+ * INTEGRATION.md shows the Rust-side binding.
+ *
+ * Memory layouts are the reference's own, so a Rust caller passes its buffers unchanged:
+ *   Fr  : 4 x u64 little-endian limbs, Montgomery form R = 2^256  (ark-ff Fp<MontBackend<_,4>,4>), 32 B
+ *   Fq  : 6 x u64 limbs, Montgomery form R = 2^384, 48 B
+ *   G1 affine: { x: Fq, y: Fq, infinity: bool }  -- stride 104 as a Rust struct; stride 96
+ *              (x||y, with x = y = 0 meaning infinity) is accepted too
+ *   G1 projective (results): Jacobian { x, y, z } 3 x 48 B = 144 B, as ark-ec Projective.
+ *              Results are returned NORMALISED (z = R mod q, or (1,1,0) for infinity), so
+ *              they are bit-comparable and are valid `Projective` values.
+ *
+ * Conventions: every function returns 0 on success or a negative zk_status; nothing aborts.
+ * `d_` pointers are device (HBM) pointers, `h_` pointers are host pointers.  A ctx is bound
+ * to one GPU; calls on distinct ctx are thread-safe, calls on one ctx are serialised by the
+ * caller.  All work is enqueued on the ctx stream; functions that return host results
+ * synchronise that stream before returning.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zk_ctx zk_ctx;
+typedef struct zk_srs zk_srs; /* device-resident base vector(s): one level of powers_of_g */
+
+typedef enum {
+    ZK_OK = 0,
+    ZK_ERR_INVALID = -1,   /* bad argument (null, not a power of two, ...) : the reference's assert!s */
+    ZK_ERR_LENGTH = -2,    /* bases/scalars length mismatch: `msm` -> Err(min_len); see zk_last_error */
+    ZK_ERR_HIP = -3,       /* HIP runtime error */
+    ZK_ERR_NO_DEVICE = -4, /* no gfx950 device / library built without device code */
+    ZK_ERR_DIV_ZERO = -5,  /* zero denominator in zk_fr_batch_div (reference: inverse().unwrap() panic) */
+    ZK_ERR_OOM = -6
+} zk_status;
+
+/* ---- context ------------------------------------------------------------------------ */
+int zk_ctx_create(int device_id, zk_ctx **out);
+void zk_ctx_destroy(zk_ctx *ctx);
+const char *zk_last_error(zk_ctx *ctx);
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL = ctx-owned stream */
+int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
+int zk_ctx_sync(zk_ctx *ctx);
+const char *zk_version(void);
+
+/* ---- device memory helpers (thin hipMalloc/hipMemcpy wrappers for non-HIP callers) -- */
+int zk_malloc(zk_ctx *ctx, size_t bytes, void **d_out);
+int zk_free(zk_ctx *ctx, void *d_ptr);
+int zk_memcpy_h2d(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int zk_memcpy_d2h(zk_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- element-wise Fr (hyperplonk/src/dhyperplonk.rs:233-238,251-256,326-339) -------- */
+int zk_fr_add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
+int zk_fr_sub(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
+int zk_fr_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
+/* out[i] = a[i] + alpha*b[i] + beta          (`s + alpha*sid + beta`, dhyperplonk.rs:326-337) */
+int zk_fr_axpb(zk_ctx *ctx, const void *d_a, const void *d_b, const uint64_t h_alpha[4],
+               const uint64_t h_beta[4], void *d_out, size_t n);
+/* out[i] = num[i] / den[i] (dhyperplonk.rs:339), batched inversion; ZK_ERR_DIV_ZERO if a den is 0 */
+int zk_fr_batch_div(zk_ctx *ctx, const void *d_num, const void *d_den, void *d_out, size_t n);
+
+/* ---- sumcheck family ---------------------------------------------------------------- */
+/* Phase-1 loop of sumcheck / c_sumcheck / d_sumcheck (dsumcheck.rs:10-21 = :107-121 = :301-315).
+ * d_tab: len = 2^n Fr (not modified). h_chal: n Fr. h_out_pairs: n pairs (sum_lo, sum_hi) = 2n Fr.
+ * h_last: the single remaining table element (the caller appends (0,last), runs pss2ss, ...). */
+int zk_sumcheck(zk_ctx *ctx, const void *d_tab, size_t len, const uint64_t *h_chal,
+                uint64_t *h_out_pairs, uint64_t h_last[4]);
+/* Phase-1 loop of sumcheck_product / c_ / d_ (dsumcheck.rs:37-85 = :167-219 = :377-429).
+ * h_out_triples: n x (t0,t1,t2) = 3n Fr; h_last_f / h_last_g: remaining elements. */
+int zk_sumcheck_product(zk_ctx *ctx, const void *d_f, const void *d_g, size_t len,
+                        const uint64_t *h_chal, uint64_t *h_out_triples, uint64_t h_last_f[4],
+                        uint64_t h_last_g[4]);
+/* fix_variable (mle.rs:88-105): fold min(n, n_points) times; d_out receives len >> rounds Fr. */
+int zk_fold(zk_ctx *ctx, const void *d_tab, size_t len, const uint64_t *h_points, size_t n_points,
+            void *d_out);
+/* Phase 1 of open / d_local_open / c_open (dpoly_comm.rs:309-323 = :337-351 = :418-432):
+ * for every round q_i = hi - lo then fold with point[i].  d_q_out receives len-1 Fr: q_0 (len/2)
+ * followed by q_1 (len/4) ... q_{n-1} (1) -- exactly the scalar vectors of the n commitments.
+ * h_value: the final evaluation. */
+int zk_open_rounds(zk_ctx *ctx, const void *d_tab, size_t len, const uint64_t *h_point,
+                   void *d_q_out, uint64_t h_value[4]);
+/* product tree of acc_product / d_acc_product / c_acc_product (dacc_product.rs:31-38):
+ * d_tree receives 2N Fr: tree[0..N) = x, tree[N+j] = tree[2j]*tree[2j+1], tree[2N-1] = 0. */
+int zk_product_tree(zk_ctx *ctx, const void *d_x, size_t N, void *d_tree);
+
+/* ---- G1 MSM -------------------------------------------------------------------------- */
+/* Upload a base vector once (the reference clones powers_of_g[level] per call, dpoly_comm.rs:258).
+ * h_bases: n affine points at `stride` bytes (96 or 104); stored on device packed at 96 B. */
+int zk_srs_register(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n, zk_srs **out);
+/* Same from a device buffer already in the packed 96-B layout (no copy is made; caller keeps it alive) */
+int zk_srs_wrap_device(zk_ctx *ctx, const void *d_bases96, size_t n, zk_srs **out);
+/* Synthetic SRS on device: P_i = (k0 + i*k1)*G, the generator G1; mirrors the random-point SRS of
+ * PolynomialCommitmentCub::new_single/new_random (dpoly_comm.rs:197-233). k0,k1 canonical 4xu64. */
+int zk_srs_generate(zk_ctx *ctx, const uint64_t h_k0[4], const uint64_t h_k1[4], size_t n, zk_srs **out);
+int zk_srs_free(zk_ctx *ctx, zk_srs *srs);
+size_t zk_srs_len(const zk_srs *srs);
+const void *zk_srs_device_ptr(const zk_srs *srs);
+
+/* sum_i scalars[i] * bases[offset + i], i < n.  d_scalars: n Fr (Montgomery, as the reference
+ * passes them; converted on device like `into_bigint`).  h_out: 18 u64 normalised Jacobian. */
+int zk_msm_g1(zk_ctx *ctx, const zk_srs *srs, size_t offset, const void *d_scalars, size_t n,
+              uint64_t h_out[18]);
+/* Drop-in for `G::msm(&[Affine], &[Fr]) -> Result<G, usize>` on host slices (dmsm.rs:23):
+ * returns ZK_ERR_LENGTH when n_bases != n_scalars and stores min(n_bases, n_scalars) in *h_err_len. */
+int zk_msm_g1_host(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n_bases,
+                   const uint64_t *h_scalars, size_t n_scalars, uint64_t h_out[18], size_t *h_err_len);
+/* window size (bits) the device Pippenger picks for n points; 0 < override <= 20 forces it */
+int zk_msm_window(size_t n);
+int zk_msm_set_window(zk_ctx *ctx, int c_override);
+/* per-phase device time of the last zk_msm_g1 on this ctx, in ms:
+ * [0] digits+sort, [1] bucket accumulation, [2] bucket reduction, [3] host combine, [4] total */
+int zk_msm_last_timing(zk_ctx *ctx, float h_ms[5]);
+
+/* ---- test hooks (used by tests/ only; stable but not part of the drop-in surface) --- */
+int zk_dbg_fq_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
+int zk_dbg_fq_add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
+int zk_dbg_fq_sub(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
+/* device XYZZ formulas on pairs of packed affine points; h_out[i] = 18 u64 normalised Jacobian.
+ * mode 0: p+q (mixed add)  1: (p+q)+p (full add)  2: (p+q)+(p+q) (doubling path)  3: p-q */
+int zk_dbg_g1_op(zk_ctx *ctx, int mode, const void *d_p96, const void *d_q96, void *h_out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

@@ -246,17 +246,29 @@ __device__ __forceinline__ Fp<C> fp_from_mont(const Fp<C>& a) {
     return fp_mul<C>(a, one);
 }
 
+// limb k of p - 2 (compile-time borrow chain; r ends in ...00000001 so the borrow propagates)
+template <class C>
+__host__ __device__ constexpr u32 fp_pm2_limb(int k) {
+    u64 borrow = 2;
+    u32 res = 0;
+    for (int j = 0; j <= k; j++) {
+        u64 pj = C::P(j);
+        res = (u32)(pj - borrow);
+        borrow = (pj < borrow) ? 1 : 0;
+    }
+    return res;
+}
+
 // a^(p-2): Fermat inverse (0 -> 0).  Exponent bits come from the compile-time modulus.
 template <class C>
 __device__ __noinline__ Fp<C> fp_inv(const Fp<C>& a) {
     Fp<C> acc = fp_one<C>();
     for (int i = C::N * 32 - 1; i >= 0; i--) {
         acc = fp_sqr<C>(acc);
-        // p - 2: only limb 0 changes (both moduli end in ...01 / ...ab, >= 2)
         u32 w = 0;
 #pragma unroll
         for (int k = 0; k < C::N; k++)
-            if ((i >> 5) == k) w = (k == 0) ? C::P(0) - 2u : C::P(k);
+            if ((i >> 5) == k) w = fp_pm2_limb<C>(k);
         if ((w >> (i & 31)) & 1u) acc = fp_mul<C>(acc, a);
     }
     return acc;

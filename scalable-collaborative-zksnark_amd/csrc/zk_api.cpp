@@ -1,0 +1,283 @@
+// zk_api.cpp -- extern "C" surface of libzkhip.so (see include/zkhip.h) and context plumbing.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "zk_ctx.hpp"
+
+namespace zk {
+
+int fail(zk_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+int hip_fail(zk_ctx* ctx, hipError_t e, const char* what) {
+    return fail(ctx, e == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+void* scratch(zk_ctx* ctx, int slot, size_t bytes) {
+    zk_ctx::Arena& a = ctx->scratch[slot];
+    if (bytes <= a.cap && a.p) return a.p;
+    if (a.p) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(a.p);
+        a.p = nullptr;
+        a.cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&a.p, want);
+    if (e != hipSuccess) {
+        hip_fail(ctx, e, "hipMalloc(scratch)");
+        a.p = nullptr;
+        return nullptr;
+    }
+    a.cap = want;
+    return a.p;
+}
+void* pinned(zk_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->h_pinned_cap && ctx->h_pinned) return ctx->h_pinned;
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    ctx->h_pinned = nullptr;
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    hipError_t e = hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        hip_fail(ctx, e, "hipHostMalloc");
+        ctx->h_pinned = nullptr;
+        ctx->h_pinned_cap = 0;
+        return nullptr;
+    }
+    ctx->h_pinned_cap = want;
+    return ctx->h_pinned;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+const char* zk_version(void) { return "zkhip 0.1 (gfx950)"; }
+
+int zk_ctx_create(int device_id, zk_ctx** out) {
+    if (!out) return ZK_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return ZK_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return ZK_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return ZK_ERR_HIP;
+    zk_ctx* c = new zk_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ZK_ERR_HIP;
+    }
+    c->own_stream = true;
+    for (auto& e : c->ev) hipEventCreate(&e);
+    *out = c;
+    return ZK_OK;
+}
+void zk_ctx_destroy(zk_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& a : ctx->scratch)
+        if (a.p) hipFree(a.p);
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    for (auto& e : ctx->ev)
+        if (e) hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+const char* zk_last_error(zk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream) {
+    if (!ctx) return ZK_ERR_INVALID;
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return ZK_ERR_HIP;
+        ctx->own_stream = true;
+    }
+    return ZK_OK;
+}
+int zk_ctx_sync(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_INVALID;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int zk_malloc(zk_ctx* ctx, size_t bytes, void** d_out) {
+    if (!ctx || !d_out) return ZK_ERR_INVALID;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ZK_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));
+    return ZK_OK;
+}
+int zk_free(zk_ctx* ctx, void* d_ptr) {
+    if (!ctx) return ZK_ERR_INVALID;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, hipFree(d_ptr));
+    return ZK_OK;
+}
+int zk_memcpy_h2d(zk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx) return ZK_ERR_INVALID;
+    ZK_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+int zk_memcpy_d2h(zk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx) return ZK_ERR_INVALID;
+    ZK_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+#define NEED(ctx, cond)                                              \
+    do {                                                             \
+        if (!(ctx)) return ZK_ERR_INVALID;                           \
+        if (!(cond)) return fail(ctx, ZK_ERR_INVALID, "null argument"); \
+    } while (0)
+
+int zk_fr_add(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
+    NEED(ctx, n == 0 || (a && b && out));
+    return fr_binary(ctx, 0, a, b, out, n);
+}
+int zk_fr_sub(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
+    NEED(ctx, n == 0 || (a && b && out));
+    return fr_binary(ctx, 1, a, b, out, n);
+}
+int zk_fr_mul(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
+    NEED(ctx, n == 0 || (a && b && out));
+    return fr_binary(ctx, 2, a, b, out, n);
+}
+int zk_fr_axpb(zk_ctx* ctx, const void* a, const void* b, const uint64_t alpha[4], const uint64_t beta[4], void* out, size_t n) {
+    NEED(ctx, alpha && beta && (n == 0 || (a && b && out)));
+    return fr_axpb(ctx, a, b, alpha, beta, out, n);
+}
+int zk_fr_batch_div(zk_ctx* ctx, const void* num, const void* den, void* out, size_t n) {
+    NEED(ctx, n == 0 || (num && den && out));
+    return fr_batch_div(ctx, num, den, out, n);
+}
+
+static int log2_exact(size_t len) {
+    int n = 0;
+    while (((size_t)1 << n) < len) n++;
+    return n;
+}
+int zk_sumcheck(zk_ctx* ctx, const void* d_tab, size_t len, const uint64_t* h_chal, uint64_t* h_out_pairs, uint64_t h_last[4]) {
+    NEED(ctx, d_tab && h_last && (len <= 1 || (h_chal && h_out_pairs)));
+    return multilinear_run(ctx, 0, d_tab, nullptr, len, h_chal, (size_t)log2_exact(len), h_out_pairs, h_last, nullptr, nullptr, nullptr);
+}
+int zk_sumcheck_product(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, const uint64_t* h_chal, uint64_t* h_out_triples,
+                        uint64_t h_last_f[4], uint64_t h_last_g[4]) {
+    NEED(ctx, d_f && d_g && h_last_f && h_last_g && (len <= 1 || (h_chal && h_out_triples)));
+    return multilinear_run(ctx, 1, d_f, d_g, len, h_chal, (size_t)log2_exact(len), h_out_triples, h_last_f, h_last_g, nullptr, nullptr);
+}
+int zk_fold(zk_ctx* ctx, const void* d_tab, size_t len, const uint64_t* h_points, size_t n_points, void* d_out) {
+    NEED(ctx, d_tab && d_out && (n_points == 0 || h_points));
+    if (len == 0 || (len & (len - 1))) return fail(ctx, ZK_ERR_INVALID, "table length %zu is not a power of two", len);
+    size_t n = (size_t)log2_exact(len);
+    size_t rounds = n_points < n ? n_points : n;  // min(n, points_cnt), mle.rs:94
+    return multilinear_run(ctx, 2, d_tab, nullptr, len, h_points, rounds, nullptr, nullptr, nullptr, d_out, nullptr);
+}
+int zk_open_rounds(zk_ctx* ctx, const void* d_tab, size_t len, const uint64_t* h_point, void* d_q_out, uint64_t h_value[4]) {
+    NEED(ctx, d_tab && h_value && (len <= 1 || (h_point && d_q_out)));
+    return multilinear_run(ctx, 3, d_tab, nullptr, len, h_point, (size_t)log2_exact(len), nullptr, h_value, nullptr, nullptr, d_q_out);
+}
+int zk_product_tree(zk_ctx* ctx, const void* d_x, size_t N, void* d_tree) {
+    NEED(ctx, d_x && d_tree);
+    return product_tree(ctx, d_x, N, d_tree);
+}
+
+int zk_srs_register(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out) {
+    NEED(ctx, out);
+    return srs_pack(ctx, h_bases, stride, n, out);
+}
+int zk_srs_wrap_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out) {
+    NEED(ctx, out && (n == 0 || d_bases96));
+    zk_srs* s = new zk_srs();
+    s->d_bases = const_cast<void*>(d_bases96);
+    s->n = n;
+    s->owned = false;
+    *out = s;
+    return ZK_OK;
+}
+int zk_srs_generate(zk_ctx* ctx, const uint64_t k0[4], const uint64_t k1[4], size_t n, zk_srs** out) {
+    NEED(ctx, out && k0 && k1);
+    return srs_generate(ctx, k0, k1, n, out);
+}
+int zk_srs_free(zk_ctx* ctx, zk_srs* srs) {
+    if (!srs) return ZK_OK;
+    if (srs->owned && srs->d_bases) {
+        if (ctx) hipStreamSynchronize(ctx->stream);
+        hipFree(srs->d_bases);
+    }
+    delete srs;
+    return ZK_OK;
+}
+size_t zk_srs_len(const zk_srs* srs) { return srs ? srs->n : 0; }
+const void* zk_srs_device_ptr(const zk_srs* srs) { return srs ? srs->d_bases : nullptr; }
+
+int zk_msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t h_out[18]) {
+    NEED(ctx, srs && h_out && (n == 0 || d_scalars));
+    return msm_g1(ctx, srs, offset, d_scalars, n, h_out);
+}
+int zk_msm_g1_host(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n_bases, const uint64_t* h_scalars, size_t n_scalars,
+                   uint64_t h_out[18], size_t* h_err_len) {
+    NEED(ctx, h_out);
+    if (n_bases != n_scalars) {  // VariableBaseMSM::msm -> Err(min(len)) (ark-ec 0.4.2), unwrap()ed at dmsm.rs:23
+        size_t m = n_bases < n_scalars ? n_bases : n_scalars;
+        if (h_err_len) *h_err_len = m;
+        return fail(ctx, ZK_ERR_LENGTH, "msm: bases.len() = %zu != scalars.len() = %zu (Err(%zu))", n_bases, n_scalars, m);
+    }
+    zk_srs* srs = nullptr;
+    int rc = srs_pack(ctx, h_bases, stride, n_bases, &srs);
+    if (rc) return rc;
+    void* d_s = nullptr;
+    if (n_scalars) {
+        d_s = scratch(ctx, 7, n_scalars * 32);
+        if (!d_s) {
+            zk_srs_free(ctx, srs);
+            return ZK_ERR_OOM;
+        }
+        hipError_t e = hipMemcpyAsync(d_s, h_scalars, n_scalars * 32, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            zk_srs_free(ctx, srs);
+            return hip_fail(ctx, e, "hipMemcpyAsync(scalars)");
+        }
+    }
+    rc = msm_g1(ctx, srs, 0, d_s, n_scalars, h_out);
+    zk_srs_free(ctx, srs);
+    return rc;
+}
+int zk_msm_window(size_t n) { return msm_pick_window(n); }
+int zk_msm_set_window(zk_ctx* ctx, int c) {
+    if (!ctx || c < 0 || c > 20) return ZK_ERR_INVALID;
+    ctx->msm_window_override = c;
+    return ZK_OK;
+}
+int zk_msm_last_timing(zk_ctx* ctx, float h_ms[5]) {
+    if (!ctx || !h_ms) return ZK_ERR_INVALID;
+    std::memcpy(h_ms, ctx->msm_ms, sizeof(ctx->msm_ms));
+    return ZK_OK;
+}
+
+int zk_dbg_fq_add(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 0, a, b, out, n); }
+int zk_dbg_fq_sub(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 1, a, b, out, n); }
+int zk_dbg_fq_mul(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 2, a, b, out, n); }
+int zk_dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n) {
+    NEED(ctx, n == 0 || (p && q && h_out));
+    return dbg_g1_op(ctx, mode, p, q, h_out, n);
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// zk_ctx.hpp -- per-GPU context shared by the libzkhip translation units (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/zkhip.h"
+
+struct zk_srs {
+    void* d_bases = nullptr;  // packed 96-B affine points (x||y Montgomery, x=y=0: infinity)
+    size_t n = 0;
+    bool owned = true;
+};
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    // growable device scratch arenas (never shrunk; freed with the ctx)
+    struct Arena {
+        void* p = nullptr;
+        size_t cap = 0;
+    };
+    Arena scratch[8];
+    void* h_pinned = nullptr;  // pinned host staging
+    size_t h_pinned_cap = 0;
+    int msm_window_override = 0;
+    float msm_ms[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int cu_count = 256;
+};
+
+namespace zk {
+
+int fail(zk_ctx* ctx, int code, const char* fmt, ...);
+int hip_fail(zk_ctx* ctx, hipError_t e, const char* what);
+// returns device scratch of at least `bytes` (slot 0..7), or nullptr after recording the error
+void* scratch(zk_ctx* ctx, int slot, size_t bytes);
+void* pinned(zk_ctx* ctx, size_t bytes);
+
+#define ZK_HIP(ctx, call)                                            \
+    do {                                                             \
+        hipError_t _e = (call);                                      \
+        if (_e != hipSuccess) return zk::hip_fail(ctx, _e, #call);   \
+    } while (0)
+
+// ---- zk_fr.hip ----
+int fr_binary(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n);
+int fr_axpb(zk_ctx* ctx, const void* a, const void* b, const uint64_t* alpha, const uint64_t* beta, void* out, size_t n);
+int fr_batch_div(zk_ctx* ctx, const void* num, const void* den, void* out, size_t n);
+// mode 0 plain sums, 1 product sums, 2 fold only, 3 open quotients
+int multilinear_run(zk_ctx* ctx, int mode, const void* d_f, const void* d_g, size_t len, const uint64_t* h_chal,
+                    size_t rounds, uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q);
+int product_tree(zk_ctx* ctx, const void* d_x, size_t N, void* d_tree);
+int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n);
+
+// ---- zk_msm.hip ----
+int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out);
+int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
+int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, zk_srs** out);
+int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n);
+int msm_pick_window(size_t n);
+
+}  // namespace zk

@@ -1,0 +1,543 @@
+// zk_fr.hip -- Fr kernels of the dist-primitive hot path on gfx950:
+//   K2/K3 sumcheck rounds (dsumcheck.rs:10-21, :37-85 and their c_/d_ copies),
+//   K4   fold / fix_variable (mle.rs:95-103),
+//   K5   open quotients q = hi - lo fused with the fold (dpoly_comm.rs:309-323),
+//   K6   product tree (dacc_product.rs:31-38),
+//   K8   element-wise maps and batched division (dhyperplonk.rs:233-238,251-256,326-339).
+//
+// Data layout in HBM: the reference's own AoS -- one Fr = 32 B (4 x u64 Montgomery limbs),
+// so a lane moves one element with two 16-byte accesses and a wave reads 2 KiB contiguous.
+//
+// Round fusion: the reference folds the TOP variable each round (lo = tab[..m/2], hi = tab[m/2..]).
+// Because every challenge is known up front, a thread that loads the 2^K elements
+// {j + s*m/2^K} can run K rounds in registers: one HBM sweep per K rounds instead of per round.
+// All sums are exact modular sums, so any association order is bit-identical to the reference.
+#include "fp.cuh"
+#include "zk_ctx.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace zk {
+
+static constexpr int kBlock = 256;
+static constexpr size_t kTailMax = 2048;  // elements handled by the single-workgroup tail kernel
+
+struct ChalArgs {
+    Fr c[3];
+};
+
+// ---------------------------------------------------------------------------------------
+// block-level reduction of NS running sums held by every thread of a 256-thread block.
+// lds: NS * 256 Fr.  Result for sum s is returned to the thread with (tid == 32*s) ... see use.
+// ---------------------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void block_reduce_sums(Fr (&acc)[NS], uint4* lds, Fr& result, bool& has_result, int& which) {
+    static_assert(NS <= 8, "one 32-lane group per sum");
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < NS; s++) fr_store(lds, (size_t)s * kBlock + tid, acc[s]);
+    __syncthreads();
+    const int grp = tid >> 5, l32 = tid & 31;
+    has_result = false;
+    which = grp;
+    if (grp < NS) {
+        Fr v = fr_load(lds, (size_t)grp * kBlock + l32);
+#pragma unroll
+        for (int i = 1; i < 8; i++) v = fr_add(v, fr_load(lds, (size_t)grp * kBlock + l32 + 32 * i));
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            Fr o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.l[k] = __shfl_down(v.l[k], off, 32);
+            v = fr_add(v, o);
+        }
+        result = v;
+        has_result = (l32 == 0);
+    }
+    __syncthreads();
+}
+
+// one sumcheck / fold / open round on the register-resident slice e[0 .. 2*half)
+// MODE 0: plain sums (2), 1: product sums (3), 2: fold only, 3: open (q written by caller)
+template <int MODE>
+__device__ __forceinline__ void round_pair(Fr& flo, const Fr& fhi, Fr& glo, const Fr& ghi, const Fr& r, Fr* acc, Fr& q_out) {
+    Fr df = fr_sub(fhi, flo);
+    if (MODE == 0) {
+        acc[0] = fr_add(acc[0], flo);
+        acc[1] = fr_add(acc[1], fhi);
+    }
+    if (MODE == 1) {
+        Fr dg = fr_sub(ghi, glo);
+        acc[0] = fr_add(acc[0], fr_mul(flo, glo));
+        acc[1] = fr_add(acc[1], fr_mul(fhi, ghi));
+        // (2 f_hi - f_lo)(2 g_hi - g_lo) = (f_hi + df)(g_hi + dg)      dsumcheck.rs:55-72
+        acc[2] = fr_add(acc[2], fr_mul(fr_add(fhi, df), fr_add(ghi, dg)));
+        glo = fr_add(glo, fr_mul(r, dg));
+    }
+    if (MODE == 3) q_out = df;
+    // lo*(1-r) + hi*r == lo + r*(hi - lo)  (same canonical field element)   dsumcheck.rs:14-19
+    flo = fr_add(flo, fr_mul(r, df));
+}
+
+template <int MODE>
+struct ModeTraits {
+    static constexpr int W = (MODE == 0) ? 2 : (MODE == 1 ? 3 : 0);
+    static constexpr bool TWO = (MODE == 1);
+};
+
+// ---------------------------------------------------------------------------------------
+// K fused rounds over a table of length m living in HBM.  Thread handles output index j
+// (grid-stride), reading f[j + s*(m>>K)], s < 2^K (each a coalesced 2-KiB wave read).
+// partials layout: [(rd*W + w) * gridDim.x + blockIdx.x]
+// ---------------------------------------------------------------------------------------
+template <int K, int MODE>
+__global__ void __launch_bounds__(kBlock) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
+                                               void* __restrict__ go, size_t m, ChalArgs ch, void* __restrict__ partials,
+                                               void* __restrict__ qbase) {
+    constexpr int W = ModeTraits<MODE>::W;
+    constexpr bool TWO = ModeTraits<MODE>::TWO;
+    constexpr int E = 1 << K;
+    constexpr int NS = (W == 0) ? 1 : K * W;
+    extern __shared__ uint4 lds[];
+    const size_t q = m >> K;
+    Fr acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) acc[s] = fp_zero<FrCfg>();
+
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += (size_t)gridDim.x * kBlock) {
+        Fr ef[E], eg[TWO ? E : 1];
+#pragma unroll
+        for (int s = 0; s < E; s++) {
+            ef[s] = fr_load(f, j + (size_t)s * q);
+            if (TWO) eg[s] = fr_load(g, j + (size_t)s * q);
+        }
+        size_t qoff = 0;  // offset of this round's q vector relative to qbase
+        size_t mcur = m;
+#pragma unroll
+        for (int rd = 0; rd < K; rd++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int half = E >> (rd + 1);
+#pragma unroll
+            for (int s = 0; s < E / 2; s++) {
+                if (s < half) {
+                    Fr qv;
+                    round_pair<MODE>(ef[s], ef[s + half], eg[TWO ? s : 0], eg[TWO ? s + half : 0], ch.c[rd],
+                                     &acc[(W == 0) ? 0 : rd * W], qv);
+                    if (MODE == 3) fr_store(qbase, qoff + j + (size_t)s * q, qv);
+                }
+            }
+            qoff += mcur >> 1;
+            mcur >>= 1;
+        }
+        fr_store(fo, j, ef[0]);
+        if (TWO) fr_store(go, j, eg[0]);
+    }
+    if (W != 0) {
+        Fr res;
+        bool has;
+        int which;
+        block_reduce_sums<NS>(acc, lds, res, has, which);
+        if (has) fr_store(partials, (size_t)which * gridDim.x + blockIdx.x, res);
+    }
+}
+
+// sums partials[s][0..nb) -> out[s]; one block per s
+__global__ void __launch_bounds__(kBlock) k_reduce_partials(const void* __restrict__ partials, size_t nb, void* __restrict__ out) {
+    extern __shared__ uint4 lds[];
+    const int s = blockIdx.x;
+    Fr acc[1];
+    acc[0] = fp_zero<FrCfg>();
+    for (size_t i = threadIdx.x; i < nb; i += kBlock) acc[0] = fr_add(acc[0], fr_load(partials, (size_t)s * nb + i));
+    Fr res;
+    bool has;
+    int which;
+    block_reduce_sums<1>(acc, lds, res, has, which);
+    if (has) fr_store(out, s, res);
+}
+
+// ---------------------------------------------------------------------------------------
+// Tail: all remaining rounds on a table of m <= kTailMax elements inside ONE workgroup, the
+// table(s) resident in LDS (2048 x 32 B x 2 tables = 128 KiB of the CU's 160 KiB).
+// Writes: sums -> sums_out[(rd)*W + w]; q -> qbase; final table (m >> rounds) -> fo / go.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_tail(const void* __restrict__ f, const void* __restrict__ g, size_t m, int rounds,
+                                               const void* __restrict__ chal, void* __restrict__ sums_out,
+                                               void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go) {
+    constexpr int W = ModeTraits<MODE>::W;
+    constexpr bool TWO = ModeTraits<MODE>::TWO;
+    constexpr int NS = (W == 0) ? 1 : W;
+    extern __shared__ uint4 lds[];
+    uint4* tf = lds;
+    uint4* tg = lds + 2 * m;                    // 2 uint4 per Fr
+    uint4* red = lds + (TWO ? 4 : 2) * m;       // NS*256 Fr reduction area
+    const int tid = threadIdx.x;
+    for (size_t i = tid; i < m; i += kBlock) {
+        fr_store(tf, i, fr_load(f, i));
+        if (TWO) fr_store(tg, i, fr_load(g, i));
+    }
+    __syncthreads();
+    size_t qoff = 0;
+    for (int rd = 0; rd < rounds; rd++) {
+        const size_t h = m >> 1;
+        const Fr r = fr_load(chal, rd);
+        Fr acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc[s] = fp_zero<FrCfg>();
+        for (size_t j = tid; j < h; j += kBlock) {
+            Fr flo = fr_load(tf, j), fhi = fr_load(tf, j + h), glo, ghi, qv;
+            if (TWO) {
+                glo = fr_load(tg, j);
+                ghi = fr_load(tg, j + h);
+            }
+            round_pair<MODE>(flo, fhi, glo, ghi, r, acc, qv);
+            if (MODE == 3) fr_store(qbase, qoff + j, qv);
+            fr_store(tf, j, flo);
+            if (TWO) fr_store(tg, j, glo);
+        }
+        if (W != 0) {
+            Fr res;
+            bool has;
+            int which;
+            block_reduce_sums<NS>(acc, red, res, has, which);  // contains the barriers
+            if (has) fr_store(sums_out, (size_t)rd * W + which, res);
+        } else {
+            __syncthreads();
+        }
+        qoff += h;
+        m = h;
+    }
+    for (size_t i = tid; i < m; i += kBlock) {
+        fr_store(fo, i, fr_load(tf, i));
+        if (TWO) fr_store(go, i, fr_load(tg, i));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------
+static int ilog2(size_t x) {
+    int l = 0;
+    while (((size_t)1 << (l + 1)) <= x) l++;
+    return l;
+}
+
+template <int K, int MODE>
+static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void* go, size_t m, const uint64_t* chal,
+                       void* d_sums_at, void* qbase) {
+    constexpr int W = ModeTraits<MODE>::W;
+    const size_t q = m >> K;
+    size_t blocks = (q + kBlock - 1) / kBlock;
+    const size_t maxb = (size_t)ctx->cu_count * 4;
+    if (blocks > maxb) blocks = maxb;
+    ChalArgs ch;
+    std::memset(&ch, 0, sizeof(ch));
+    std::memcpy(&ch, chal, (size_t)K * 32);
+    void* partials = nullptr;
+    size_t lds = 0;
+    if (W != 0) {
+        partials = scratch(ctx, 4, (size_t)K * W * blocks * 32);
+        if (!partials) return ZK_ERR_OOM;
+        lds = (size_t)K * W * kBlock * 32;
+    }
+    hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
+                       qbase);
+    if (W != 0)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(K * W), dim3(kBlock), (size_t)kBlock * 32, ctx->stream, partials, blocks,
+                           d_sums_at);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+template <int MODE>
+static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, const uint64_t* h_chal, size_t rounds,
+                    uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q) {
+    constexpr int W = ModeTraits<MODE>::W;
+    constexpr bool TWO = ModeTraits<MODE>::TWO;
+    constexpr int KMAX = (MODE == 0 || MODE == 2) ? 3 : 2;
+    const size_t fr = 32;
+    // result block on device: [sums rounds*W][last_f][last_g]
+    const size_t res_elems = rounds * W + 2;
+    char* d_res = (char*)scratch(ctx, 5, res_elems * fr);
+    if (!d_res) return ZK_ERR_OOM;
+    void* d_last_f = d_res + rounds * W * fr;
+    void* d_last_g = d_res + (rounds * W + 1) * fr;
+    // challenges on device for the tail kernel
+    char* d_chal = (char*)scratch(ctx, 6, std::max<size_t>(rounds, 1) * fr);
+    if (!d_chal) return ZK_ERR_OOM;
+    if (rounds) ZK_HIP(ctx, hipMemcpyAsync(d_chal, h_chal, rounds * fr, hipMemcpyHostToDevice, ctx->stream));
+
+    const void* cf = d_f;
+    const void* cg = d_g;
+    size_t m = len, done = 0;
+    int flip = 0;
+    void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (len > kTailMax && rounds > 0) {
+        bufs[0] = scratch(ctx, 0, (len / 2) * fr);
+        bufs[1] = scratch(ctx, 1, (len / 4) * fr);
+        if (!bufs[0] || !bufs[1]) return ZK_ERR_OOM;
+        if (TWO) {
+            bufs[2] = scratch(ctx, 2, (len / 2) * fr);
+            bufs[3] = scratch(ctx, 3, (len / 4) * fr);
+            if (!bufs[2] || !bufs[3]) return ZK_ERR_OOM;
+        }
+    }
+    while (done < rounds && m > kTailMax) {
+        int k = (int)std::min<size_t>({(size_t)KMAX, rounds - done, (size_t)(ilog2(m) - ilog2(kTailMax))});
+        const bool final_out = (MODE == 2) && (done + k == rounds);
+        void* fo = final_out ? d_out : bufs[flip];
+        void* go = TWO ? bufs[2 + flip] : nullptr;
+        void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
+        void* sums_at = d_res + done * W * fr;
+        int rc;
+        if (k == 3) rc = launch_pass<(KMAX >= 3 ? 3 : 1), MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
+        else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
+        else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
+        if (rc) return rc;
+        cf = fo;
+        cg = go;
+        m >>= k;
+        done += k;
+        flip ^= 1;
+    }
+    if (done < rounds || MODE != 2) {
+        // tail: the remaining rounds (possibly zero) in one workgroup; also emits the final table
+        const int rl = (int)(rounds - done);
+        if (m > kTailMax) return fail(ctx, ZK_ERR_INVALID, "internal: tail too large");
+        size_t lds = (TWO ? 2 : 1) * m * fr + (size_t)(W ? W : 1) * kBlock * fr;
+        void* fo = (MODE == 2) ? d_out : d_last_f;
+        void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k_tail<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_tail<MODE>), dim3(1), dim3(kBlock), lds, ctx->stream, cf, cg, m, rl, (const void*)(d_chal + done * fr),
+                           (void*)(d_res + done * W * fr), qb, fo, d_last_g);
+        ZK_HIP(ctx, hipGetLastError());
+    } else if (rounds == 0) {
+        ZK_HIP(ctx, hipMemcpyAsync(d_out, d_f, len * fr, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (MODE != 2) {
+        char* h = (char*)pinned(ctx, res_elems * fr);
+        if (!h) return ZK_ERR_OOM;
+        ZK_HIP(ctx, hipMemcpyAsync(h, d_res, res_elems * fr, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_sums && rounds * W) std::memcpy(h_sums, h, rounds * W * fr);
+        if (h_last_f) std::memcpy(h_last_f, h + rounds * W * fr, fr);
+        if (TWO && h_last_g) std::memcpy(h_last_g, h + (rounds * W + 1) * fr, fr);
+    }
+    return ZK_OK;
+}
+
+int multilinear_run(zk_ctx* ctx, int mode, const void* d_f, const void* d_g, size_t len, const uint64_t* h_chal, size_t rounds,
+                    uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q) {
+    if (len == 0 || (len & (len - 1))) return fail(ctx, ZK_ERR_INVALID, "table length %zu is not a power of two", len);
+    if (rounds > (size_t)ilog2(len)) return fail(ctx, ZK_ERR_INVALID, "more rounds than variables");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    switch (mode) {
+        case 0: return run_mode<0>(ctx, d_f, d_g, len, h_chal, rounds, h_sums, h_last_f, h_last_g, d_out, d_q);
+        case 1: return run_mode<1>(ctx, d_f, d_g, len, h_chal, rounds, h_sums, h_last_f, h_last_g, d_out, d_q);
+        case 2: return run_mode<2>(ctx, d_f, d_g, len, h_chal, rounds, h_sums, h_last_f, h_last_g, d_out, d_q);
+        case 3: return run_mode<3>(ctx, d_f, d_g, len, h_chal, rounds, h_sums, h_last_f, h_last_g, d_out, d_q);
+    }
+    return fail(ctx, ZK_ERR_INVALID, "bad mode");
+}
+
+// ---------------------------------------------------------------------------------------
+// K6 product tree.  Level l >= 1 lives at tree[2N - 2N/2^l ...) with N/2^l elements and
+// element i of level l+1 = level_l[2i] * level_l[2i+1]  (sub_index, dacc_product.rs:18-23).
+// A 256-thread block owns 512 consecutive inputs of some level and produces up to 9 levels,
+// exchanging intermediate products through LDS; each level's outputs of a block are contiguous.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_tree(const void* __restrict__ x, void* __restrict__ tree, size_t N, int in_level,
+                                               size_t in_len, int levels, int copy_leaves) {
+    __shared__ uint4 buf[2 * kBlock];  // 256 Fr
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * 2 * kBlock;  // first input element of this block
+    const size_t i0 = base + 2 * (size_t)tid;
+    const size_t in_off = (in_level == 0) ? 0 : 2 * N - ((2 * N) >> in_level);
+    const void* src = (in_level == 0 && copy_leaves) ? x : tree;
+    Fr v = fp_zero<FrCfg>();
+    bool active = i0 + 1 < in_len + 0 || i0 + 1 == in_len - 0;  // i0+1 <= in_len-1
+    active = (i0 + 1) < in_len + 0;
+    if (i0 + 1 < in_len || i0 + 1 == in_len) active = (i0 + 1) <= in_len - 1;
+    if (active) {
+        Fr a = fr_load(src, (in_level == 0 && copy_leaves) ? i0 : in_off + i0);
+        Fr b = fr_load(src, (in_level == 0 && copy_leaves) ? i0 + 1 : in_off + i0 + 1);
+        if (copy_leaves) {
+            fr_store(tree, i0, a);
+            fr_store(tree, i0 + 1, b);
+        }
+        v = fr_mul(a, b);
+    }
+    // level in_level+1: this block's outputs are [base/2, base/2 + 256)
+    int lvl = in_level + 1;
+    size_t cnt = kBlock;  // number of outputs this block may hold at the current level
+    size_t lvl_len = in_len >> 1;
+    for (int step = 0; step < levels; step++) {
+        const size_t off = 2 * N - ((2 * N) >> lvl);
+        const size_t blk_first = (base >> (step + 1));
+        if ((size_t)tid < cnt && blk_first + tid < lvl_len) fr_store(tree, off + blk_first + tid, v);
+        if (step + 1 == levels) break;
+        fr_store(buf, tid, v);
+        __syncthreads();
+        cnt >>= 1;
+        lvl_len >>= 1;
+        lvl++;
+        if ((size_t)tid < cnt && (blk_first >> 1) + tid < lvl_len) v = fr_mul(fr_load(buf, 2 * tid), fr_load(buf, 2 * tid + 1));
+        __syncthreads();
+    }
+}
+
+__global__ void k_tree_finish(void* tree, size_t N) {
+    if (threadIdx.x == 0) fr_store(tree, 2 * N - 1, fp_zero<FrCfg>());
+}
+
+int product_tree(zk_ctx* ctx, const void* d_x, size_t N, void* d_tree) {
+    if (N == 0 || (N & (N - 1))) return fail(ctx, ZK_ERR_INVALID, "product tree size %zu is not a power of two", N);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    if (N == 1) {
+        // tree = x || x, then tree[1] = 0   (dacc_product.rs:32-38 with an empty loop)
+        ZK_HIP(ctx, hipMemcpyAsync(d_tree, d_x, 32, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_tree_finish, dim3(1), dim3(64), 0, ctx->stream, d_tree, N);
+        return ZK_OK;
+    }
+    const int total_levels = ilog2(N);  // levels 1..log2 N
+    int in_level = 0;
+    size_t in_len = N;
+    while (in_level < total_levels) {
+        int levels = std::min(9, total_levels - in_level);
+        size_t blocks = (in_len + 2 * kBlock - 1) / (2 * kBlock);
+        hipLaunchKernelGGL(k_tree, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, d_x, d_tree, N, in_level, in_len, levels,
+                           in_level == 0 ? 1 : 0);
+        in_level += levels;
+        in_len >>= levels;
+    }
+    hipLaunchKernelGGL(k_tree_finish, dim3(1), dim3(64), 0, ctx->stream, d_tree, N);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// K8 element-wise maps
+// ---------------------------------------------------------------------------------------
+template <int OP>
+__global__ void __launch_bounds__(kBlock) k_fr_binary(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ out,
+                                                    size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        Fr x = fr_load(a, i), y = fr_load(b, i);
+        Fr r = (OP == 0) ? fr_add(x, y) : (OP == 1) ? fr_sub(x, y) : fr_mul(x, y);
+        fr_store(out, i, r);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_fr_axpb(const void* __restrict__ a, const void* __restrict__ b, Fr alpha, Fr beta,
+                                                  void* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        Fr r = fr_add(fr_add(fr_load(a, i), fr_mul(alpha, fr_load(b, i))), beta);
+        fr_store(out, i, r);
+    }
+}
+template <class C, int OP>
+__global__ void __launch_bounds__(kBlock) k_fp_binary(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ out,
+                                                    size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        Fp<C> x = fp_load<C>(a, i), y = fp_load<C>(b, i);
+        Fp<C> r = (OP == 0) ? fp_add<C>(x, y) : (OP == 1) ? fp_sub<C>(x, y) : fp_mul<C>(x, y);
+        fp_store<C>(out, i, r);
+    }
+}
+
+static unsigned grid_for(zk_ctx* ctx, size_t n) {
+    size_t b = (n + kBlock - 1) / kBlock;
+    size_t maxb = (size_t)ctx->cu_count * 8;
+    return (unsigned)std::max<size_t>(1, std::min(b, maxb));
+}
+
+int fr_binary(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned g = grid_for(ctx, n);
+    if (op == 0) hipLaunchKernelGGL((k_fr_binary<0>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
+    else if (op == 1) hipLaunchKernelGGL((k_fr_binary<1>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
+    else hipLaunchKernelGGL((k_fr_binary<2>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned g = grid_for(ctx, n);
+    if (op == 0) hipLaunchKernelGGL((k_fp_binary<FqCfg, 0>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
+    else if (op == 1) hipLaunchKernelGGL((k_fp_binary<FqCfg, 1>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
+    else hipLaunchKernelGGL((k_fp_binary<FqCfg, 2>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+int fr_axpb(zk_ctx* ctx, const void* a, const void* b, const uint64_t* alpha, const uint64_t* beta, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    Fr al, be;
+    std::memcpy(&al, alpha, 32);
+    std::memcpy(&be, beta, 32);
+    hipLaunchKernelGGL(k_fr_axpb, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, a, b, al, be, out, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// batched division out = num / den (dhyperplonk.rs:339).  Montgomery's trick per thread over
+// CH strided elements (coalesced: element k of thread t is t + k*T), prefix products parked in
+// `out`, one Fermat inversion per thread.  Identical result to per-element inverse().
+// ---------------------------------------------------------------------------------------
+static constexpr int kDivChunk = 16;
+__global__ void __launch_bounds__(kBlock) k_batch_div(const void* __restrict__ num, const void* __restrict__ den,
+                                                    void* __restrict__ out, size_t n, size_t T, int* __restrict__ zero_flag) {
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= T) return;
+    Fr p = fp_one<FrCfg>();
+    int cnt = 0;
+    bool zero = false;
+    for (int k = 0; k < kDivChunk; k++) {
+        size_t i = t + (size_t)k * T;
+        if (i >= n) break;
+        Fr d = fr_load(den, i);
+        zero |= fp_is_zero<FrCfg>(d);
+        fr_store(out, i, p);  // prefix product BEFORE element k
+        p = fr_mul(p, d);
+        cnt++;
+    }
+    if (zero) {
+        atomicOr(zero_flag, 1);
+        return;
+    }
+    Fr inv = fp_inv<FrCfg>(p);
+    for (int k = cnt - 1; k >= 0; k--) {
+        size_t i = t + (size_t)k * T;
+        Fr pre = fr_load(out, i);
+        Fr di = fr_mul(inv, pre);  // 1/den_k
+        inv = fr_mul(inv, fr_load(den, i));
+        fr_store(out, i, fr_mul(fr_load(num, i), di));
+    }
+}
+
+int fr_batch_div(zk_ctx* ctx, const void* num, const void* den, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    if (out == den || out == num) return fail(ctx, ZK_ERR_INVALID, "zk_fr_batch_div: out must not alias an input");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    int* flag = (int*)scratch(ctx, 6, 256);
+    if (!flag) return ZK_ERR_OOM;
+    ZK_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    size_t T = (n + kDivChunk - 1) / kDivChunk;
+    hipLaunchKernelGGL(k_batch_div, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, num, den, out, n, T,
+                       flag);
+    int h = 0;
+    ZK_HIP(ctx, hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h) return fail(ctx, ZK_ERR_DIV_ZERO, "zero denominator");
+    return ZK_OK;
+}
+
+}  // namespace zk

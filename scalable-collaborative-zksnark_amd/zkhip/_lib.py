@@ -1,0 +1,85 @@
+"""
+ctypes binding of libzkhip.so (include/zkhip.h).  The library is the product; there is no
+Python/CPU fallback: if it is missing or has no usable GPU, loading/creating a context raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_ROOT, "libzkhip.so")
+CSRC = os.path.join(_ROOT, "csrc")
+
+# every symbol include/zkhip.h declares: (name, restype, argtypes)
+_vp, _sz, _i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+_pp = ctypes.POINTER(ctypes.c_void_p)
+SYMBOLS = [
+    ("zk_ctx_create", _i, [_i, _pp]),
+    ("zk_ctx_destroy", None, [_vp]),
+    ("zk_last_error", ctypes.c_char_p, [_vp]),
+    ("zk_ctx_set_stream", _i, [_vp, _vp]),
+    ("zk_ctx_sync", _i, [_vp]),
+    ("zk_version", ctypes.c_char_p, []),
+    ("zk_malloc", _i, [_vp, _sz, _pp]),
+    ("zk_free", _i, [_vp, _vp]),
+    ("zk_memcpy_h2d", _i, [_vp, _vp, _vp, _sz]),
+    ("zk_memcpy_d2h", _i, [_vp, _vp, _vp, _sz]),
+    ("zk_fr_add", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("zk_fr_sub", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("zk_fr_mul", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("zk_fr_axpb", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    ("zk_fr_batch_div", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("zk_sumcheck", _i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    ("zk_sumcheck_product", _i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    ("zk_fold", _i, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    ("zk_open_rounds", _i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    ("zk_product_tree", _i, [_vp, _vp, _sz, _vp]),
+    ("zk_srs_register", _i, [_vp, _vp, _sz, _sz, _pp]),
+    ("zk_srs_wrap_device", _i, [_vp, _vp, _sz, _pp]),
+    ("zk_srs_generate", _i, [_vp, _vp, _vp, _sz, _pp]),
+    ("zk_srs_free", _i, [_vp, _vp]),
+    ("zk_srs_len", _sz, [_vp]),
+    ("zk_srs_device_ptr", _vp, [_vp]),
+    ("zk_msm_g1", _i, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    ("zk_msm_g1_host", _i, [_vp, _vp, _sz, _sz, _vp, _sz, _vp, ctypes.POINTER(ctypes.c_size_t)]),
+    ("zk_msm_window", _i, [_sz]),
+    ("zk_msm_set_window", _i, [_vp, _i]),
+    ("zk_msm_last_timing", _i, [_vp, _vp]),
+    ("zk_dbg_fq_mul", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("zk_dbg_fq_add", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("zk_dbg_fq_sub", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("zk_dbg_g1_op", _i, [_vp, _i, _vp, _vp, _vp, _sz]),
+]
+
+ZK_OK, ZK_ERR_INVALID, ZK_ERR_LENGTH, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_DIV_ZERO, ZK_ERR_OOM = 0, -1, -2, -3, -4, -5, -6
+
+
+def build(force: bool = False) -> str:
+    """compile libzkhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)"""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """load libzkhip.so; raises if it is not built (no fallback path exists)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python __graft_entry__.py build` (or `make -C {CSRC}`). "
+                "zkhip has no CPU fallback."
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(l, name)  # AttributeError here = header/library mismatch
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib

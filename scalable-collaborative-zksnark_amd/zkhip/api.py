@@ -1,0 +1,282 @@
+"""
+Thin object wrapper over the C ABI: `Ctx` = one GPU (zk_ctx), `DeviceBuffer`, `Srs`.
+Arguments that name device memory accept a DeviceBuffer, a torch CUDA tensor (data_ptr) or a
+raw integer address.  Host-side results come back as numpy uint64 limb arrays.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import ZK_ERR_DIV_ZERO, ZK_ERR_LENGTH
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"zkhip error {code}: {msg}")
+        self.code = code
+
+
+class MsmLengthError(ZkError):
+    """`G::msm` -> Err(min_len) (ark-ec 0.4.2), which dmsm.rs:23 unwrap()s"""
+
+    def __init__(self, code, msg, min_len):
+        super().__init__(code, msg)
+        self.min_len = min_len
+
+
+def _ptr(x) -> int:
+    if x is None:
+        return 0
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):  # torch tensor
+        return int(x.data_ptr())
+    raise TypeError(f"not a device buffer: {type(x)}")
+
+
+def _h(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+class DeviceBuffer:
+    def __init__(self, ctx: "Ctx", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = nbytes
+        p = ctypes.c_void_p()
+        ctx._check(ctx.lib.zk_malloc(ctx.h, nbytes, ctypes.byref(p)))
+        self.ptr = p.value or 0
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.zk_free(self.ctx.h, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, a: np.ndarray, offset: int = 0):
+        a = np.ascontiguousarray(a)
+        assert offset + a.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.zk_memcpy_h2d(self.ctx.h, self.ptr + offset, _h(a), a.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.uint64, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.zk_memcpy_d2h(self.ctx.h, _h(out), self.ptr + offset, out.nbytes))
+        return out
+
+    def at(self, byte_offset: int) -> int:
+        return self.ptr + byte_offset
+
+
+class Srs:
+    def __init__(self, ctx: "Ctx", handle: int):
+        self.ctx, self.h = ctx, handle
+
+    def __len__(self):
+        return self.ctx.lib.zk_srs_len(self.h)
+
+    @property
+    def device_ptr(self) -> int:
+        return self.ctx.lib.zk_srs_device_ptr(self.h) or 0
+
+    def download(self) -> np.ndarray:
+        n = len(self)
+        out = np.empty((n, 12), dtype=np.uint64)
+        if n:
+            self.ctx._check(self.ctx.lib.zk_memcpy_d2h(self.ctx.h, _h(out), self.device_ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.zk_srs_free(self.ctx.h, self.h)
+            self.h = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Ctx:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.lib()
+        h = ctypes.c_void_p()
+        rc = self.lib.zk_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise ZkError(rc, "zk_ctx_create failed (no MI355X visible?) -- zkhip has no CPU fallback")
+        self.h = h.value
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise ZkError(rc, (self.lib.zk_last_error(self.h) or b"").decode())
+
+    def set_stream(self, hip_stream: int):
+        self._check(self.lib.zk_ctx_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        self._check(self.lib.zk_ctx_sync(self.h))
+
+    # ---- memory ----
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, a: np.ndarray) -> DeviceBuffer:
+        a = np.ascontiguousarray(a)
+        return DeviceBuffer(self, max(a.nbytes, 1)).upload(a) if a.nbytes else DeviceBuffer(self, 1)
+
+    # ---- element-wise ----
+    def _binary(self, fn, a, b, n, out=None) -> DeviceBuffer:
+        out = out or self.alloc(max(32 * n, 1))
+        self._check(fn(self.h, _ptr(a), _ptr(b), _ptr(out), n))
+        return out
+
+    def fr_add(self, a, b, n, out=None):
+        return self._binary(self.lib.zk_fr_add, a, b, n, out)
+
+    def fr_sub(self, a, b, n, out=None):
+        return self._binary(self.lib.zk_fr_sub, a, b, n, out)
+
+    def fr_mul(self, a, b, n, out=None):
+        return self._binary(self.lib.zk_fr_mul, a, b, n, out)
+
+    def fr_batch_div(self, num, den, n, out=None):
+        out = out or self.alloc(max(32 * n, 1))
+        rc = self.lib.zk_fr_batch_div(self.h, _ptr(num), _ptr(den), _ptr(out), n)
+        if rc == ZK_ERR_DIV_ZERO:
+            raise ZeroDivisionError("zero denominator (the reference panics on inverse().unwrap())")
+        self._check(rc)
+        return out
+
+    def fr_axpb(self, a, b, alpha: np.ndarray, beta: np.ndarray, n, out=None):
+        out = out or self.alloc(max(32 * n, 1))
+        al, be = np.ascontiguousarray(alpha, dtype=np.uint64), np.ascontiguousarray(beta, dtype=np.uint64)
+        self._check(self.lib.zk_fr_axpb(self.h, _ptr(a), _ptr(b), _h(al), _h(be), _ptr(out), n))
+        return out
+
+    # ---- sumcheck family ----
+    def sumcheck(self, tab, length: int, chal: np.ndarray):
+        """-> (pairs [n,2,4], last [4])"""
+        n = length.bit_length() - 1
+        chal = np.ascontiguousarray(chal, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((n, 2, 4), dtype=np.uint64)
+        last = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.zk_sumcheck(self.h, _ptr(tab), length, _h(chal), _h(out), _h(last)))
+        return out, last
+
+    def sumcheck_product(self, f, g, length: int, chal: np.ndarray):
+        """-> (triples [n,3,4], last_f [4], last_g [4])"""
+        n = length.bit_length() - 1
+        chal = np.ascontiguousarray(chal, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((n, 3, 4), dtype=np.uint64)
+        lf = np.zeros(4, dtype=np.uint64)
+        lg = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.zk_sumcheck_product(self.h, _ptr(f), _ptr(g), length, _h(chal), _h(out), _h(lf), _h(lg)))
+        return out, lf, lg
+
+    def fold(self, tab, length: int, points: np.ndarray, out=None):
+        points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 4)
+        n = length.bit_length() - 1
+        rounds = min(n, len(points))
+        out = out or self.alloc(32 * (length >> rounds))
+        self._check(self.lib.zk_fold(self.h, _ptr(tab), length, _h(points), len(points), _ptr(out)))
+        return out
+
+    def open_rounds(self, tab, length: int, point: np.ndarray, q_out=None):
+        """-> (q device buffer with length-1 Fr, value [4])"""
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        q_out = q_out or self.alloc(max(32 * (length - 1), 1))
+        val = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.zk_open_rounds(self.h, _ptr(tab), length, _h(point), _ptr(q_out), _h(val)))
+        return q_out, val
+
+    def product_tree(self, x, N: int, out=None):
+        out = out or self.alloc(64 * N)
+        self._check(self.lib.zk_product_tree(self.h, _ptr(x), N, _ptr(out)))
+        return out
+
+    # ---- MSM ----
+    def srs_register(self, bases: np.ndarray, stride: int = 96) -> Srs:
+        b = np.ascontiguousarray(bases)
+        n = b.nbytes // stride
+        h = ctypes.c_void_p()
+        self._check(self.lib.zk_srs_register(self.h, _h(b), stride, n, ctypes.byref(h)))
+        return Srs(self, h.value)
+
+    def srs_wrap_device(self, d_bases, n: int) -> Srs:
+        h = ctypes.c_void_p()
+        self._check(self.lib.zk_srs_wrap_device(self.h, _ptr(d_bases), n, ctypes.byref(h)))
+        return Srs(self, h.value)
+
+    def srs_generate(self, k0: int, k1: int, n: int) -> Srs:
+        from .field import int_to_limbs
+
+        a, b = int_to_limbs(k0, 4), int_to_limbs(k1, 4)
+        h = ctypes.c_void_p()
+        self._check(self.lib.zk_srs_generate(self.h, _h(a), _h(b), n, ctypes.byref(h)))
+        return Srs(self, h.value)
+
+    def msm_g1(self, srs: Srs, scalars, n: int, offset: int = 0) -> np.ndarray:
+        """-> normalised Jacobian [18] uint64"""
+        out = np.zeros(18, dtype=np.uint64)
+        rc = self.lib.zk_msm_g1(self.h, srs.h, offset, _ptr(scalars), n, _h(out))
+        if rc == ZK_ERR_LENGTH:
+            raise MsmLengthError(rc, (self.lib.zk_last_error(self.h) or b"").decode(), min(n, max(len(srs) - offset, 0)))
+        self._check(rc)
+        return out
+
+    def msm_g1_host(self, bases: np.ndarray, scalars: np.ndarray, stride: int = 96) -> np.ndarray:
+        """drop-in for G::msm(&[Affine], &[Fr]) on host arrays"""
+        b = np.ascontiguousarray(bases)
+        s = np.ascontiguousarray(scalars, dtype=np.uint64)
+        nb, ns = b.nbytes // stride, s.size // 4
+        out = np.zeros(18, dtype=np.uint64)
+        err = ctypes.c_size_t(0)
+        rc = self.lib.zk_msm_g1_host(self.h, _h(b), stride, nb, _h(s), ns, _h(out), ctypes.byref(err))
+        if rc == ZK_ERR_LENGTH:
+            raise MsmLengthError(rc, (self.lib.zk_last_error(self.h) or b"").decode(), err.value)
+        self._check(rc)
+        return out
+
+    def msm_set_window(self, c: int):
+        self._check(self.lib.zk_msm_set_window(self.h, c))
+
+    def msm_last_timing(self) -> np.ndarray:
+        t = np.zeros(5, dtype=np.float32)
+        self._check(self.lib.zk_msm_last_timing(self.h, _h(t)))
+        return t
+
+    # ---- test hooks ----
+    def dbg_fq(self, op: str, a, b, n, out=None):
+        fn = {"add": self.lib.zk_dbg_fq_add, "sub": self.lib.zk_dbg_fq_sub, "mul": self.lib.zk_dbg_fq_mul}[op]
+        out = out or self.alloc(max(48 * n, 1))
+        self._check(fn(self.h, _ptr(a), _ptr(b), _ptr(out), n))
+        return out
+
+    def dbg_g1_op(self, mode: int, p, q, n) -> np.ndarray:
+        out = np.zeros((n, 18), dtype=np.uint64)
+        self._check(self.lib.zk_dbg_g1_op(self.h, mode, _ptr(p), _ptr(q), _h(out), n))
+        return out

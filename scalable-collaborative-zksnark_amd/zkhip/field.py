@@ -1,0 +1,85 @@
+"""
+numpy helpers for the reference's memory layouts (no arithmetic: that is the library's job).
+Fr = [.., 4] uint64 Montgomery limbs; Fq = [.., 6]; affine G1 = [.., 12] (x||y, zeros = infinity).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+Q_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+_M64 = (1 << 64) - 1
+_R_LIMBS = np.array([(R_MOD >> (64 * i)) & _M64 for i in range(4)], dtype=np.uint64)
+
+
+def int_to_limbs(x: int, n: int) -> np.ndarray:
+    return np.array([(x >> (64 * i)) & _M64 for i in range(n)], dtype=np.uint64)
+
+
+def limbs_to_int(a) -> int:
+    a = np.asarray(a, dtype=np.uint64).reshape(-1)
+    return sum(int(a[i]) << (64 * i) for i in range(a.size))
+
+
+def fr_mont(x: int) -> np.ndarray:
+    """Montgomery limbs of the field element x (host big-int; for scalars like challenges)"""
+    return int_to_limbs((x % R_MOD) * (1 << 256) % R_MOD, 4)
+
+
+def fr_from_mont(a) -> int:
+    return limbs_to_int(a) * pow(1 << 256, -1, R_MOD) % R_MOD
+
+
+def fq_mont(x: int) -> np.ndarray:
+    return int_to_limbs((x % Q_MOD) * (1 << 384) % Q_MOD, 6)
+
+
+def fq_from_mont(a) -> int:
+    return limbs_to_int(a) * pow(1 << 384, -1, Q_MOD) % Q_MOD
+
+
+def random_fr(n: int, seed: int) -> np.ndarray:
+    """
+    n uniform field elements as [n,4] uint64 limbs < r (what `random_evaluations`,
+    dist-primitive/src/lib.rs:13-18, produces: any canonical limb pattern is the Montgomery
+    form of a uniform element).  Vectorised rejection sampling, seeded.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.empty((n, 4), dtype=np.uint64)
+    filled = 0
+    while filled < n:
+        m = max(16, int((n - filled) * 1.15) + 8)
+        cand = rng.integers(0, 1 << 64, size=(m, 4), dtype=np.uint64)
+        cand[:, 3] &= np.uint64(0x7FFFFFFFFFFFFFFF)
+        # lexicographic compare with r from the top limb down
+        lt = np.zeros(m, dtype=bool)
+        eq = np.ones(m, dtype=bool)
+        for k in (3, 2, 1, 0):
+            lt |= eq & (cand[:, k] < _R_LIMBS[k])
+            eq &= cand[:, k] == _R_LIMBS[k]
+        good = cand[lt]
+        take = min(len(good), n - filled)
+        out[filled : filled + take] = good[:take]
+        filled += take
+    return out
+
+
+def jacobian_to_affine_ints(j18):
+    """normalised Jacobian (18 u64, as returned by zk_msm_g1) -> (x, y) ints or None"""
+    j = np.asarray(j18, dtype=np.uint64).reshape(18)
+    if not j[12:].any():
+        return None
+    return (fq_from_mont(j[0:6]), fq_from_mont(j[6:12]))
+
+
+def affine_mont_to_ints(a12):
+    a = np.asarray(a12, dtype=np.uint64).reshape(12)
+    if not a.any():
+        return None
+    return (fq_from_mont(a[:6]), fq_from_mont(a[6:]))
+
+
+def affine_ints_to_mont(P) -> np.ndarray:
+    if P is None:
+        return np.zeros(12, dtype=np.uint64)
+    return np.concatenate([fq_mont(P[0]), fq_mont(P[1])])

@@ -1,0 +1,101 @@
+"""GPU parity: G1 MSM (zk_msm_g1 / zk_msm_g1_host) vs the CPU oracle, bit-exact on the affine point."""
+import numpy as np
+import pytest
+
+from helpers import jac_norm_to_affine, pt_mont, rand_fr, synthetic_bases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 257, 1000, 4096, 1 << 14])
+def test_msm_matches_oracle(ctx, co, n):
+    bases, _ = synthetic_bases(n, 40 + n)
+    scalars = rand_fr(n, 50 + n)
+    srs = ctx.srs_register(bases)
+    got = ctx.msm_g1(srs, ctx.to_device(scalars), n)
+    assert (jac_norm_to_affine(got) == co.msm_g1(bases, scalars)).all()
+
+
+@pytest.mark.parametrize("c", [4, 7, 8, 11, 13, 15, 16])
+def test_msm_all_window_sizes(ctx, co, c):
+    n = 3000
+    bases, _ = synthetic_bases(n, 77)
+    scalars = rand_fr(n, 78)
+    srs = ctx.srs_register(bases)
+    exp = co.msm_g1(bases, scalars)
+    ctx.msm_set_window(c)
+    try:
+        got = ctx.msm_g1(srs, ctx.to_device(scalars), n)
+    finally:
+        ctx.msm_set_window(0)
+    assert (jac_norm_to_affine(got) == exp).all()
+
+
+def test_msm_edge_cases(ctx, co):
+    import pyoracle as po
+
+    n = 64
+    bases, _ = synthetic_bases(n, 91)
+    scalars = rand_fr(n, 92)
+    # zero scalars, scalar = 1, scalar = r-1, repeated points, opposite points, infinity bases
+    scalars[0] = 0
+    scalars[1] = po.fr_to_mont_limbs(1)
+    scalars[2] = po.fr_to_mont_limbs(po.R_MOD - 1)
+    bases[4] = bases[3]
+    scalars[4] = scalars[3]  # same point, same scalar -> same bucket (doubling path)
+    bases[6] = bases[5]
+    scalars[6] = co.fr_sub(np.zeros((1, 4), dtype=np.uint64), scalars[5:6])[0]  # s and -s on the same point
+    bases[7] = 0  # infinity
+    srs = ctx.srs_register(bases)
+    got = ctx.msm_g1(srs, ctx.to_device(scalars), n)
+    assert (jac_norm_to_affine(got) == co.msm_g1(bases, scalars)).all()
+    # all-zero scalars -> infinity; n = 0 -> infinity
+    z = np.zeros((n, 4), dtype=np.uint64)
+    assert not jac_norm_to_affine(ctx.msm_g1(srs, ctx.to_device(z), n)).any()
+    assert not jac_norm_to_affine(ctx.msm_g1(srs, ctx.to_device(z), 0)).any()
+    # all scalars equal (one bucket per window holds everything)
+    same = np.tile(scalars[9], (n, 1))
+    assert (jac_norm_to_affine(ctx.msm_g1(srs, ctx.to_device(same), n)) == co.msm_g1(bases, same)).all()
+
+
+def test_msm_host_dropin_and_length_error(ctx, co):
+    import zkhip
+
+    n = 200
+    bases, _ = synthetic_bases(n, 93)
+    scalars = rand_fr(n, 94)
+    exp = co.msm_g1(bases, scalars)
+    assert (jac_norm_to_affine(ctx.msm_g1_host(bases, scalars)) == exp).all()
+    # Rust struct layout: stride 104 with the infinity flag byte
+    b104 = np.zeros((n, 104), dtype=np.uint8)
+    b104[:, :96] = bases.view(np.uint8).reshape(n, 96)
+    b104[10, 96] = 1  # flagged infinity (coordinates left in place, as ark does not clear them)
+    bases_inf = bases.copy()
+    bases_inf[10] = 0
+    assert (jac_norm_to_affine(ctx.msm_g1_host(b104, scalars, stride=104)) == co.msm_g1(bases_inf, scalars)).all()
+    # G::msm -> Err(min_len) when the slices differ in length (ark-ec 0.4.2), dmsm.rs:23
+    with pytest.raises(zkhip.MsmLengthError) as ei:
+        ctx.msm_g1_host(bases[:150], scalars)
+    assert ei.value.min_len == 150
+
+
+def test_srs_generate_matches_oracle_points(ctx, co):
+    import pyoracle as po
+
+    n = 1500
+    bases, (k0, k1) = synthetic_bases(n, 95)
+    srs = ctx.srs_generate(k0, k1, n)
+    assert (srs.download() == bases).all()
+
+
+def test_msm_linearity_property_large(ctx, co):
+    """size-independent property at 2^18: MSM(b, s1) + MSM(b, s2) == MSM(b, s1 + s2)"""
+    n = 1 << 18
+    srs = ctx.srs_generate(12345, 67891, n)
+    s1, s2 = rand_fr(n, 96), rand_fr(n, 97)
+    d1, d2 = ctx.to_device(s1), ctx.to_device(s2)
+    d3 = ctx.fr_add(d1, d2, n)
+    r1 = jac_norm_to_affine(ctx.msm_g1(srs, d1, n))
+    r2 = jac_norm_to_affine(ctx.msm_g1(srs, d2, n))
+    r3 = jac_norm_to_affine(ctx.msm_g1(srs, d3, n))
+    assert (co.g1_add_affine(r1, r2) == r3).all()

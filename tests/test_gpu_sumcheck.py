@@ -1,0 +1,69 @@
+"""GPU parity: sumcheck family, fold, open quotients, product tree vs the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+from helpers import rand_fr
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 4, 64, 2048, 4096, 8192, 1 << 15, 1 << 17]
+
+
+@pytest.mark.parametrize("length", SIZES)
+def test_sumcheck(ctx, co, length):
+    n = length.bit_length() - 1
+    tab, chal = rand_fr(length, 100 + n), rand_fr(max(n, 1), 200 + n)
+    pairs, last = ctx.sumcheck(ctx.to_device(tab), length, chal)
+    exp = co.sumcheck(tab, chal)  # [n+1,2,4], last entry (0, last)
+    assert (pairs == exp[:n]).all()
+    assert (last == exp[n, 1]).all() and not exp[n, 0].any()
+
+
+@pytest.mark.parametrize("length", SIZES)
+def test_sumcheck_product(ctx, co, length):
+    n = length.bit_length() - 1
+    f, g, chal = rand_fr(length, 300 + n), rand_fr(length, 400 + n), rand_fr(max(n, 1), 500 + n)
+    triples, lf, lg = ctx.sumcheck_product(ctx.to_device(f), ctx.to_device(g), length, chal)
+    exp, elf, elg = co.sumcheck_product_rounds(f, g, chal)
+    assert (triples == exp).all()
+    assert (lf == elf).all() and (lg == elg).all()
+
+
+@pytest.mark.parametrize("length,npts", [(1, 0), (8, 0), (8, 2), (8, 3), (8, 5), (4096, 2), (1 << 14, 2), (1 << 14, 14), (1 << 16, 5), (1 << 16, 9)])
+def test_fold(ctx, co, length, npts):
+    n = length.bit_length() - 1
+    tab, pts = rand_fr(length, 600 + n), rand_fr(max(npts, 1), 700 + npts)[:npts]
+    rounds = min(n, npts)
+    got = ctx.fold(ctx.to_device(tab), length, pts).download((length >> rounds, 4))
+    cur = tab
+    for i in range(rounds):
+        cur = co.fold(cur, pts[i])
+    assert (got == cur).all()
+
+
+@pytest.mark.parametrize("length", SIZES)
+def test_open_rounds(ctx, co, length):
+    n = length.bit_length() - 1
+    tab, pt = rand_fr(length, 800 + n), rand_fr(max(n, 1), 900 + n)
+    q, val = ctx.open_rounds(ctx.to_device(tab), length, pt)
+    eq, ev = co.open_quotients(tab, pt)
+    assert (val == ev).all()
+    if length > 1:
+        assert (q.download((length - 1, 4)) == eq).all()
+
+
+@pytest.mark.parametrize("N", [1, 2, 4, 8, 256, 512, 1024, 1 << 13, 1 << 16])
+def test_product_tree(ctx, co, N):
+    x = rand_fr(N, 1000 + N)
+    got = ctx.product_tree(ctx.to_device(x), N).download((2 * N, 4))
+    assert (got == co.product_tree(x)).all()
+
+
+def test_product_tree_reference_kat(ctx, co):
+    """dacc_product.rs:450-466: input [1,2,3,4] -> ([1,3,2,24],[2,4,12,0],[2,12,24,0])"""
+    import pyoracle as po
+
+    x = np.array([po.fr_to_mont_limbs(v) for v in (1, 2, 3, 4)], dtype=np.uint64)
+    tree = ctx.product_tree(ctx.to_device(x), 4).download((8, 4))
+    vals = [po.fr_from_mont_limbs(t) for t in tree]
+    assert vals[0::2] == [1, 3, 2, 24] and vals[1::2] == [2, 4, 12, 0] and vals[4:] == [2, 12, 24, 0]
