@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""
+bench.py -- the reference's headline metric on MI355X: d_msm G1 scalar-muls/s (+ d_sumcheck Fr
+field-ops/s) at 2^20 shares (BASELINE.json configs[1]/[2]).
+
+A "step" = one party's d_msm on 2^20 packed BLS12-381 G1 shares: the local `G::msm`
+(dist-primitive/src/dmsm.rs:19-24) on HBM-resident bases and scalars, followed -- when more
+than one rank runs -- by the d_msm exchange (dmsm.rs:29-40) as one RCCL all-gather of the
+144-byte results plus the replicated public linear map (at 8 ranks this is exactly the l = 1,
+8-party d_msm).  One process per GPU, rank = party: per-GPU work is fixed => "scaling": "weak".
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = bucket accumulation, HIP-event
+timed inside the library on its own stream) and `cpu_baseline` (oracle = C port of the
+reference's single-threaded ark-ec Pippenger, timed on the host cores of this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd"))
+
+import numpy as np  # noqa: E402
+
+LOG2_N = 20
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FQ_MUL_PEAK = 60.0e9  # measured Fq Montgomery mul/s, whole chip (profiles/r01_ubench_int_alu.txt)
+FR_MUL_PEAK = 133.0e9  # measured Fr Montgomery mul/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=LOG2_N)
+    ap.add_argument("--cpu-log2n", type=int, default=17, help="size of the bounded CPU-baseline MSM sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import zkhip
+    from zkhip.field import random_fr
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = 1 << args.log2n
+    ctx = zkhip.Ctx(local_rank)  # raises if libzkhip.so / the GPU is missing (no fallback)
+
+    # ---- synthetic inputs, resident in HBM before the timed region ----
+    seed = 0x5CA1AB1E + 1000 * 2 + rank
+    srs = ctx.srs_generate(0x1234567 + rank, 0x89ABCDE + 7 * rank, n)  # P_i = (k0 + i k1) G
+    scal_np = random_fr(n, seed)
+    scalars = torch.from_numpy(scal_np.view(np.int64)).to(dev)
+    f_t = torch.from_numpy(random_fr(n, seed + 1).view(np.int64)).to(dev)
+    g_t = torch.from_numpy(random_fr(n, seed + 2).view(np.int64)).to(dev)
+    chal = random_fr(args.log2n, seed + 3)
+    torch.cuda.synchronize()
+
+    net = pp = None
+    if world > 1:
+        from zkhip.net import TorchDistNet
+        from zkhip.pss import PackedSharingParams
+
+        net = TorchDistNet(device=dev)
+        pp = PackedSharingParams(1) if world == 8 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if world == 1:
+            return ctx.msm_g1(srs, scalars, n)
+        if pp is not None:  # the full 8-party d_msm
+            from zkhip.dist_primitive import d_msm
+
+            return d_msm(ctx, [srs], [scalars], [n], pp, net)
+        local = ctx.msm_g1(srs, scalars, n)
+        net.all_gather(local)  # partial party set: the exchange only
+        return local
+
+    for _ in range(args.warmup):
+        step()
+    phase = np.zeros(5)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        phase += ctx.msm_last_timing()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    phase /= max(args.steps, 1)
+
+    # ---- secondary metric: d_sumcheck_product Phase-1 at 2^20 (dsumcheck.rs:377-429) ----
+    for _ in range(2):
+        ctx.sumcheck_product(f_t, g_t, n, chal)
+    barrier()
+    s0 = time.perf_counter()
+    sc_reps = max(args.steps, 1)
+    for _ in range(sc_reps):
+        ctx.sumcheck_product(f_t, g_t, n, chal)
+    barrier()
+    sc_dt = (time.perf_counter() - s0) / sc_reps
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = world * n * args.steps / dt
+    accum_ms = float(phase[1])
+    alg_bytes = 128.0 * n  # 96-B affine point + 32-B scalar per scalar-mul, read once
+    achieved = alg_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
+    c = ctx.lib.zk_msm_window(n)
+    windows = (255 + c - 1) // c
+    fq_mul_equiv = n * windows * 10.0  # one XYZZ mixed add (8M + 2S) per point per window
+    out = {
+        "metric": "G1 scalar-muls/sec (d_msm) + Fr field-ops/sec (d_sumcheck), 2^20 shares, 1/2/4/8 GPU",
+        "value": value,
+        "unit": "G1 scalar-muls/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"d_msm on 2^{args.log2n} packed BLS12-381 G1 shares per party (BASELINE.json configs[1]), l=1",
+            "points_per_party": n,
+            "parties": world,
+            "exchange": "none" if world == 1 else ("d_msm all-gather + PSS unpack2/pack map" if world == 8 else "all-gather only (partial party set)"),
+            "pippenger_window_bits": c,
+        },
+        "msm_phase_ms": {"digits_sort": float(phase[0]), "bucket_accumulate": accum_ms, "bucket_reduce": float(phase[2]), "host_combine": float(phase[3])},
+        "roofline": {
+            "kernel": "k_accum (bucket accumulation)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "note": "integer-VALU bound, not HBM bound: see int_alu",
+            "int_alu": {
+                "achieved_fq_mul_per_s": fq_mul_equiv / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,
+                "measured_peak_fq_mul_per_s": FQ_MUL_PEAK,
+                "frac": (fq_mul_equiv / (accum_ms * 1e-3) / FQ_MUL_PEAK) if accum_ms > 0 else 0.0,
+            },
+        },
+        "sumcheck": {
+            "workload": f"d_sumcheck_product phase 1, 2^{args.log2n} Fr shares x 2 tables, {args.log2n} rounds",
+            "ms": sc_dt * 1e3,
+            "fr_field_ops_per_s": 18.0 * n / sc_dt,  # reference op count: 9N mul + 9N add
+            "fr_mul_as_written_per_s": 9.0 * n / sc_dt,
+            "hbm_algorithmic_GBps": 64.0 * n / sc_dt / 1e9,
+            "hbm_frac": 64.0 * n / sc_dt / 1e9 / HBM_PEAK_GBS,
+        },
+    }
+
+    if not args.no_cpu:
+        # CPU baseline leg: the oracle (C port of the reference's single-threaded path) on this
+        # box's host cores.  Checker/baseline only -- never part of the measured GPU path.
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import coracle as co
+
+        m = 1 << args.cpu_log2n
+        bases_h = srs.download()[:m].copy()
+        sc_h = scal_np[:m].copy()
+        t = time.perf_counter()
+        ref = co.msm_g1(bases_h, sc_h)
+        cpu_dt = time.perf_counter() - t
+        got = ctx.msm_g1(srs, ctx.to_device(sc_h), m)
+        assert (got[:12] == ref).all(), "GPU MSM differs from the CPU oracle on the baseline sample"
+        t = time.perf_counter()
+        co.sumcheck_product(np.ascontiguousarray(f_t.cpu().numpy().view(np.uint64)[: 1 << 18]), np.ascontiguousarray(g_t.cpu().numpy().view(np.uint64)[: 1 << 18]), chal[:18])
+        cpu_sc = time.perf_counter() - t
+        out["cpu_baseline"] = {
+            "value": m / cpu_dt,
+            "unit": "G1 scalar-muls/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"one MSM of 2^{args.cpu_log2n} of the same bases/scalars (ark-ec window rule c={co.msm_window(m)}), {cpu_dt:.1f} s; result bit-identical to the GPU",
+            "sumcheck_fr_field_ops_per_s": 18.0 * (1 << 18) / cpu_sc,
+            "sumcheck_sample": f"sumcheck_product on 2^18 of the same tables, {cpu_sc:.2f} s",
+            "host": os.uname().nodename,
+            "nproc": os.cpu_count(),
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,6 +120,13 @@ int zk_msm_g1(zk_ctx *ctx, const zk_srs *srs, size_t offset, const void *d_scala
  * returns ZK_ERR_LENGTH when n_bases != n_scalars and stores min(n_bases, n_scalars) in *h_err_len. */
 int zk_msm_g1_host(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n_bases,
                    const uint64_t *h_scalars, size_t n_scalars, uint64_t h_out[18], size_t *h_err_len);
+/* K9 -- the leader's small public linear maps on points (d_msm closure dmsm.rs:30-39: unpack2 ->
+ * sum -> pack_from_public; d_commit/d_open sums dpoly_comm.rs:289-292,372-391): sum_i k_i * P_i
+ * for a handful of points.  h_points: n Jacobian points (18 u64 each, any representative),
+ * h_scalars: n CANONICAL (non-Montgomery) 4xu64 scalars; h_out normalised Jacobian.  Runs on
+ * the host: n is N_p = 8l and the work is one ~255-step dependency chain. */
+int zk_g1_lincomb(zk_ctx *ctx, const uint64_t *h_points, const uint64_t *h_scalars, size_t n,
+                  uint64_t h_out[18]);
 /* window size (bits) the device Pippenger picks for n points; 0 < override <= 20 forces it */
 int zk_msm_window(size_t n);
 int zk_msm_set_window(zk_ctx *ctx, int c_override);

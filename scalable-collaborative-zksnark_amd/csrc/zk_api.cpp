@@ -260,6 +260,10 @@ int zk_msm_g1_host(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n_bas
     zk_srs_free(ctx, srs);
     return rc;
 }
+int zk_g1_lincomb(zk_ctx* ctx, const uint64_t* h_points, const uint64_t* h_scalars, size_t n, uint64_t h_out[18]) {
+    NEED(ctx, h_out && (n == 0 || (h_points && h_scalars)));
+    return g1_lincomb_host(ctx, h_points, h_scalars, n, h_out);
+}
 int zk_msm_window(size_t n) { return msm_pick_window(n); }
 int zk_msm_set_window(zk_ctx* ctx, int c) {
     if (!ctx || c < 0 || c > 20) return ZK_ERR_INVALID;

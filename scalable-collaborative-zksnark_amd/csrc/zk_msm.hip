@@ -332,6 +332,31 @@ int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, 
     return srs_pack(ctx, pts.data(), 96, n, out);
 }
 
+// K9: tiny public linear maps on points (PSS unpack2 / pack of d_msm's leader closure,
+// dmsm.rs:30-39; sums of N_p commitments dpoly_comm.rs:289-292): sum_i k_i * P_i for a handful
+// of points.  A joint double-and-add on the host: it is a ~255-step dependency chain, the same
+// shape as the MSM's final combine.
+int g1_lincomb_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h_scalars_canon, size_t n, uint64_t* h_out) {
+    namespace H = zkhost;
+    std::vector<H::Aff> pts(n);
+    std::vector<H::Jac> tmp(n);
+    for (size_t i = 0; i < n; i++) {
+        std::memcpy(tmp[i].x.data(), h_points_jac + 18 * i, 48);
+        std::memcpy(tmp[i].y.data(), h_points_jac + 18 * i + 6, 48);
+        std::memcpy(tmp[i].z.data(), h_points_jac + 18 * i + 12, 48);
+    }
+    if (n) H::batch_to_affine(tmp, pts.data());
+    H::Jac acc = H::jac_inf();
+    for (int b = 255; b >= 0; b--) {
+        acc = H::jac_dbl(acc);
+        for (size_t i = 0; i < n; i++)
+            if ((h_scalars_canon[4 * i + b / 64] >> (b % 64)) & 1) acc = H::jac_add_mixed(acc, pts[i]);
+    }
+    H::write_normalised(acc, h_out);
+    (void)ctx;
+    return ZK_OK;
+}
+
 int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n) {
     if (n == 0) return ZK_OK;
     ZK_HIP(ctx, hipSetDevice(ctx->device));

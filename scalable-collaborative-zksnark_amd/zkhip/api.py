@@ -261,6 +261,15 @@ class Ctx:
         self._check(rc)
         return out
 
+    def g1_lincomb(self, points: np.ndarray, scalars_canon: np.ndarray) -> np.ndarray:
+        """sum_i k_i * P_i for a few points (host side, K9): points [n,18] Jacobian, scalars [n,4] canonical"""
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 18)
+        sc = np.ascontiguousarray(scalars_canon, dtype=np.uint64).reshape(-1, 4)
+        assert len(pts) == len(sc)
+        out = np.zeros(18, dtype=np.uint64)
+        self._check(self.lib.zk_g1_lincomb(self.h, _h(pts), _h(sc), len(pts), _h(out)))
+        return out
+
     def msm_set_window(self, c: int):
         self._check(self.lib.zk_msm_set_window(self.h, c))
 

@@ -1,0 +1,225 @@
+"""
+Host-side mirror of the reference's `dist-primitive` functions (same names, argument meaning,
+output shape and ordering -- SURVEY.md Appendix A), with every loop body executed by
+libzkhip.so on the GPU.  `be` is the compute backend: a `zkhip.Ctx` in production.  (The CPU
+multi-process tests inject an oracle-backed stand-in with the same methods to exercise the
+exchange logic without a GPU; this module never imports the oracle.)
+
+Field elements cross this API as numpy uint64 Montgomery limbs ([4] per Fr), points as
+normalised Jacobian [18]; tables and SRS levels stay resident in HBM (DeviceBuffer / Srs).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from .field import R_MOD, fr_from_mont, fr_mont, int_to_limbs
+from .net import Net
+from .pss import PackedSharingParams
+
+ZERO = np.zeros(4, dtype=np.uint64)
+
+
+def _fr_vec_to_ints(a) -> List[int]:
+    return [fr_from_mont(x) for x in np.asarray(a, dtype=np.uint64).reshape(-1, 4)]
+
+
+def _ints_to_fr(xs) -> np.ndarray:
+    return np.array([fr_mont(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
+
+
+# ---------------------------------------------------------------------------------------
+# pss2ss (unpack.rs:72-97): gather 1 Fr, unpack, pack_single each secret, scatter
+# ---------------------------------------------------------------------------------------
+def pss2ss(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """returns this party's Vec<F> of length l as [l,4] limbs"""
+    shares = _fr_vec_to_ints(np.stack(net.all_gather(np.asarray(share, dtype=np.uint64).reshape(4))))
+    secrets = pp.unpack(shares)
+    return _ints_to_fr([pp.pack_single(v)[net.party_id] for v in secrets])
+
+
+# ---------------------------------------------------------------------------------------
+# d_msm (dmsm.rs:9-43)
+# ---------------------------------------------------------------------------------------
+def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """
+    bases[k]: Srs (device-resident level), scalars[k]: device buffer of lens[k] Fr shares.
+    Returns this party's share of every MSM result: [batch, 18] normalised Jacobian.
+    Local: G::msm per batch item (dmsm.rs:19-24).  Exchange: the leader closure
+    unpack2 -> sum -> pack_from_public([sum; l]) (:29-40) is a public linear map, applied by
+    every party to the all-gathered results for its own slot.
+    """
+    assert len(bases) == len(scalars) == len(lens)  # dmsm.rs:16
+    c_shares = np.stack([be.msm_g1(b, s, n) for b, s, n in zip(bases, scalars, lens)]) if len(lens) else np.zeros((0, 18), np.uint64)
+    gathered = net.all_gather(c_shares)  # [party][batch,18]
+    coeff = np.array([int_to_limbs(c, 4) for c in pp.dmsm_coeffs(net.party_id)], dtype=np.uint64)
+    out = np.zeros_like(c_shares)
+    for k in range(len(lens)):
+        pts = np.stack([gathered[p][k] for p in range(net.n_parties)])
+        out[k] = be.g1_lincomb(pts, coeff)
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# sumcheck family (dsumcheck.rs)
+# ---------------------------------------------------------------------------------------
+def _round_plain(f: List[int], r: int):
+    h = len(f) // 2
+    s = (sum(f[:h]) % R_MOD, sum(f[h:]) % R_MOD)
+    return s, [(f[j] * (1 - r) + f[j + h] * r) % R_MOD for j in range(h)]
+
+
+def _round_product(f: List[int], g: List[int], r: int):
+    h = len(f) // 2
+    t0 = sum(f[j] * g[j] for j in range(h)) % R_MOD
+    t1 = sum(f[j + h] * g[j + h] for j in range(h)) % R_MOD
+    t2 = sum((2 * f[j + h] - f[j]) * (2 * g[j + h] - g[j]) for j in range(h)) % R_MOD
+    fold = lambda v: [(v[j] * (1 - r) + v[j + h] * r) % R_MOD for j in range(h)]
+    return (t0, t1, t2), fold(f), fold(g)
+
+
+def sumcheck(be, evaluation, length: int, challenge: np.ndarray) -> np.ndarray:
+    """dsumcheck.rs:6-26 -> [n+1, 2, 4]; last entry (0, last)"""
+    n = length.bit_length() - 1
+    pairs, last = be.sumcheck(evaluation, length, challenge[:n])
+    return np.concatenate([pairs, np.stack([ZERO, last])[None]])
+
+
+def sumcheck_product(be, ef, eg, length: int, challenge: np.ndarray) -> np.ndarray:
+    """dsumcheck.rs:28-90 -> [n+1, 3, 4]; last entry (0, f*g, 0)"""
+    n = length.bit_length() - 1
+    tr, lf, lg = be.sumcheck_product(ef, eg, length, challenge[:n])
+    prod = fr_mont(fr_from_mont(lf) * fr_from_mont(lg) % R_MOD)
+    return np.concatenate([tr, np.stack([ZERO, prod, ZERO])[None]])
+
+
+def c_sumcheck(be, shares, length: int, challenge: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """dsumcheck.rs:92-146 -> [n + log2(l) + 1, 2, 4]"""
+    n = length.bit_length() - 1
+    pairs, last = be.sumcheck(shares, length, challenge[:n])
+    v = _fr_vec_to_ints(pss2ss(last, pp, net))
+    ch = _fr_vec_to_ints(challenge)
+    extra = []
+    for i in range(pp.l.bit_length() - 1):  # phase 2 re-uses challenge[0..log2 l] (:129)
+        s, v = _round_plain(v, ch[i])
+        extra.append(s)
+    extra.append((0, v[0]))
+    return np.concatenate([pairs, _ints_to_fr([x for p in extra for x in p]).reshape(-1, 2, 4)])
+
+
+def c_sumcheck_product(be, shares_f, shares_g, length: int, challenge: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """dsumcheck.rs:148-285 -> [n + log2(l) + 1, 3, 4]"""
+    n = length.bit_length() - 1
+    tr, lf, lg = be.sumcheck_product(shares_f, shares_g, length, challenge[:n])
+    vf = _fr_vec_to_ints(pss2ss(lf, pp, net))  # :224
+    vg = _fr_vec_to_ints(pss2ss(lg, pp, net))  # :225
+    ch = _fr_vec_to_ints(challenge)
+    extra = []
+    for i in range(pp.l.bit_length() - 1):
+        t, vf, vg = _round_product(vf, vg, ch[i])
+        extra.append(t)
+    extra.append((0, vf[0] * vg[0] % R_MOD, 0))  # :282
+    return np.concatenate([tr, _ints_to_fr([x for t in extra for x in t]).reshape(-1, 3, 4)])
+
+
+def d_sumcheck(be, partial_poly, length: int, challenge: np.ndarray, net: Net) -> np.ndarray:
+    """dsumcheck.rs:287-357.  Leader: [n'+s, 2, 4]; workers: empty"""
+    n = length.bit_length() - 1
+    s = net.n_parties.bit_length() - 1
+    pairs, last = be.sumcheck(partial_poly, length, challenge[:n])
+    local = np.concatenate([pairs, np.stack([ZERO, last])[None]])
+    allp = net.all_gather(local)
+    if not net.is_leader:
+        return np.zeros((0, 2, 4), dtype=np.uint64)
+    res = []
+    for i in range(n):
+        res.append(tuple(sum(fr_from_mont(allp[p][i][k]) for p in range(net.n_parties)) % R_MOD for k in range(2)))
+    v = [fr_from_mont(allp[p][n][1]) for p in range(net.n_parties)]
+    ch = _fr_vec_to_ints(challenge)
+    for i in range(n, n + s):
+        sm, v = _round_plain(v, ch[i])
+        res.append(sm)
+    return _ints_to_fr([x for p in res for x in p]).reshape(-1, 2, 4)
+
+
+def d_sumcheck_product(be, partial_f, partial_g, length: int, challenge: np.ndarray, net: Net) -> np.ndarray:
+    """dsumcheck.rs:359-512.  Leader: [n'+s, 3, 4]; workers: empty.  Marker tuple is (g, f, 0) (:433)"""
+    n = length.bit_length() - 1
+    s = net.n_parties.bit_length() - 1
+    tr, lf, lg = be.sumcheck_product(partial_f, partial_g, length, challenge[:n])
+    local = np.concatenate([tr, np.stack([lg, lf, ZERO])[None]])
+    allp = net.all_gather(local)
+    if not net.is_leader:
+        return np.zeros((0, 3, 4), dtype=np.uint64)
+    res = []
+    for i in range(n):
+        res.append(tuple(sum(fr_from_mont(allp[p][i][k]) for p in range(net.n_parties)) % R_MOD for k in range(3)))
+    f = [fr_from_mont(allp[p][n][1]) for p in range(net.n_parties)]  # :448
+    g = [fr_from_mont(allp[p][n][0]) for p in range(net.n_parties)]  # :449
+    ch = _fr_vec_to_ints(challenge)
+    for i in range(n, n + s):
+        t, f, g = _round_product(f, g, ch[i])
+        res.append(t)
+    return _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)
+
+
+# ---------------------------------------------------------------------------------------
+# product accumulation (dacc_product.rs)
+# ---------------------------------------------------------------------------------------
+def sub_index(i: int) -> Tuple[int, int]:
+    """dacc_product.rs:18-23"""
+    x = (i & ~(1 << (i.bit_length() - 1))) << 1
+    return x, x + 1
+
+
+def acc_product(be, x, N: int):
+    """dacc_product.rs:30-57 -> device tree (2N Fr); views v(x,0)=tree[0::2], v(x,1)=tree[1::2], v(1,x)=tree[N:]"""
+    return be.product_tree(x, N)
+
+
+def d_acc_product(be, inputs, N: int, net: Net):
+    """dacc_product.rs:365-414 -> (subtree device buffer, leader tree [2*N_p,4] or None)"""
+    subtree = be.product_tree(inputs, N)
+    root = subtree.download((1, 4), offset=32 * (2 * N - 1))[0]  # the forced 0 (:381,:390)
+    roots = net.all_gather(root)
+    if not net.is_leader:
+        return subtree, None
+    t = [fr_from_mont(r) for r in roots]
+    npar = net.n_parties
+    for i in range(npar, 2 * npar - 1):
+        a, b = sub_index(i)
+        t.append(t[a] * t[b] % R_MOD)
+    t.append(0)
+    return subtree, _ints_to_fr(t)
+
+
+# ---------------------------------------------------------------------------------------
+# polynomial commitment (dpoly_comm.rs:236-464).  powers_of_g: list of Srs, level k has 2^k points
+# ---------------------------------------------------------------------------------------
+def commit(be, powers_of_g, peval, length: int) -> np.ndarray:
+    """dpoly_comm.rs:237-243 (= d_local_commit :269-275)"""
+    level = length.bit_length() - 1
+    assert level < len(powers_of_g) and length == 1 << level
+    return be.msm_g1(powers_of_g[level], peval, length)
+
+
+def open_(be, powers_of_g, peval, length: int, point: np.ndarray):
+    """dpoly_comm.rs:299-325 (= d_local_open :327-353) -> (value [4], proofs [n,18])"""
+    n = length.bit_length() - 1
+    q, value = be.open_rounds(peval, length, point[:n])
+    proofs, off, m = [], 0, length
+    for _ in range(n):
+        h = m // 2
+        proofs.append(be.msm_g1(powers_of_g[h.bit_length() - 1], q.at(32 * off), h))
+        off += h
+        m = h
+    return value, (np.stack(proofs) if proofs else np.zeros((0, 18), np.uint64))
+
+
+def d_commit(be, powers_of_g, peval, length: int, net: Net) -> np.ndarray:
+    """dpoly_comm.rs:276-297: every party ends with the sum of the local commitments"""
+    local = commit(be, powers_of_g, peval, length)
+    pts = np.stack(net.all_gather(local))
+    ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
+    return be.g1_lincomb(pts, ones)

@@ -1,0 +1,126 @@
+"""
+Party-axis exchange layer -- what replaces mpc-net's TCP star (mpc-net/src/lib.rs:35-287) and
+the typed adapter dist-primitive/src/utils/serializing_net.rs.
+
+Every exchange of the hot path is a star through party 0 whose leader function is a PUBLIC
+linear map, so on one node it is re-expressed as ONE all-gather of raw limbs
+followed by the same map computed by every party for its own slot.  Payloads are raw
+Montgomery limbs (no compression on xGMI).
+
+  TorchDistNet   one process per GPU, torch.distributed: backend "nccl" (= RCCL over xGMI) on
+                 the GPU box, "gloo" in the CPU tests
+  LocalTestNet   all parties as threads of one process (mirrors LocalTestNet::simulate_network_round,
+                 mpc-net/src/multi.rs:268-362)
+  LeaderEchoNet  the no-`comm` fake (serializing_net.rs:144-264): the leader sees n copies of
+                 its own message; only party 0 is meaningful
+"""
+from __future__ import annotations
+
+import threading
+from typing import Callable, List
+
+import numpy as np
+
+
+class Net:
+    n_parties: int
+    party_id: int
+
+    @property
+    def is_leader(self) -> bool:
+        return self.party_id == 0
+
+    def all_gather(self, a: np.ndarray) -> List[np.ndarray]:
+        """every party contributes `a` (same shape everywhere); returns the list ordered by party id"""
+        raise NotImplementedError
+
+    def sync(self):
+        self.all_gather(np.zeros(1, dtype=np.uint64))
+
+    # byte accounting like MPCNet::get_comm (multi.rs:378-387): (up, down)
+    def __init_counters(self):
+        self.upload = 0
+        self.download = 0
+
+    def _count(self, nbytes: int):
+        if not hasattr(self, "upload"):
+            self.__init_counters()
+        self.upload += nbytes * (self.n_parties - 1)
+        self.download += nbytes * (self.n_parties - 1)
+
+
+class LeaderEchoNet(Net):
+    def __init__(self, n_parties: int = 8):
+        self.n_parties, self.party_id = n_parties, 0
+
+    def all_gather(self, a):
+        self._count(a.nbytes)
+        return [np.array(a, copy=True) for _ in range(self.n_parties)]
+
+
+class TorchDistNet(Net):
+    """torch.distributed process group; device tensors for nccl, CPU tensors for gloo"""
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.n_parties = dist.get_world_size(group)
+        self.party_id = dist.get_rank(group)
+        self.device = device
+
+    def all_gather(self, a):
+        import torch
+
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
+        if self.device is not None:
+            t = t.to(self.device)
+        outs = [torch.empty_like(t) for _ in range(self.n_parties)]
+        self.dist.all_gather(outs, t, group=self.group)
+        self._count(a.nbytes)
+        return [o.cpu().numpy().view(a.dtype).reshape(a.shape) for o in outs]
+
+
+class _LocalHub:
+    def __init__(self, n):
+        self.n = n
+        self.slots = [None] * n
+        self.barrier = threading.Barrier(n)
+
+
+class LocalTestNet(Net):
+    def __init__(self, hub: _LocalHub, party_id: int):
+        self.hub, self.party_id, self.n_parties = hub, party_id, hub.n
+
+    def all_gather(self, a):
+        self.hub.slots[self.party_id] = np.array(a, copy=True)
+        self.hub.barrier.wait()
+        out = [np.array(s, copy=True) for s in self.hub.slots]
+        self.hub.barrier.wait()
+        self._count(a.nbytes)
+        return out
+
+    @staticmethod
+    def simulate_network_round(n_parties: int, fn: Callable[["LocalTestNet"], object]) -> list:
+        """run fn(net) for every party on its own thread; results ordered by party id"""
+        hub = _LocalHub(n_parties)
+        results: list = [None] * n_parties
+        errors: list = []
+
+        def run(p):
+            try:
+                results[p] = fn(LocalTestNet(hub, p))
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                hub.barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(p,)) for p in range(n_parties)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results

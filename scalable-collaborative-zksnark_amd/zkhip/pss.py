@@ -1,0 +1,101 @@
+"""
+Packed secret sharing parameters -- host-side mirror of secret-sharing/src/pss.rs:17-172.
+
+Every PSS map is a fixed PUBLIC linear map over Fr on vectors of N_p = 8l entries, so it is
+kept as small integer matrices (python ints) and applied either to Fr values on the host or,
+for points, through the library's K9 entry point (zk_g1_lincomb).  The ark-poly semantics the
+reference relies on are isolated in `_fft` / `_ifft`: `fft_in_place` / `ifft_in_place` first
+resize (zero-pad or truncate) the vector to the domain size (SURVEY.md Appendix C -- an
+assumption that cannot be checked against arkworks in this environment).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+from .field import R_MOD
+
+FR_GENERATOR = 7
+TWO_ADICITY = 32
+ROOT_OF_UNITY = pow(FR_GENERATOR, (R_MOD - 1) >> TWO_ADICITY, R_MOD)
+
+
+class _Domain:
+    def __init__(self, size: int, offset: int = 1):
+        assert size & (size - 1) == 0
+        self.size, self.offset = size, offset % R_MOD
+        self.omega = pow(ROOT_OF_UNITY, (1 << TWO_ADICITY) // size, R_MOD)
+
+    def _resize(self, v: Sequence[int]) -> List[int]:
+        v = list(v[: self.size])
+        return v + [0] * (self.size - len(v))
+
+    def fft(self, coeffs: Sequence[int]) -> List[int]:
+        c = self._resize(coeffs)
+        out = []
+        for j in range(self.size):
+            x = self.offset * pow(self.omega, j, R_MOD) % R_MOD
+            acc, xp = 0, 1
+            for k in range(self.size):
+                acc = (acc + c[k] * xp) % R_MOD
+                xp = xp * x % R_MOD
+            out.append(acc)
+        return out
+
+    def ifft(self, evals: Sequence[int]) -> List[int]:
+        e = self._resize(evals)
+        ninv, oinv, winv = pow(self.size, -1, R_MOD), pow(self.offset, -1, R_MOD), pow(self.omega, -1, R_MOD)
+        out = []
+        for k in range(self.size):
+            acc = 0
+            for j in range(self.size):
+                acc = (acc + e[j] * pow(winv, j * k, R_MOD)) % R_MOD
+            out.append(acc * ninv % R_MOD * pow(oinv, k, R_MOD) % R_MOD)
+        return out
+
+
+class PackedSharingParams:
+    """PackedSharingParams::new(l) (pss.rs:38-64): n = 8l parties, t = l-1"""
+
+    def __init__(self, l: int):
+        assert l >= 1 and l & (l - 1) == 0
+        self.l, self.n, self.t = l, 8 * l, l - 1
+        self.share = _Domain(self.n)
+        self.secret = _Domain(2 * l, FR_GENERATOR)
+        self.secret2 = _Domain(4 * l, FR_GENERATOR)
+        unit = lambda m, j: [1 if k == j else 0 for k in range(m)]
+        tr = lambda cols: [list(r) for r in zip(*cols)]
+        # share_i = sum_j pack[i][j] * secret_j        (secrets zero-padded to 2l)
+        self.pack_matrix = tr([self.pack_from_public(unit(2 * l, j)) for j in range(2 * l)])
+        # secret_j = sum_i unpack[j][i] * share_i
+        self.unpack_matrix = tr([self.unpack(unit(self.n, i)) for i in range(self.n)])
+        self.unpack2_matrix = tr([self.unpack2(unit(self.n, i)) for i in range(self.n)])
+
+    # --- the reference's maps on Fr vectors (python ints) ---
+    def pack_from_public(self, secrets: Sequence[int]) -> List[int]:
+        """pss.rs:69-73,93-99"""
+        return self.share.fft(self.secret.ifft(secrets))
+
+    def pack_single(self, secret: int) -> List[int]:
+        """pss.rs:103-113 -- packs and then packs the n-vector AGAIN (reference quirk, kept literally)"""
+        return self.pack_from_public(self.share.fft(self.secret.ifft([secret])))
+
+    def unpack(self, shares: Sequence[int]) -> List[int]:
+        """pss.rs:117-120,132-149"""
+        return self.secret.fft(self.share.ifft(shares))[: self.l]
+
+    def unpack2(self, shares: Sequence[int]) -> List[int]:
+        """pss.rs:124-128,153-171 (slots 0,2,..,2l-2)"""
+        assert len(shares) == self.n
+        return self.secret2.fft(self.share.ifft(shares))[0 : 2 * self.l : 2]
+
+    # --- coefficient rows used by the distributed primitives ---
+    def dmsm_coeffs(self, party: int) -> List[int]:
+        """
+        d_msm leader closure (dmsm.rs:30-39) for one output party p:
+            out_p = pack_from_public([S; l])[p],  S = sum_j unpack2(shares)_j
+                  = sum_i (c_p * lambda_i) * C_i
+        returns [c_p * lambda_i mod r for i < n].
+        """
+        lam = [sum(self.unpack2_matrix[j][i] for j in range(self.l)) % R_MOD for i in range(self.n)]
+        c_p = sum(self.pack_matrix[party][j] for j in range(self.l)) % R_MOD
+        return [c_p * x % R_MOD for x in lam]
