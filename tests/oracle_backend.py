@@ -1,0 +1,86 @@
+"""
+Oracle-backed stand-in for `zkhip.Ctx` used ONLY by the CPU tests of the host/exchange logic
+(zkhip.dist_primitive over LocalTestNet / gloo): same method names, numpy arrays instead of HBM
+buffers, arithmetic by the oracle.  It lives under tests/ -- the product never sees it.
+"""
+import numpy as np
+
+import coracle as co
+import pyoracle as po
+from helpers import pt_ints, pt_mont
+
+
+class NumpyBuf:
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+
+    def download(self, shape, dtype=np.uint64, offset=0):
+        flat = self.a.reshape(-1)[offset // 8 :]
+        n = int(np.prod(shape))
+        return flat[:n].reshape(shape).copy()
+
+    def at(self, byte_offset):
+        return NumpyBuf(self.a.reshape(-1)[byte_offset // 8 :].reshape(-1, 4))
+
+
+def _arr(x):
+    return x.a if isinstance(x, NumpyBuf) else np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+
+
+def _jac(aff12):
+    out = np.zeros(18, dtype=np.uint64)
+    a = np.asarray(aff12, dtype=np.uint64)
+    one = np.array(po.fq_to_mont_limbs(1), dtype=np.uint64)
+    if not a.any():
+        out[0:6] = one
+        out[6:12] = one
+        return out
+    out[:12] = a
+    out[12:] = one
+    return out
+
+
+class OracleSrs:
+    def __init__(self, bases):
+        self.bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
+
+    def __len__(self):
+        return len(self.bases)
+
+
+class OracleBackend:
+    def to_device(self, a):
+        return NumpyBuf(a)
+
+    def srs_register(self, bases, stride=96):
+        return OracleSrs(bases)
+
+    def msm_g1(self, srs, scalars, n, offset=0):
+        return _jac(co.msm_g1(srs.bases[offset : offset + n], _arr(scalars)[:n]))
+
+    def g1_lincomb(self, points, scalars_canon):
+        acc = None
+        for p, k in zip(np.asarray(points).reshape(-1, 18), np.asarray(scalars_canon).reshape(-1, 4)):
+            P = None if not p[12:].any() else pt_ints(p[:12])
+            kk = sum(int(k[i]) << (64 * i) for i in range(4))
+            acc = po.g1_add(acc, po.g1_mul(P, kk))
+        return _jac(pt_mont(acc))
+
+    def sumcheck(self, tab, length, chal):
+        r = co.sumcheck(_arr(tab)[:length], np.asarray(chal).reshape(-1, 4)) if length > 1 else None
+        if length == 1:
+            return np.zeros((0, 2, 4), np.uint64), _arr(tab)[0].copy()
+        n = length.bit_length() - 1
+        return r[:n], r[n, 1]
+
+    def sumcheck_product(self, f, g, length, chal):
+        if length == 1:
+            return np.zeros((0, 3, 4), np.uint64), _arr(f)[0].copy(), _arr(g)[0].copy()
+        return co.sumcheck_product_rounds(_arr(f)[:length], _arr(g)[:length], np.asarray(chal).reshape(-1, 4))
+
+    def product_tree(self, x, N):
+        return NumpyBuf(co.product_tree(_arr(x)[:N]))
+
+    def open_rounds(self, tab, length, point):
+        q, v = co.open_quotients(_arr(tab)[:length], np.asarray(point).reshape(-1, 4))
+        return NumpyBuf(q if len(q) else np.zeros((1, 4), np.uint64)), v

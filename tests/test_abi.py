@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "zkhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import zkhip
+
+    lib = ctypes.CDLL(zkhip.LIB_PATH)
+    declared = _header_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/zkhip.h but not exported"
+    bound = {s[0] for s in zkhip._lib.SYMBOLS}
+    assert bound == set(declared), (bound ^ set(declared))
+
+
+def test_no_silent_fallback_without_gpu():
+    """on a box without a GPU the product path must fail loudly, not fall back to CPU code"""
+    import torch
+
+    import zkhip
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(zkhip.ZkError) as e:
+        zkhip.Ctx(0)
+    assert e.value.code == zkhip._lib.ZK_ERR_NO_DEVICE
+
+
+def test_product_does_not_import_oracle():
+    """the package and bench's GPU path never reference oracle/ (only tests, smoke, cpu_baseline may)"""
+    pkg = os.path.join(ROOT, "scalable-collaborative-zksnark_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".cuh", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in text and "coracle" not in text and "zk_oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_status_codes_and_version():
+    import zkhip
+
+    lib = zkhip.lib()
+    assert lib.zk_version().startswith(b"zkhip")
+    assert lib.zk_msm_window(1 << 20) == 16
+    h = ctypes.c_void_p()
+    assert lib.zk_ctx_create(0, None) == zkhip._lib.ZK_ERR_INVALID

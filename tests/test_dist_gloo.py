@@ -1,0 +1,78 @@
+"""
+The N > 1 path over torch.distributed with the `gloo` backend on CPU (world_size 2; and the full
+8-party d_msm at world_size 8): TorchDistNet + zkhip.dist_primitive with the oracle-backed compute
+stand-in.  On the GPU box the same code runs with backend "nccl" (= RCCL over xGMI) and zkhip.Ctx.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, json
+sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch.distributed as dist
+import pyoracle as po
+from helpers import pt_ints, pt_mont
+from oracle_backend import OracleBackend, OracleSrs
+from zkhip import dist_primitive as dp
+from zkhip.net import TorchDistNet
+from zkhip.pss import PackedSharingParams
+dist.init_process_group("gloo")
+net = TorchDistNet()
+W, p = net.n_parties, net.party_id
+be = OracleBackend()
+to_m = lambda xs: np.array([po.fr_to_mont_limbs(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
+ints = lambda a: [po.fr_from_mont_limbs(r) for r in np.asarray(a).reshape(-1, 4)]
+rng = po.SplitMix64(1234)          # same stream on every rank: every rank can rebuild all inputs
+n = 3
+pf = [rng.fr_vec(1 << n) for _ in range(W)]
+pg = [rng.fr_vec(1 << n) for _ in range(W)]
+s = W.bit_length() - 1
+ch = rng.fr_vec(n + s)
+out = dp.d_sumcheck_product(be, be.to_device(to_m(pf[p])), be.to_device(to_m(pg[p])), 1 << n, to_m(ch), net)
+tree, top = dp.d_acc_product(be, be.to_device(to_m(pf[p])), 1 << n, net)
+if p == 0:
+    assert [tuple(ints(t)) for t in out] == po.d_sumcheck_product_all(pf, pg, ch)
+    assert ints(top) == po.d_acc_product_all(pf)[1]
+else:
+    assert len(out) == 0 and top is None
+if W == 8:                           # the l = 1, 8-party d_msm
+    pp, opp = PackedSharingParams(1), po.PackedSharingParams(1)
+    bases = [[po.g1_bases(4, 50 + q)] for q in range(W)]
+    scal = [[rng.fr_vec(4)] for _ in range(W)]
+    got = dp.d_msm(be, [OracleSrs(np.array([pt_mont(P) for P in bases[p][0]]))], [be.to_device(to_m(scal[p][0]))], [4], pp, net)
+    exp = po.d_msm_all(bases, scal, opp)
+    assert pt_ints(got[0][:12]) == exp[p][0]
+dist.barrier()
+print("RANK_OK", p)
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world):
+    script = "ROOT = %r\n" % ROOT + WORKER
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "--no-python", sys.executable, "-c", script]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("RANK_OK") == world
+
+
+def test_gloo_world_size_2():
+    _run(2)
+
+
+def test_gloo_world_size_8_full_dmsm():
+    _run(8)

@@ -1,0 +1,139 @@
+"""
+Host / exchange logic of zkhip.dist_primitive, run WITHOUT a GPU: the compute backend is the
+oracle-backed stand-in (tests/oracle_backend.py), the parties are threads (LocalTestNet, like the
+reference's LocalTestNet::simulate_network_round) -- results must equal the all-parties-in-one
+restatement in oracle/pyoracle.py (which follows the reference's star protocol literally).
+"""
+import numpy as np
+import pytest
+
+import pyoracle as po
+from helpers import pt_ints, pt_mont
+from oracle_backend import OracleBackend, OracleSrs
+from zkhip import dist_primitive as dp
+from zkhip.net import LeaderEchoNet, LocalTestNet
+from zkhip.pss import PackedSharingParams
+
+
+def to_m(xs):
+    return np.array([po.fr_to_mont_limbs(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
+
+
+def ints(a):
+    return [po.fr_from_mont_limbs(r) for r in np.asarray(a).reshape(-1, 4)]
+
+
+def jac_pt(j):
+    return None if not j[12:].any() else pt_ints(j[:12])
+
+
+@pytest.mark.parametrize("l", [1, 2])
+def test_pss_matrices_match_oracle(l):
+    a, b = PackedSharingParams(l), po.PackedSharingParams(l)
+    assert a.pack_matrix == b.pack_matrix() and a.unpack_matrix == b.unpack_matrix() and a.unpack2_matrix == b.unpack2_matrix()
+    assert a.pack_single(987654321) == b.pack_single(987654321)
+
+
+@pytest.mark.parametrize("l", [1, 2])
+def test_pss2ss_and_c_sumchecks(l):
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    rng = po.SplitMix64(70 + l)
+    n = 3
+    sf = [rng.fr_vec(1 << n) for _ in range(pp.n)]
+    sg = [rng.fr_vec(1 << n) for _ in range(pp.n)]
+    ch = rng.fr_vec(n + 2)
+    be = OracleBackend()
+
+    def party(net):
+        p = net.party_id
+        a = dp.c_sumcheck(be, be.to_device(to_m(sf[p])), 1 << n, to_m(ch), pp, net)
+        b = dp.c_sumcheck_product(be, be.to_device(to_m(sf[p])), be.to_device(to_m(sg[p])), 1 << n, to_m(ch), pp, net)
+        return a, b
+
+    res = LocalTestNet.simulate_network_round(pp.n, party)
+    exp_a = po.c_sumcheck_all(sf, ch, opp)
+    exp_b = po.c_sumcheck_product_all(sf, sg, ch, opp)
+    for p in range(pp.n):
+        assert [tuple(ints(t)) for t in res[p][0]] == exp_a[p]
+        assert [tuple(ints(t)) for t in res[p][1]] == exp_b[p]
+
+
+def test_d_sumchecks_and_acc_product():
+    rng = po.SplitMix64(81)
+    np_, n = 8, 3
+    pf = [rng.fr_vec(1 << n) for _ in range(np_)]
+    pg = [rng.fr_vec(1 << n) for _ in range(np_)]
+    ch = rng.fr_vec(n + 3)
+    be = OracleBackend()
+
+    def party(net):
+        p = net.party_id
+        a = dp.d_sumcheck(be, be.to_device(to_m(pf[p])), 1 << n, to_m(ch), net)
+        b = dp.d_sumcheck_product(be, be.to_device(to_m(pf[p])), be.to_device(to_m(pg[p])), 1 << n, to_m(ch), net)
+        tree, top = dp.d_acc_product(be, be.to_device(to_m(pf[p])), 1 << n, net)
+        return a, b, tree.download((2 << n, 4)), top
+
+    res = LocalTestNet.simulate_network_round(np_, party)
+    assert [tuple(ints(t)) for t in res[0][0]] == po.d_sumcheck_all(pf, ch)
+    assert [tuple(ints(t)) for t in res[0][1]] == po.d_sumcheck_product_all(pf, pg, ch)
+    subtrees, leader = po.d_acc_product_all(pf)
+    for p in range(np_):
+        assert ints(res[p][2]) == subtrees[p]
+        if p:
+            assert len(res[p][0]) == 0 and len(res[p][1]) == 0 and res[p][3] is None  # workers: vec![] / None
+    assert ints(res[0][3]) == leader
+
+
+@pytest.mark.parametrize("l", [1, 2])
+def test_d_msm_over_threads(l):
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    rng = po.SplitMix64(90 + l)
+    sizes = [8, 4]  # a batch of two MSMs, like c_open's shrinking batch
+    bases = [[po.g1_bases(m, 100 * p + m) for m in sizes] for p in range(pp.n)]
+    scal = [[rng.fr_vec(m) for m in sizes] for p in range(pp.n)]
+    be = OracleBackend()
+
+    def party(net):
+        p = net.party_id
+        srs = [OracleSrs(np.array([pt_mont(P) for P in b])) for b in bases[p]]
+        sc = [be.to_device(to_m(s)) for s in scal[p]]
+        return dp.d_msm(be, srs, sc, sizes, pp, net)
+
+    res = LocalTestNet.simulate_network_round(pp.n, party)
+    exp = po.d_msm_all(bases, scal, opp)
+    for p in range(pp.n):
+        assert [jac_pt(j) for j in res[p]] == exp[p]
+
+
+def test_leader_echo_mode_matches_appendix_b():
+    """config 1 plumbing (no-`comm` fake): d_msm returns (4/7) * MSM for party 0 at l = 1"""
+    pp = PackedSharingParams(1)
+    be = OracleBackend()
+    rng = po.SplitMix64(3)
+    pts, sc = po.g1_bases(6, 9), rng.fr_vec(6)
+    net = LeaderEchoNet(8)
+    out = dp.d_msm(be, [OracleSrs(np.array([pt_mont(P) for P in pts]))], [be.to_device(to_m(sc))], [6], pp, net)
+    c0 = 4 * pow(7, -1, po.R_MOD) % po.R_MOD
+    assert jac_pt(out[0]) == po.g1_mul(po.g1_msm(pts, sc), c0)
+    up, down = net.upload, net.download
+    assert up == down == 7 * 144  # one 144-byte point "sent to 7 others"
+
+
+def test_commit_open_and_d_commit():
+    be = OracleBackend()
+    n, np_ = 3, 8
+    levels_pts = [po.g1_bases(1 << k, 300 + k) for k in range(n + 1)]
+    levels = [OracleSrs(np.array([pt_mont(P) for P in lv])) for lv in levels_pts]
+    rng = po.SplitMix64(5)
+    chunks = [rng.fr_vec(1 << n) for _ in range(np_)]
+    point = rng.fr_vec(n)
+    v, proofs = dp.open_(be, levels, be.to_device(to_m(chunks[0])), 1 << n, to_m(point))
+    ev, eproofs = po.open_(levels_pts, chunks[0], point)
+    assert ints(v) == [ev] and [jac_pt(p) for p in proofs] == eproofs
+
+    def party(net):
+        return dp.d_commit(be, levels, be.to_device(to_m(chunks[net.party_id])), 1 << n, net)
+
+    res = LocalTestNet.simulate_network_round(np_, party)
+    exp = po.d_commit_all(levels_pts, chunks)
+    assert all(jac_pt(r) == exp for r in res)
