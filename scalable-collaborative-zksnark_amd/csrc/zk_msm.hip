@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,55 +40,103 @@ int msm_pick_window(size_t n) {
     return c;
 }
 
-// number of windows so that the top signed digit never carries out (scalars are < r < 2^255)
-static int msm_windows(int c) {
-    static const u64 Rm1[4] = {0xffffffff00000000ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
-    int W = (255 + c - 1) / c;
-    const int sh = c * (W - 1);  // <= 254
-    const int li = sh / 64, bi = sh % 64;
-    u64 top = Rm1[li] >> bi;
-    if (bi && li + 1 < 4) top |= Rm1[li + 1] << (64 - bi);
-    // the top window sees at most top + 1 (carry in) and must stay <= 2^(c-1) to remain positive
-    if (top + 1 > ((u64)1 << (c - 1))) W++;
-    return W;
+// Window layout: the 256 bits (255-bit scalar + room for the last carry) are split into W
+// windows whose widths differ by at most one bit (the first `rem` windows are base+1 wide, the
+// rest base wide, base+1 <= c).  Balanced widths matter: a narrow (or carry-only) top window would
+// funnel ~all points of that window into a handful of buckets.
+struct WinLayout {
+    int W, base, rem;
+    __host__ __device__ int width(int w) const { return base + (w < rem ? 1 : 0); }
+    __host__ __device__ int bit_offset(int w) const { return w * base + (w < rem ? w : rem); }
+};
+static WinLayout msm_layout(int c) {
+    WinLayout L;
+    L.W = (256 + c - 1) / c;
+    L.base = 256 / L.W;
+    L.rem = 256 % L.W;
+    return L;
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlk) k_digits(const void* __restrict__ scalars, size_t n, int c, int W, size_t nb,
-                                               u32* __restrict__ digits, u32* __restrict__ counts) {
+// 1. digits: scalars out of Montgomery form, signed c-bit digits.  digits row stride = ns.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlk) k_digits(const void* __restrict__ scalars, size_t n, size_t ns, WinLayout L,
+                                               u32* __restrict__ digits) {
     const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
-    if (i >= n) return;
+    if (i >= ns) return;
+    if (i >= n) {  // padding up to the row stride
+        for (int w = 0; w < L.W; w++) digits[(size_t)w * ns + i] = kSkip;
+        return;
+    }
     Fr s = fp_from_mont<FrCfg>(fr_load(scalars, i));
-    const u32 mask = (1u << c) - 1u;
     u32 carry = 0;
-    for (int w = 0; w < W; w++) {
+    for (int w = 0; w < L.W; w++) {
+        const int cw = L.width(w);  // <= 16
+        const u32 mask = (1u << cw) - 1u, half = 1u << (cw - 1);
         u32 v = (s.l[0] & mask) + carry;
-        // s >>= c   (c <= 16 < 32)
+        // s >>= cw
 #pragma unroll
-        for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> c) | (s.l[k + 1] << (32 - c));
-        s.l[7] >>= c;
+        for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> cw) | (s.l[k + 1] << (32 - cw));
+        s.l[7] >>= cw;
         u32 d;
-        if (v > (u32)nb) {
-            v = (1u << c) - v;
+        if (v > half) {  // recentre to [-2^(cw-1), 2^(cw-1)]; never triggers in the top window
+            v = (1u << cw) - v;
             carry = 1;
             d = 0x80000000u;
         } else {
             carry = 0;
             d = 0;
         }
-        if (v == 0) {
-            d = kSkip;
-        } else {
-            d |= (v - 1);
-            atomicAdd(&counts[(size_t)w * nb + (v - 1)], 1u);
-        }
-        digits[(size_t)w * n + i] = d;
+        d = (v == 0) ? kSkip : (d | (v - 1));
+        digits[(size_t)w * ns + i] = d;
     }
 }
 
-// exclusive scan of counts[w][0..nb) -> offsets, cursor.  One block per window.
-__global__ void __launch_bounds__(kBlk) k_scan(const u32* __restrict__ counts, size_t nb, u32* __restrict__ offsets,
-                                             u32* __restrict__ cursor) {
+// ---------------------------------------------------------------------------------------
+// 2./3. counting sort with LDS-privatised counters.  Block (p, w) owns the bucket range
+// [p*bpb, (p+1)*bpb) of window w, keeps its counters / cursors in LDS and sweeps the whole digit
+// row of the window (16-byte coalesced reads served by L2 / Infinity Cache): no global atomics.
+// SCATTER = false: histogram -> counts.   SCATTER = true: cursors start at offsets; writes the
+// point index (bit 31 = negate) at its sorted position.
+// ---------------------------------------------------------------------------------------
+static constexpr int kSortThreads = 1024;
+template <bool SCATTER>
+__global__ void __launch_bounds__(kSortThreads) k_sort_pass(const u32* __restrict__ digits, size_t ns, size_t nb, u32 bpb,
+                                                          u32* __restrict__ counts_or_offsets, u32* __restrict__ sorted) {
+    extern __shared__ u32 cnt[];
+    const int w = blockIdx.y;
+    const u32 lo = blockIdx.x * bpb;
+    u32* glob = counts_or_offsets + (size_t)w * nb + lo;
+    for (u32 i = threadIdx.x; i < bpb; i += kSortThreads) cnt[i] = SCATTER ? glob[i] : 0u;
+    __syncthreads();
+    const uint4* row = reinterpret_cast<const uint4*>(digits + (size_t)w * ns);
+    u32* out = sorted + (size_t)w * ns;
+    const size_t n4 = ns >> 2;
+    for (size_t i4 = threadIdx.x; i4 < n4; i4 += kSortThreads) {
+        uint4 d4 = row[i4];
+        u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 d = dd[k];
+            u32 b = (d & 0x7fffffffu) - lo;  // kSkip maps far outside any range
+            if (d != kSkip && b < bpb) {
+                if (SCATTER) {
+                    u32 pos = atomicAdd(&cnt[b], 1u);
+                    out[pos] = (u32)(4 * i4 + k) | (d & 0x80000000u);
+                } else {
+                    atomicAdd(&cnt[b], 1u);
+                }
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < bpb; i += kSortThreads) glob[i] = cnt[i];
+    }
+}
+
+// exclusive scan of counts[w][0..nb) -> offsets.  One block per window.
+__global__ void __launch_bounds__(kBlk) k_scan(const u32* __restrict__ counts, size_t nb, u32* __restrict__ offsets) {
     __shared__ u32 part[kBlk];
     const int w = blockIdx.x, tid = threadIdx.x;
     const size_t per = (nb + kBlk - 1) / kBlk;
@@ -108,39 +157,132 @@ __global__ void __launch_bounds__(kBlk) k_scan(const u32* __restrict__ counts, s
     u32 run = part[tid];
     for (size_t b = lo; b < hi; b++) {
         offsets[(size_t)w * nb + b] = run;
-        cursor[(size_t)w * nb + b] = run;
         run += counts[(size_t)w * nb + b];
     }
 }
 
-__global__ void __launch_bounds__(kBlk) k_scatter(const u32* __restrict__ digits, size_t n, size_t nb, u32* __restrict__ cursor,
-                                                u32* __restrict__ sorted) {
-    const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
-    const int w = blockIdx.y;
-    if (i >= n) return;
-    u32 d = digits[(size_t)w * n + i];
-    if (d == kSkip) return;
-    u32 pos = atomicAdd(&cursor[(size_t)w * nb + (d & 0x7fffffffu)], 1u);
-    sorted[(size_t)w * n + pos] = (u32)i | (d & 0x80000000u);
+// ---------------------------------------------------------------------------------------
+// 4. bucket accumulation over fixed-size TILES of the sorted array: every lane performs exactly
+// T mixed additions regardless of how the scalars distribute over buckets (no lock-step waiting
+// on the fullest bucket of a wave, no collapse on skewed inputs).  A lane walks T consecutive
+// sorted entries; runs that are whole buckets are stored directly, the (at most two) runs cut by
+// the tile boundary go to heads[] / tails[] and are stitched by k_fixup.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlk) k_accum_tiles(const void* __restrict__ bases, const u32* __restrict__ sorted,
+                                                    const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t ns,
+                                                    size_t nb, u32 T, size_t tiles_per_w, size_t total_tiles,
+                                                    void* __restrict__ buckets, void* __restrict__ heads, void* __restrict__ tails) {
+    const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (g >= total_tiles) return;
+    const size_t w = g / tiles_per_w, t = g % tiles_per_w;
+    const u32* off = offsets + w * nb;
+    const u32* cnt = counts + w * nb;
+    const u32 nw = off[nb - 1] + cnt[nb - 1];  // entries of this window (zero digits are skipped)
+    const u32 e0 = (u32)t * T;
+    if (e0 >= nw) return;
+    const u32 e1 = (e0 + T < nw) ? e0 + T : nw;
+    // bucket holding entry e0: the largest b with off[b] <= e0 (ties = empty buckets, skipped)
+    u32 lo = 0, hi = (u32)nb - 1;
+    while (lo < hi) {
+        u32 mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= e0) lo = mid;
+        else hi = mid - 1;
+    }
+    u32 b = lo;
+    u32 bstart = off[b], bend = bstart + cnt[b];
+    u32 ps = e0;  // start of the current run
+    const u32* run = sorted + w * ns;
+    Xyzz acc;
+    xyzz_set_inf(acc);
+    u32 v = run[e0];
+    Aff p = aff_load(bases, v & 0x7fffffffu);
+    for (u32 e = e0; e < e1; e++) {
+        if (e == bend) {  // run finished: flush and move to the next non-empty bucket
+            if (ps == bstart) xyzz_store(buckets, w * nb + b, acc);  // whole bucket
+            else xyzz_store(heads, g, acc);                            // started before this tile
+            do {
+                b++;
+                bstart = off[b];
+                bend = bstart + cnt[b];
+            } while (bend == bstart);
+            ps = e;
+            xyzz_set_inf(acc);
+        }
+        const bool neg = (v >> 31) != 0;
+        Aff cur = p;
+        if (e + 1 < e1) {  // prefetch the next point while this one is being added
+            v = run[e + 1];
+            p = aff_load(bases, v & 0x7fffffffu);
+        }
+        xyzz_madd(acc, cur, neg);
+    }
+    // last run of the tile
+    if (ps == bstart && e1 == bend) xyzz_store(buckets, w * nb + b, acc);
+    else if (ps == e0) xyzz_store(heads, g, acc);  // single run covering the tile from its start
+    else xyzz_store(tails, g, acc);
 }
 
-// bucket accumulation: lane g = (w, b) sums its run.  buckets: [W][nb] Xyzz
-__global__ void __launch_bounds__(kBlk) k_accum(const void* __restrict__ bases, const u32* __restrict__ sorted,
-                                              const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t n, size_t nb,
-                                              size_t total, void* __restrict__ buckets) {
+// stitch the runs cut by tile boundaries; also writes infinity for empty buckets.  Buckets that
+// span more than kLongSpan tiles (skewed scalars: many equal digits) are queued for k_fixup_long.
+static constexpr u32 kLongSpan = 24;
+__global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, u32 T,
+                                              size_t tiles_per_w, size_t total, void* __restrict__ buckets,
+                                              const void* __restrict__ heads, const void* __restrict__ tails,
+                                              u32* __restrict__ long_count, u32* __restrict__ long_list) {
     const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (g >= total) return;
     const size_t w = g / nb;
-    const u32* run = sorted + w * n + offsets[g];
-    const u32 cnt = counts[g];
-    Xyzz acc;
-    xyzz_set_inf(acc);
-    for (u32 e = 0; e < cnt; e++) {
-        u32 v = run[e];
-        Aff p = aff_load(bases, v & 0x7fffffffu);
-        xyzz_madd(acc, p, (v >> 31) != 0);
+    const u32 s = offsets[g], c = counts[g];
+    if (c == 0) {
+        Xyzz z;
+        xyzz_set_inf(z);
+        xyzz_store(buckets, g, z);
+        return;
     }
+    const u32 e = s + c;
+    const u32 t0 = s / T, t1 = (e - 1) / T;
+    if (t0 == t1) return;  // the whole bucket sat inside one tile and was stored by k_accum_tiles
+    if (t1 - t0 > kLongSpan) {
+        long_list[atomicAdd(long_count, 1u)] = (u32)g;
+        return;
+    }
+    const size_t base = w * tiles_per_w;
+    Xyzz acc = (s == t0 * T) ? xyzz_load(heads, base + t0) : xyzz_load(tails, base + t0);
+    for (u32 t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, xyzz_load(heads, base + t));
     xyzz_store(buckets, g, acc);
+}
+
+// one workgroup per long bucket: strided partial sums per lane, then an LDS tree
+__global__ void __launch_bounds__(kBlk) k_fixup_long(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, u32 T,
+                                                   size_t tiles_per_w, void* __restrict__ buckets, const void* __restrict__ heads,
+                                                   const void* __restrict__ tails, const u32* __restrict__ long_count,
+                                                   const u32* __restrict__ long_list) {
+    __shared__ uint4 red[kBlk * 12];  // 256 XYZZ points
+    const u32 nlong = *long_count;
+    for (u32 i = blockIdx.x; i < nlong; i += gridDim.x) {
+        const size_t g = long_list[i];
+        const size_t w = g / nb;
+        const u32 s = offsets[g], e = s + counts[g];
+        const u32 t0 = s / T, t1 = (e - 1) / T;
+        const size_t base = w * tiles_per_w;
+        Xyzz acc;
+        xyzz_set_inf(acc);
+        for (u32 k = threadIdx.x; k <= t1 - t0; k += kBlk) {
+            Xyzz piece = (k == 0 && s != t0 * T) ? xyzz_load(tails, base + t0) : xyzz_load(heads, base + t0 + k);
+            acc = xyzz_add(acc, piece);
+        }
+        xyzz_store(red, threadIdx.x, acc);
+        __syncthreads();
+        for (int stride = kBlk / 2; stride > 0; stride >>= 1) {
+            if ((int)threadIdx.x < stride) {
+                Xyzz a = xyzz_load(red, threadIdx.x), b2 = xyzz_load(red, threadIdx.x + stride);
+                xyzz_store(red, threadIdx.x, xyzz_add(a, b2));
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) xyzz_store(buckets, g, xyzz_load(red, 0));
+        __syncthreads();
+    }
 }
 
 // one bit-plane pass of the bucket reduction.  in: [W][rows][len], out: [W][rows+1][len/2]
@@ -207,31 +349,53 @@ int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars,
         return ZK_OK;
     }
     const int c = ctx->msm_window_override > 0 ? ctx->msm_window_override : msm_pick_window(n);
-    const int W = msm_windows(c);
+    const WinLayout L = msm_layout(c);
+    const int W = L.W;
     const size_t nb = (size_t)1 << (c - 1);
     const size_t total = (size_t)W * nb;
     hipStream_t st = ctx->stream;
 
-    u32* digits = (u32*)scratch(ctx, 0, (size_t)W * n * 4);
-    u32* sorted = (u32*)scratch(ctx, 1, (size_t)W * n * 4);
-    u32* cnts = (u32*)scratch(ctx, 2, 3 * total * 4);
+    const size_t ns = (n + 3) & ~(size_t)3;  // row stride of digits / sorted (16-byte rows)
+    static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
+    static const u32 bpb_env = getenv("ZK_MSM_BPB") ? (u32)atoi(getenv("ZK_MSM_BPB")) : 0;
+    const u32 T = T_env ? T_env : 32;        // sorted entries per lane in k_accum_tiles
+    const size_t tiles_per_w = (n + T - 1) / T;
+    const size_t total_tiles = tiles_per_w * W;
+    u32* digits = (u32*)scratch(ctx, 0, (size_t)W * ns * 4);
+    u32* sorted = (u32*)scratch(ctx, 1, (size_t)W * ns * 4);
+    u32* cnts = (u32*)scratch(ctx, 2, 2 * total * 4);
     void* bufA = scratch(ctx, 3, total * 192);
     void* bufB = scratch(ctx, 4, total * 192);
-    if (!digits || !sorted || !cnts || !bufA || !bufB) return ZK_ERR_OOM;
+    char* parts = (char*)scratch(ctx, 5, 2 * total_tiles * 192);
+    const size_t long_cap = total_tiles / kLongSpan + 64;
+    u32* longs = (u32*)scratch(ctx, 6, (long_cap + 1) * 4);
+    if (!digits || !sorted || !cnts || !bufA || !bufB || !parts || !longs) return ZK_ERR_OOM;
     u32* counts = cnts;
     u32* offsets = cnts + total;
-    u32* cursor = cnts + 2 * total;
+    void* heads = parts;
+    void* tails = parts + total_tiles * 192;
     const char* bases = (const char*)srs->d_bases + offset * 96;
+    // buckets per sort block: LDS counters (<= 32 KiB) vs. re-reads of the digit row
+    u32 bpb = (u32)std::min<size_t>(nb, bpb_env ? bpb_env : 4096);
+    const unsigned P = (unsigned)(nb / bpb);
 
     hipEventRecord(ctx->ev[0], st);
-    ZK_HIP(ctx, hipMemsetAsync(counts, 0, total * 4, st));
-    const unsigned gn = (unsigned)((n + kBlk - 1) / kBlk);
-    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(kBlk), 0, st, d_scalars, n, c, W, nb, digits, counts);
-    hipLaunchKernelGGL(k_scan, dim3(W), dim3(kBlk), 0, st, counts, nb, offsets, cursor);
-    hipLaunchKernelGGL(k_scatter, dim3(gn, W), dim3(kBlk), 0, st, digits, n, nb, cursor, sorted);
+    ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, d_scalars, n, ns, L, digits);
+    hipLaunchKernelGGL((k_sort_pass<false>), dim3(P, W), dim3(kSortThreads), bpb * 4, st, (const u32*)digits, ns, nb, bpb, counts,
+                       (u32*)nullptr);
+    hipLaunchKernelGGL(k_scan, dim3(W), dim3(kBlk), 0, st, (const u32*)counts, nb, offsets);
+    hipLaunchKernelGGL((k_sort_pass<true>), dim3(P, W), dim3(kSortThreads), bpb * 4, st, (const u32*)digits, ns, nb, bpb, offsets,
+                       sorted);
+    // k_sort_pass<true> advanced its LDS cursors only; offsets[] still holds the bucket starts
     hipEventRecord(ctx->ev[1], st);
-    hipLaunchKernelGGL(k_accum, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)bases, sorted, offsets,
-                       counts, n, nb, total, bufA);
+    hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)bases,
+                       (const u32*)sorted, (const u32*)offsets, (const u32*)counts, ns, nb, T, tiles_per_w, total_tiles, bufA, heads,
+                       tails);
+    hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
+                       (const u32*)counts, nb, T, tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs, longs + 1);
+    hipLaunchKernelGGL(k_fixup_long, dim3(512), dim3(kBlk), 0, st, (const u32*)offsets, (const u32*)counts, nb, T, tiles_per_w, bufA,
+                       (const void*)heads, (const void*)tails, (const u32*)longs, (const u32*)(longs + 1));
     hipEventRecord(ctx->ev[2], st);
     void* in = bufA;
     void* out = bufB;
@@ -254,13 +418,13 @@ int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars,
     ZK_HIP(ctx, hipStreamSynchronize(st));
     auto t0 = std::chrono::steady_clock::now();
     // host combine: position p = c*w + k carries weight 2^p
-    std::vector<zkhost::Jac> pos((size_t)W * c + 1, zkhost::jac_inf());
+    std::vector<zkhost::Jac> pos((size_t)256 + c + 1, zkhost::jac_inf());
     for (int w = 0; w < W; w++) {
         for (int k = 0; k < rows; k++) {
             zkhost::Jac pt = load_xyzz_host(h + ((size_t)w * rows + k) * 24);
             if (zkhost::is_zero(pt.z)) continue;
             // rows 0..rows-2 are planes T_k (weight 2^k); the last row is T_all (weight 1)
-            size_t p = (size_t)c * w + ((k == rows - 1) ? 0 : k);
+            size_t p = (size_t)L.bit_offset(w) + ((k == rows - 1) ? 0 : k);
             pos[p] = zkhost::jac_add(pos[p], pt);
         }
     }

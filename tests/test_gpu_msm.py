@@ -99,3 +99,26 @@ def test_msm_linearity_property_large(ctx, co):
     r2 = jac_norm_to_affine(ctx.msm_g1(srs, d2, n))
     r3 = jac_norm_to_affine(ctx.msm_g1(srs, d3, n))
     assert (co.g1_add_affine(r1, r2) == r3).all()
+
+
+def test_msm_skewed_scalars_long_buckets(ctx, co):
+    """skewed digit distributions (few distinct scalars -> giant buckets) take the cooperative fix-up path"""
+    n = 1 << 14
+    bases, _ = synthetic_bases(n, 120)
+    few = rand_fr(3, 121)
+    scalars = few[np.arange(n) % 3].copy()  # only three distinct scalars: ~n/3 points per bucket per window
+    scalars[::5] = rand_fr(n, 122)[::5]
+    srs = ctx.srs_register(bases)
+    exp = co.msm_g1(bases, scalars)
+    for c in (0, 9, 12):
+        ctx.msm_set_window(c)
+        try:
+            got = ctx.msm_g1(srs, ctx.to_device(scalars), n)
+        finally:
+            ctx.msm_set_window(0)
+        assert (jac_norm_to_affine(got) == exp).all(), c
+    # small scalars only (high windows all zero, low windows dense)
+    small = np.zeros((n, 4), dtype=np.uint64)
+    small[:, 0] = np.arange(n) % 7
+    sm = co.fr_to_mont(small)
+    assert (jac_norm_to_affine(ctx.msm_g1(srs, ctx.to_device(sm), n)) == co.msm_g1(bases, sm)).all()
