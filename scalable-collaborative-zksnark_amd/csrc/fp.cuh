@@ -233,6 +233,13 @@ __device__ __forceinline__ Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
     return fp_reduce_once<C>(t);
 }
 
+// Production multiplier: generated, one asm statement per accumulation run, hazard-safe carry
+// rotation (tools/gen_fp_mul.py).  The generic template above is the readable reference and the
+// -DZK_NO_ASM / -DZK_GENERIC_MUL fallback used to cross-check it.
+#if !defined(ZK_NO_ASM) && !defined(ZK_GENERIC_MUL)
+#include "fp_mul_gen.cuh"
+#endif
+
 template <class C>
 __device__ __forceinline__ Fp<C> fp_sqr(const Fp<C>& a) {
     return fp_mul<C>(a, a);

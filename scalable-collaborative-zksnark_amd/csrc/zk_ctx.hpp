@@ -23,7 +23,7 @@ struct zk_ctx {
         void* p = nullptr;
         size_t cap = 0;
     };
-    Arena scratch[8];
+    Arena scratch[12];
     void* h_pinned = nullptr;  // pinned host staging
     size_t h_pinned_cap = 0;
     int msm_window_override = 0;

@@ -93,27 +93,32 @@ __global__ void __launch_bounds__(kBlk) k_digits(const void* __restrict__ scalar
 }
 
 // ---------------------------------------------------------------------------------------
-// 2./3. counting sort with LDS-privatised counters.  Block (p, w) owns the bucket range
-// [p*bpb, (p+1)*bpb) of window w, keeps its counters / cursors in LDS and sweeps the whole digit
-// row of the window (16-byte coalesced reads served by L2 / Infinity Cache): no global atomics.
-// SCATTER = false: histogram -> counts.   SCATTER = true: cursors start at offsets; writes the
-// point index (bit 31 = negate) at its sorted position.
+// 2./3. counting sort, every digit read exactly once per pass.  A "row" is one bucket set (a
+// window, or -- with a precomputed SRS -- all windows at once).  The row is cut into chunks;
+// block (chunk, p, row) keeps the counters of bucket range p in LDS (no global atomics):
+//   k_sort_pass<false>  per-chunk histogram  -> cc[row][p][chunk][bpb]
+//   k_bucket_totals     counts[row][b] = sum over chunks
+//   k_scan              offsets[row][b] = exclusive scan of counts
+//   k_chunk_offsets     cc <- offsets[row][b] + sum of earlier chunks (start cursor of each chunk)
+//   k_sort_pass<true>   cursors from cc; writes the entry (index in row | sign bit) in place
 // ---------------------------------------------------------------------------------------
 static constexpr int kSortThreads = 1024;
 template <bool SCATTER>
-__global__ void __launch_bounds__(kSortThreads) k_sort_pass(const u32* __restrict__ digits, size_t ns, size_t nb, u32 bpb,
-                                                          u32* __restrict__ counts_or_offsets, u32* __restrict__ sorted) {
+__global__ void __launch_bounds__(kSortThreads) k_sort_pass(const u32* __restrict__ digits, size_t row_len, size_t chunk_len,
+                                                          u32 nchunks, size_t nb, u32 bpb, u32* __restrict__ cc,
+                                                          u32* __restrict__ sorted) {
     extern __shared__ u32 cnt[];
-    const int w = blockIdx.y;
-    const u32 lo = blockIdx.x * bpb;
-    u32* glob = counts_or_offsets + (size_t)w * nb + lo;
+    const u32 chunk = blockIdx.x, p = blockIdx.y, row = blockIdx.z, P = gridDim.y;
+    const u32 lo = p * bpb;
+    u32* glob = cc + (((size_t)row * P + p) * nchunks + chunk) * bpb;
     for (u32 i = threadIdx.x; i < bpb; i += kSortThreads) cnt[i] = SCATTER ? glob[i] : 0u;
     __syncthreads();
-    const uint4* row = reinterpret_cast<const uint4*>(digits + (size_t)w * ns);
-    u32* out = sorted + (size_t)w * ns;
-    const size_t n4 = ns >> 2;
-    for (size_t i4 = threadIdx.x; i4 < n4; i4 += kSortThreads) {
-        uint4 d4 = row[i4];
+    const size_t c0 = (size_t)chunk * chunk_len;                        // multiple of 4
+    const size_t c1 = (c0 + chunk_len < row_len) ? c0 + chunk_len : row_len;  // row_len multiple of 4
+    const uint4* row4 = reinterpret_cast<const uint4*>(digits + (size_t)row * row_len);
+    u32* out = sorted + (size_t)row * row_len;
+    for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
+        uint4 d4 = row4[i4];
         u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -135,26 +140,50 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_pass(const u32* __restric
     }
 }
 
-// exclusive scan of counts[w][0..nb) -> offsets.  One block per window.
-__global__ void __launch_bounds__(kBlk) k_scan(const u32* __restrict__ counts, size_t nb, u32* __restrict__ offsets) {
-    __shared__ u32 part[kBlk];
+// counts[row][b] = sum over chunks of cc[row][p][chunk][b - p*bpb]
+__global__ void __launch_bounds__(kBlk) k_bucket_totals(const u32* __restrict__ cc, u32 nchunks, size_t nb, u32 bpb, size_t total,
+                                                      u32* __restrict__ counts) {
+    const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (g >= total) return;
+    const size_t row = g / nb, b = g % nb, p = b / bpb, bl = b % bpb, P = nb / bpb;
+    const u32* src = cc + ((row * P + p) * nchunks) * bpb + bl;
+    u32 s = 0;
+    for (u32 ch = 0; ch < nchunks; ch++) s += src[(size_t)ch * bpb];
+    counts[g] = s;
+}
+__global__ void __launch_bounds__(kBlk) k_chunk_offsets(u32* __restrict__ cc, u32 nchunks, size_t nb, u32 bpb, size_t total,
+                                                      const u32* __restrict__ offsets) {
+    const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (g >= total) return;
+    const size_t row = g / nb, b = g % nb, p = b / bpb, bl = b % bpb, P = nb / bpb;
+    u32* src = cc + ((row * P + p) * nchunks) * bpb + bl;
+    u32 run = offsets[g];
+    for (u32 ch = 0; ch < nchunks; ch++) {
+        u32 v = src[(size_t)ch * bpb];
+        src[(size_t)ch * bpb] = run;
+        run += v;
+    }
+}
+
+// exclusive scan of counts[row][0..nb) -> offsets.  One block per row.
+static constexpr int kScanThreads = 1024;
+__global__ void __launch_bounds__(kScanThreads) k_scan(const u32* __restrict__ counts, size_t nb, u32* __restrict__ offsets) {
+    __shared__ u32 part[kScanThreads];
     const int w = blockIdx.x, tid = threadIdx.x;
-    const size_t per = (nb + kBlk - 1) / kBlk;
+    const size_t per = (nb + kScanThreads - 1) / kScanThreads;
     const size_t lo = (size_t)tid * per, hi = (lo + per < nb) ? lo + per : nb;
     u32 s = 0;
     for (size_t b = lo; b < hi; b++) s += counts[(size_t)w * nb + b];
     part[tid] = s;
     __syncthreads();
-    if (tid == 0) {
-        u32 run = 0;
-        for (int t = 0; t < kBlk; t++) {
-            u32 v = part[t];
-            part[t] = run;
-            run += v;
-        }
+    // Hillis-Steele inclusive scan over the 1024 per-thread sums
+    for (int off = 1; off < kScanThreads; off <<= 1) {
+        u32 v = (tid >= off) ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
     }
-    __syncthreads();
-    u32 run = part[tid];
+    u32 run = part[tid] - s;  // exclusive
     for (size_t b = lo; b < hi; b++) {
         offsets[(size_t)w * nb + b] = run;
         run += counts[(size_t)w * nb + b];
@@ -358,7 +387,16 @@ int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars,
     const size_t ns = (n + 3) & ~(size_t)3;  // row stride of digits / sorted (16-byte rows)
     static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
     static const u32 bpb_env = getenv("ZK_MSM_BPB") ? (u32)atoi(getenv("ZK_MSM_BPB")) : 0;
-    const u32 T = T_env ? T_env : 32;        // sorted entries per lane in k_accum_tiles
+    // sorted entries per lane in k_accum_tiles: 32 when there is enough work to fill the chip;
+    // for small MSMs balance the serial chain of a lane (T mixed adds, ~10 Fq-mul each) against
+    // the fix-up chain of a bucket (entries_per_bucket / T full adds, ~14 Fq-mul each)
+    u32 T = 32;
+    if ((size_t)W * n / T < (size_t)ctx->cu_count * 4 * 64 * 2) {
+        const double per_bucket = (double)n / (double)nb;
+        T = 4;
+        while (T < 32 && (double)T * T < 1.4 * per_bucket) T <<= 1;
+    }
+    if (T_env) T = T_env;
     const size_t tiles_per_w = (n + T - 1) / T;
     const size_t total_tiles = tiles_per_w * W;
     u32* digits = (u32*)scratch(ctx, 0, (size_t)W * ns * 4);
@@ -375,19 +413,30 @@ int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars,
     void* heads = parts;
     void* tails = parts + total_tiles * 192;
     const char* bases = (const char*)srs->d_bases + offset * 96;
-    // buckets per sort block: LDS counters (<= 32 KiB) vs. re-reads of the digit row
-    u32 bpb = (u32)std::min<size_t>(nb, bpb_env ? bpb_env : 4096);
+    // sort geometry: rows x chunks x bucket ranges; LDS counters <= 64 KiB per block
+    const size_t srows = W, row_len = ns;
+    const u32 bpb = (u32)std::min<size_t>(nb, bpb_env ? bpb_env : 16384);
     const unsigned P = (unsigned)(nb / bpb);
+    u32 nchunks = (u32)std::max<size_t>(1, std::min<size_t>(512 / (srows * P) ? 512 / (srows * P) : 1, (row_len + 8191) / 8192));
+    size_t chunk_len = ((row_len + nchunks - 1) / nchunks + 3) & ~(size_t)3;
+    nchunks = (u32)((row_len + chunk_len - 1) / chunk_len);
+    u32* cc = (u32*)scratch(ctx, 8, srows * P * (size_t)nchunks * bpb * 4);
+    if (!cc) return ZK_ERR_OOM;
 
+    hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipEventRecord(ctx->ev[0], st);
     ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, d_scalars, n, ns, L, digits);
-    hipLaunchKernelGGL((k_sort_pass<false>), dim3(P, W), dim3(kSortThreads), bpb * 4, st, (const u32*)digits, ns, nb, bpb, counts,
-                       (u32*)nullptr);
-    hipLaunchKernelGGL(k_scan, dim3(W), dim3(kBlk), 0, st, (const u32*)counts, nb, offsets);
-    hipLaunchKernelGGL((k_sort_pass<true>), dim3(P, W), dim3(kSortThreads), bpb * 4, st, (const u32*)digits, ns, nb, bpb, offsets,
-                       sorted);
-    // k_sort_pass<true> advanced its LDS cursors only; offsets[] still holds the bucket starts
+    hipLaunchKernelGGL((k_sort_pass<false>), dim3(nchunks, P, (unsigned)srows), dim3(kSortThreads), bpb * 4, st, (const u32*)digits,
+                       row_len, chunk_len, nchunks, nb, bpb, cc, (u32*)nullptr);
+    hipLaunchKernelGGL(k_bucket_totals, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)cc, nchunks, nb, bpb,
+                       total, counts);
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)srows), dim3(kScanThreads), 0, st, (const u32*)counts, nb, offsets);
+    hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, cc, nchunks, nb, bpb, total,
+                       (const u32*)offsets);
+    hipLaunchKernelGGL((k_sort_pass<true>), dim3(nchunks, P, (unsigned)srows), dim3(kSortThreads), bpb * 4, st, (const u32*)digits,
+                       row_len, chunk_len, nchunks, nb, bpb, cc, sorted);
     hipEventRecord(ctx->ev[1], st);
     hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)bases,
                        (const u32*)sorted, (const u32*)offsets, (const u32*)counts, ns, nb, T, tiles_per_w, total_tiles, bufA, heads,
