@@ -72,6 +72,9 @@ int zk_fr_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t
 /* out[i] = a[i] + alpha*b[i] + beta          (`s + alpha*sid + beta`, dhyperplonk.rs:326-337) */
 int zk_fr_axpb(zk_ctx *ctx, const void *d_a, const void *d_b, const uint64_t h_alpha[4],
                const uint64_t h_beta[4], void *d_out, size_t n);
+/* strided views of the product tree (dacc_product.rs:41-55, dhyperplonk.rs:344-359):
+ * even[i] = t[2i] (v(x,0)), odd[i] = t[2i+1] (v(x,1)), i < n; v(1,x) is the contiguous upper half. */
+int zk_fr_deinterleave(zk_ctx *ctx, const void *d_t, void *d_even, void *d_odd, size_t n);
 /* out[i] = num[i] / den[i] (dhyperplonk.rs:339), batched inversion; ZK_ERR_DIV_ZERO if a den is 0 */
 int zk_fr_batch_div(zk_ctx *ctx, const void *d_num, const void *d_den, void *d_out, size_t n);
 

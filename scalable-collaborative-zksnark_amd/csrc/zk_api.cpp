@@ -164,6 +164,10 @@ int zk_fr_axpb(zk_ctx* ctx, const void* a, const void* b, const uint64_t alpha[4
     NEED(ctx, alpha && beta && (n == 0 || (a && b && out)));
     return fr_axpb(ctx, a, b, alpha, beta, out, n);
 }
+int zk_fr_deinterleave(zk_ctx* ctx, const void* d_t, void* d_even, void* d_odd, size_t n) {
+    NEED(ctx, n == 0 || (d_t && d_even && d_odd));
+    return fr_deinterleave(ctx, d_t, d_even, d_odd, n);
+}
 int zk_fr_batch_div(zk_ctx* ctx, const void* num, const void* den, void* out, size_t n) {
     NEED(ctx, n == 0 || (num && den && out));
     return fr_batch_div(ctx, num, den, out, n);

@@ -450,6 +450,16 @@ __global__ void __launch_bounds__(kBlock) k_fp_binary(const void* __restrict__ a
     }
 }
 
+// K7 strided splits (dacc_product.rs:41-55, dhyperplonk.rs:344-359): even[i] = t[2i], odd[i] = t[2i+1]
+__global__ void __launch_bounds__(kBlock) k_fr_deinterleave(const void* __restrict__ t, void* __restrict__ even,
+                                                          void* __restrict__ odd, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        // one lane moves a 64-byte pair: both halves of the read are contiguous across the wave
+        fr_store(even, i, fr_load(t, 2 * i));
+        fr_store(odd, i, fr_load(t, 2 * i + 1));
+    }
+}
+
 static unsigned grid_for(zk_ctx* ctx, size_t n) {
     size_t b = (n + kBlock - 1) / kBlock;
     size_t maxb = (size_t)ctx->cu_count * 8;
@@ -473,6 +483,13 @@ int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t 
     if (op == 0) hipLaunchKernelGGL((k_fp_binary<FqCfg, 0>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
     else if (op == 1) hipLaunchKernelGGL((k_fp_binary<FqCfg, 1>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
     else hipLaunchKernelGGL((k_fp_binary<FqCfg, 2>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+int fr_deinterleave(zk_ctx* ctx, const void* t, void* even, void* odd, size_t n) {
+    if (n == 0) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_fr_deinterleave, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, t, even, odd, n);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }

@@ -163,6 +163,12 @@ class Ctx:
     def fr_mul(self, a, b, n, out=None):
         return self._binary(self.lib.zk_fr_mul, a, b, n, out)
 
+    def fr_deinterleave(self, t, n):
+        """(t[0::2], t[1::2]) for a table of 2n Fr -> two device buffers of n Fr"""
+        even, odd = self.alloc(max(32 * n, 1)), self.alloc(max(32 * n, 1))
+        self._check(self.lib.zk_fr_deinterleave(self.h, _ptr(t), _ptr(even), _ptr(odd), n))
+        return even, odd
+
     def fr_batch_div(self, num, den, n, out=None):
         out = out or self.alloc(max(32 * n, 1))
         rc = self.lib.zk_fr_batch_div(self.h, _ptr(num), _ptr(den), _ptr(out), n)

@@ -223,3 +223,179 @@ def d_commit(be, powers_of_g, peval, length: int, net: Net) -> np.ndarray:
     pts = np.stack(net.all_gather(local))
     ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
     return be.g1_lincomb(pts, ones)
+
+
+def c_commit(be, powers_of_g, pevals: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """dpoly_comm.rs:244-267: d_msm with bases_k = powers_of_g[log2(len_k * l)] -> [batch, 18]"""
+    bases = []
+    for n in lens:
+        level = (n * pp.l).bit_length() - 1
+        assert level < len(powers_of_g) and n * pp.l == 1 << level  # :256-257
+        bases.append(powers_of_g[level])
+    return d_msm(be, bases, pevals, lens, pp, net)
+
+
+def d_open(be, powers_of_g, peval, length: int, point: np.ndarray, net: Net):
+    """
+    dpoly_comm.rs:355-398.  Leader: (root value [4], root proofs (s entries) ++ summed local proofs
+    (n' entries)) -- root proofs FIRST (:379-384); workers: (0, []).
+    """
+    plog = net.n_parties.bit_length() - 1
+    point = np.asarray(point, dtype=np.uint64).reshape(-1, 4)
+    value, proofs = open_(be, powers_of_g, peval, length, point[plog:])
+    vals = net.all_gather(np.asarray(value, dtype=np.uint64).reshape(4))
+    prfs = net.all_gather(proofs)
+    if not net.is_leader:
+        return ZERO.copy(), np.zeros((0, 18), dtype=np.uint64)
+    ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
+    pi = [be.g1_lincomb(np.stack([prfs[p][i] for p in range(net.n_parties)]), ones) for i in range(len(proofs))]
+    root_val, root_proofs = open_(be, powers_of_g, be.to_device(np.stack(vals)), net.n_parties, point[:plog])
+    allp = list(root_proofs) + pi
+    return root_val, (np.stack(allp) if allp else np.zeros((0, 18), dtype=np.uint64))
+
+
+def c_open(be, powers_of_g, peval, length: int, point: np.ndarray, pp: PackedSharingParams, net: Net):
+    """
+    dpoly_comm.rs:401-464: n fold rounds producing every q_i, ONE batched d_msm over them (:436),
+    pss2ss of the last value, then log2(l) more rounds on the l-vector re-using point[0..] (:452).
+    Returns (value [4], proofs [n + log2 l, 18]).
+    """
+    n = length.bit_length() - 1
+    point = np.asarray(point, dtype=np.uint64).reshape(-1, 4)
+    q, value = be.open_rounds(peval, length, point[:n])
+    bufs, lens, off, m = [], [], 0, length
+    for _ in range(n):
+        h = m // 2
+        bufs.append(q.at(32 * off))
+        lens.append(h)
+        off += h
+        m = h
+    res = list(c_commit(be, powers_of_g, bufs, lens, pp, net)) if n else []
+    cur = _fr_vec_to_ints(pss2ss(value, pp, net))
+    pt = _fr_vec_to_ints(point)
+    for i in range(pp.l.bit_length() - 1):
+        h = len(cur) // 2
+        qi = [(cur[j + h] - cur[j]) % R_MOD for j in range(h)]
+        level = (len(qi) * pp.l).bit_length() - 1
+        res.append(be.msm_g1(powers_of_g[level], be.to_device(_ints_to_fr(qi)), len(qi)))
+        cur = [(cur[j] * (1 - pt[i]) + cur[j + h] * pt[i]) % R_MOD for j in range(h)]
+    return fr_mont(cur[0]), (np.stack(res) if res else np.zeros((0, 18), dtype=np.uint64))
+
+
+def fix_variable(be, evaluations, length: int, points: np.ndarray):
+    """mle.rs:88-105 -> device buffer of length >> min(n, len(points))"""
+    return be.fold(evaluations, length, points)
+
+
+def d_fix_variable(be, shares, length: int, points: np.ndarray, pp: PackedSharingParams, net: Net):
+    """mle.rs:51-86: returns a device buffer (points <= n) or a [1,4] host array (points > n)"""
+    n = length.bit_length() - 1
+    points = np.asarray(points, dtype=np.uint64).reshape(-1, 4)
+    cnt = len(points)
+    folded = be.fold(shares, length, points[: min(n, cnt)])
+    if cnt <= n:
+        return folded
+    last = folded.download((1, 4))[0]
+    cur = _fr_vec_to_ints(pss2ss(last, pp, net))
+    pt = _fr_vec_to_ints(points)
+    for i in range(min(cnt - n, pp.l.bit_length() - 1)):  # re-uses points[0..] (:78)
+        h = len(cur) // 2
+        cur = [(cur[j] * (1 - pt[i]) + cur[j + h] * pt[i]) % R_MOD for j in range(h)]
+    return _ints_to_fr([cur[0]])
+
+
+# ---------------------------------------------------------------------------------------
+# small exchanges: degree reduction and unpacking (degree_reduce.rs, unpack.rs)
+# ---------------------------------------------------------------------------------------
+def _apply_rows(rows: Sequence[Sequence[int]], columns: Sequence[np.ndarray]) -> np.ndarray:
+    """out[r][k] = sum_i rows[r][i] * columns[i][k]; columns[i]: [k,4] limbs -> [len(rows), k, 4]"""
+    cols = [_fr_vec_to_ints(c) for c in columns]
+    k = len(cols[0])
+    out = [[sum(row[i] * cols[i][j] for i in range(len(cols))) % R_MOD for j in range(k)] for row in rows]
+    return np.stack([_ints_to_fr(o) for o in out]) if k else np.zeros((len(rows), 0, 4), dtype=np.uint64)
+
+
+def degree_reduce_many(shares: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """degree_reduce.rs:10-26: element-wise pack_from_public(unpack2(.))[party] over the batch ([k,4] -> [k,4])"""
+    shares = np.asarray(shares, dtype=np.uint64).reshape(-1, 4)
+    allp = net.all_gather(shares)
+    # D = pack o unpack2 restricted to this party's row: out = sum_i D[p][i] * v_i
+    p, l = net.party_id, pp.l
+    if l == 1:
+        row = [pp.pack_matrix[p][0] * pp.unpack2_matrix[0][i] % R_MOD for i in range(pp.n)]
+        return _apply_rows([row], allp)[0]
+    # general l: the batch is processed per element exactly as the reference does (vector per item)
+    cols = [_fr_vec_to_ints(a) for a in allp]
+    out = []
+    for k in range(len(shares)):
+        out.append(pp.pack_from_public(pp.unpack2([cols[i][k] for i in range(pp.n)]))[p])
+    return _ints_to_fr(out)
+
+
+def degree_reduce(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """degree_reduce.rs:29-41"""
+    vals = _fr_vec_to_ints(np.stack(net.all_gather(np.asarray(share, dtype=np.uint64).reshape(4))))
+    return fr_mont(pp.pack_from_public(pp.unpack2(vals))[net.party_id])
+
+
+def d_unpack_0(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """unpack.rs:8-18: every party receives unpack(shares)[0]"""
+    vals = _fr_vec_to_ints(np.stack(net.all_gather(np.asarray(share, dtype=np.uint64).reshape(4))))
+    return fr_mont(pp.unpack(vals)[0])
+
+
+def d_unpack(share: np.ndarray, receiver: int, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """unpack.rs:20-35: only `receiver` obtains unpack(shares) ([l,4]); others an empty Vec"""
+    vals = net.all_gather(np.asarray(share, dtype=np.uint64).reshape(4))
+    if net.party_id != receiver:
+        return np.zeros((0, 4), dtype=np.uint64)
+    return _ints_to_fr(pp.unpack(_fr_vec_to_ints(np.stack(vals))))
+
+
+def d_unpack2(share: np.ndarray, receiver: int, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """unpack.rs:37-52"""
+    vals = net.all_gather(np.asarray(share, dtype=np.uint64).reshape(4))
+    if net.party_id != receiver:
+        return np.zeros((0, 4), dtype=np.uint64)
+    return _ints_to_fr(pp.unpack2(_fr_vec_to_ints(np.stack(vals))))
+
+
+def d_unpack2_many(share: np.ndarray, receiver: int, pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """unpack.rs:55-70: receiver gets transpose(shares).flat_map(unpack2) = [k*l, 4]"""
+    share = np.asarray(share, dtype=np.uint64).reshape(-1, 4)
+    allp = net.all_gather(share)
+    if net.party_id != receiver:
+        return np.zeros((0, 4), dtype=np.uint64)
+    cols = [_fr_vec_to_ints(a) for a in allp]
+    out = []
+    for k in range(len(share)):
+        out.extend(pp.unpack2([cols[i][k] for i in range(pp.n)]))
+    return _ints_to_fr(out)
+
+
+def c_acc_product(be, inputs, N: int, pp: PackedSharingParams, net: Net):
+    """
+    dacc_product.rs:296-363: local subtree; every party sends its LAST min(N_p, 2N) entries (:321-329);
+    the leader interleaves them level by level (:339-349) and appends N_p - 1 products and a 0.
+    Returns (subtree device buffer, leader tree [.,4] or None).
+    """
+    subtree = be.product_tree(inputs, N)
+    npar = pp.n
+    num_to_send = min(npar, 2 * N)
+    tail = subtree.download((num_to_send, 4), offset=32 * (2 * N - num_to_send))
+    recv = net.all_gather(tail)
+    if not net.is_leader:
+        return subtree, None
+    r = [_fr_vec_to_ints(a) for a in recv]
+    tree, layer, start = [], 1 << (num_to_send.bit_length() - 1 - 1), 0
+    while layer > 0:
+        for j in range(npar):
+            tree.extend(r[j][start : start + layer])
+        start += layer
+        layer >>= 1
+    total = num_to_send * npar
+    for i in range(total - npar, total - 1):
+        a, b = sub_index(i)
+        tree.append(tree[a] * tree[b] % R_MOD)
+    tree.append(0)
+    return subtree, _ints_to_fr(tree)

@@ -84,3 +84,38 @@ class OracleBackend:
     def open_rounds(self, tab, length, point):
         q, v = co.open_quotients(_arr(tab)[:length], np.asarray(point).reshape(-1, 4))
         return NumpyBuf(q if len(q) else np.zeros((1, 4), np.uint64)), v
+
+    # element-wise / table helpers used by the protocol driver
+    def fr_add(self, a, b, n, out=None):
+        return NumpyBuf(co.fr_add(_arr(a)[:n], _arr(b)[:n]))
+
+    def fr_sub(self, a, b, n, out=None):
+        return NumpyBuf(co.fr_sub(_arr(a)[:n], _arr(b)[:n]))
+
+    def fr_mul(self, a, b, n, out=None):
+        return NumpyBuf(co.fr_mul(_arr(a)[:n], _arr(b)[:n]))
+
+    def fr_axpb(self, a, b, alpha, beta, n, out=None):
+        al = np.tile(np.asarray(alpha, dtype=np.uint64).reshape(1, 4), (n, 1))
+        be = np.tile(np.asarray(beta, dtype=np.uint64).reshape(1, 4), (n, 1))
+        return NumpyBuf(co.fr_add(co.fr_add(_arr(a)[:n], co.fr_mul(al, _arr(b)[:n])), be))
+
+    def fr_batch_div(self, num, den, n, out=None):
+        return NumpyBuf(co.fr_div(_arr(num)[:n], _arr(den)[:n]))
+
+    def fr_deinterleave(self, t, n):
+        a = _arr(t)[: 2 * n]
+        return NumpyBuf(a[0::2].copy()), NumpyBuf(a[1::2].copy())
+
+    def fold(self, tab, length, points, out=None):
+        cur = _arr(tab)[:length]
+        pts = np.asarray(points, dtype=np.uint64).reshape(-1, 4)
+        for i in range(min(length.bit_length() - 1, len(pts))):
+            cur = co.fold(cur, pts[i])
+        return NumpyBuf(cur)
+
+    def srs_generate(self, k0, k1, n):
+        from helpers import pt_mont
+        start = pt_mont(po.g1_mul(po.G1_GEN, k0))
+        step = pt_mont(po.g1_mul(po.G1_GEN, k1))
+        return OracleSrs(co.g1_arith_seq(start, step, n))

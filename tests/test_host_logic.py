@@ -137,3 +137,95 @@ def test_commit_open_and_d_commit():
     res = LocalTestNet.simulate_network_round(np_, party)
     exp = po.d_commit_all(levels_pts, chunks)
     assert all(jac_pt(r) == exp for r in res)
+
+
+@pytest.mark.parametrize("l", [1, 2])
+def test_c_open_d_open_over_threads(l):
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    be = OracleBackend()
+    n = 3
+    rng = po.SplitMix64(140 + l)
+    levels_pts = [po.g1_bases(max(1, (1 << k) // l), 400 + k) for k in range(n + 2)]  # new_single: level k has 2^k / l points
+    levels = [OracleSrs(np.array([pt_mont(P) for P in lv])) for lv in levels_pts]
+    pevals = [rng.fr_vec(1 << n) for _ in range(pp.n)]
+    point = rng.fr_vec(n + 1)
+
+    def party(net):
+        return dp.c_open(be, levels, be.to_device(to_m(pevals[net.party_id])), 1 << n, to_m(point), pp, net)
+
+    res = LocalTestNet.simulate_network_round(pp.n, party)
+    exp = po.c_open_all(levels_pts, pevals, point, opp)
+    for p in range(pp.n):
+        assert ints(res[p][0]) == [exp[p][0]]
+        assert [jac_pt(j) for j in res[p][1]] == exp[p][1]
+
+
+def test_d_open_over_threads():
+    be = OracleBackend()
+    np_, n = 8, 3
+    levels_pts = [po.g1_bases(1 << k, 500 + k) for k in range(n + 1)]
+    levels = [OracleSrs(np.array([pt_mont(P) for P in lv])) for lv in levels_pts]
+    rng = po.SplitMix64(150)
+    chunks = [rng.fr_vec(1 << n) for _ in range(np_)]
+    point = rng.fr_vec(n + 3)
+
+    def party(net):
+        return dp.d_open(be, levels, be.to_device(to_m(chunks[net.party_id])), 1 << n, to_m(point), net)
+
+    res = LocalTestNet.simulate_network_round(np_, party)
+    ev, eproofs = po.d_open_all(levels_pts, chunks, point)
+    assert ints(res[0][0]) == [ev] and [jac_pt(j) for j in res[0][1]] == eproofs
+    for p in range(1, np_):
+        assert ints(res[p][0]) == [0] and len(res[p][1]) == 0  # workers: (0, [])
+
+
+@pytest.mark.parametrize("l", [1, 2])
+def test_degree_reduce_unpack_and_c_acc_product(l):
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    be = OracleBackend()
+    rng = po.SplitMix64(160 + l)
+    k = 5
+    shares = [rng.fr_vec(k) for _ in range(pp.n)]
+    inputs = [rng.fr_vec(8) for _ in range(pp.n)]
+
+    def party(net):
+        p = net.party_id
+        a = dp.degree_reduce_many(to_m(shares[p]), pp, net)
+        b = dp.degree_reduce(to_m(shares[p][:1])[0], pp, net)
+        c = dp.d_unpack2_many(to_m(shares[p]), 3, pp, net)
+        d = dp.d_unpack_0(to_m(shares[p][:1])[0], pp, net)
+        tree, top = dp.c_acc_product(be, be.to_device(to_m(inputs[p])), 8, pp, net)
+        return a, b, c, d, tree.download((16, 4)), top
+
+    res = LocalTestNet.simulate_network_round(pp.n, party)
+    exp = po.degree_reduce_many_all(shares, opp)
+    sub, leader = po.c_acc_product_all(inputs, opp)
+    flat = [v for kk in range(k) for v in opp.unpack2([shares[i][kk] for i in range(pp.n)])]
+    for p in range(pp.n):
+        assert ints(res[p][0]) == exp[p]
+        assert ints(res[p][1]) == [exp[p][0]]
+        assert ints(res[p][2]) == (flat if p == 3 else [])
+        assert ints(res[p][3]) == [opp.unpack([shares[i][0] for i in range(pp.n)])[0]]
+        assert ints(res[p][4]) == sub[p]
+    assert ints(res[0][5]) == leader and all(res[p][5] is None for p in range(1, pp.n))
+
+
+def test_d_fix_variable():
+    pp, opp = PackedSharingParams(2), po.PackedSharingParams(2)
+    be = OracleBackend()
+    rng = po.SplitMix64(170)
+    n = 3
+    shares = [rng.fr_vec(1 << n) for _ in range(pp.n)]
+    pts = rng.fr_vec(n + 1)
+
+    def party(net):
+        short = dp.d_fix_variable(be, be.to_device(to_m(shares[net.party_id])), 1 << n, to_m(pts[:2]), pp, net)
+        full = dp.d_fix_variable(be, be.to_device(to_m(shares[net.party_id])), 1 << n, to_m(pts), pp, net)
+        return short.download((2, 4)), full
+
+    res = LocalTestNet.simulate_network_round(pp.n, party)
+    lasts = [po.fix_variable(shares[p], pts[:n])[0] for p in range(pp.n)]
+    ss = po.pss2ss_all(lasts, opp)
+    for p in range(pp.n):
+        assert ints(res[p][0]) == po.fix_variable(shares[p], pts[:2])
+        assert ints(res[p][1]) == po.fold(ss[p], pts[0])  # one extra round re-using points[0] (mle.rs:78)
