@@ -1,0 +1,206 @@
+"""
+Collaborative HyperPlonk call sequence -- host-side mirror of hyperplonk/src/dhyperplonk.rs
+(`PackedProvingParameters::new` :65-156, `dhyperplonk` :159-571, `dhyperplonk_data_parallel`
+:573-960).  Like the reference it is a FIXED sequence of dist-primitive calls on synthetic
+(random) tables: there is no circuit and no Fiat-Shamir, every challenge is pre-sampled.
+All tables and SRS levels are resident in HBM; every primitive runs through libzkhip.so.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+
+from . import dist_primitive as dp
+from .field import fr_mont, random_fr
+from .net import Net
+from .pss import PackedSharingParams
+
+
+class Timers:
+    """wall-clock sections with the reference's labels (mpc-net/src/utils/timer.rs), leader only"""
+
+    def __init__(self, enabled: bool):
+        self.enabled, self.t, self.stack = enabled, {}, []
+
+    def start(self, label):
+        self.stack.append((label, time.perf_counter()))
+
+    def end(self):
+        label, t0 = self.stack.pop()
+        self.t[label] = self.t.get(label, 0.0) + time.perf_counter() - t0
+
+
+@dataclass
+class PackedProvingParameters:
+    """hyperplonk/src/dhyperplonk.rs:19-63; every table is a device buffer of Fr, lengths in `n_`"""
+
+    n: int
+    tables: Dict[str, object] = field(default_factory=dict)
+    lens: Dict[str, int] = field(default_factory=dict)
+    challenge: np.ndarray = None
+    challenge_r1: np.ndarray = None
+    challenge_r2: np.ndarray = None
+    alpha: np.ndarray = None
+    beta: np.ndarray = None
+    gamma: np.ndarray = None
+    c_commitment: List = None  # powers_of_g levels 0..n+2 (new_single, dpoly_comm.rs:197-219)
+    d_commitment: List = None  # levels 0..n-1          (new_random, dpoly_comm.rs:220-233)
+
+    @staticmethod
+    def new(n: int, pp: PackedSharingParams, be, seed: int) -> "PackedProvingParameters":
+        """dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy()"""
+        l, npar = pp.l, pp.n
+        M = 1 << n
+        pk = PackedProvingParameters(n=n)
+        sd = [seed * 1000]
+
+        def rnd(name, length):
+            sd[0] += 1
+            pk.tables[name] = be.to_device(random_fr(length, sd[0]))
+            pk.lens[name] = length
+
+        rnd("V", 4 * M // l)
+        zero, one = fr_mont(0), fr_mont(1)
+        for name, pts in (("a_evals", (zero, zero)), ("b_evals", (zero, one)), ("c_evals", (one, zero))):
+            pk.tables[name] = be.fold(pk.tables["V"], 4 * M // l, np.stack(pts))  # fix_variable(&V, ..) :71-73
+            pk.lens[name] = M // l
+        for name, length in (
+            ("I", M // l), ("I_p", M // npar), ("S1", M // l), ("S2", M // l), ("S1_p", M // npar), ("S2_p", M // npar),
+            ("ssigma", 4 * M // l), ("ssigma_p", 4 * M // npar), ("sid", 4 * M // l), ("sid_p", 4 * M // npar),
+            ("eq", M // l), ("eq_top_p", 2 * npar), ("eq_r1", 4 * M // l), ("eq_r1_p", 4 * M // npar),
+            ("eq_r2", 4 * M // l), ("eq_r2_p", 4 * M // npar),
+        ):
+            rnd(name, length)
+        sd[0] += 1
+        ch = random_fr(3 * n + 4 + 3, sd[0])
+        pk.challenge, pk.challenge_r1, pk.challenge_r2 = ch[:n], ch[n : 2 * n + 2], ch[2 * n + 2 : 3 * n + 4]
+        pk.alpha, pk.beta, pk.gamma = ch[3 * n + 4], ch[3 * n + 5], ch[3 * n + 6]
+        # synthetic SRS (random points in the reference as well)
+        pk.c_commitment = [be.srs_generate(seed * 7919 + 2 * i + 1, seed * 104729 + 2 * i + 3, max(1, (1 << i) // l)) for i in range(n + 3)]
+        pk.d_commitment = [be.srs_generate(seed * 6007 + 2 * i + 5, seed * 15485863 + 2 * i + 7, 1 << i) for i in range(n - (npar.bit_length() - 1) + 3)]
+        return pk
+
+
+def _halves(buf, length):
+    """(first half, second half) of a device table as (pointer-like, length) pairs"""
+    return buf, _at(buf, 32 * (length // 2))
+
+
+def _at(buf, byte_off):
+    return buf.at(byte_off) if hasattr(buf, "at") else buf + byte_off
+
+
+def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be, net: Net, seed: int = 1, data_parallel: bool = False):
+    """
+    dhyperplonk.rs:159-571 (data_parallel=True: dhyperplonk_data_parallel :573-960, which differs
+    only at step 2.a -- `s` is local random data, no exchange, :603).
+    Returns ((gate_identity_proofs, gate_identity_commitments), (wiring_proofs, wiring_commits, wiring_opens)), timers.
+    """
+    T, L = pk.tables, pk.lens
+    l, npar = pp.l, net.n_parties
+    M = 1 << n
+    tm = Timers(net.is_leader)
+    # "Jump from sky" (:187-190)
+    local_s_p = be.to_device(random_fr(4 * M // npar, seed * 31 + 1))
+    local_s_np = random_fr(4 * M // npar // l, seed * 31 + 2)
+    eq_top = be.to_device(random_fr(pp.n, seed * 31 + 3))
+    net.sync()
+    tm.start("Distributed HyperPlonk")
+
+    # Step 1: commit (:198-215)
+    tm.start("Commit")
+    cc, dc = pk.c_commitment, pk.d_commitment
+    com = {}
+    for name in ("a_evals", "b_evals", "c_evals"):
+        com[name] = dp.c_commit(be, cc, [T[name]], [L[name]], pp, net)[0]
+    for name in ("I_p", "S1_p", "S2_p"):
+        com[name] = dp.d_commit(be, dc, T[name], L[name], net)
+    tm.end()
+
+    # Step 3: gate identity (:223-260)
+    tm.start("Gate identity")
+    gate_proofs = []
+    csp = lambda f, g, length: dp.c_sumcheck_product(be, f, g, length, pk.challenge, pp, net)
+    Ml = M // l
+    gate_proofs.append(csp(T["eq"], T["S1"], Ml))
+    sum_ab = be.fr_add(T["a_evals"], T["b_evals"], Ml)  # :233-238
+    gate_proofs.append(csp(T["S1"], sum_ab, Ml))
+    gate_proofs.append(csp(T["eq"], T["S2"], Ml))
+    gate_proofs.append(csp(T["a_evals"], T["b_evals"], Ml))
+    gate_proofs.append(csp(T["S2"], T["a_evals"], Ml))
+    sum_ci = be.fr_sub(T["I"], T["c_evals"], Ml)  # -c + I  :251-256
+    gate_proofs.append(csp(T["eq"], sum_ci, Ml))
+    tm.end()
+
+    # Step 2: wiring identity
+    tm.start("Wire identity")
+    wiring_proofs, wiring_commits, wiring_opens = [], [], []
+    # 2.a (:268-294): every party broadcasts local_s; s = concatenation over parties (an all-gather)
+    if data_parallel:
+        s_np = random_fr(4 * M // l, seed * 31 + 4)
+    else:
+        s_np = np.concatenate(net.all_gather(local_s_np))
+    s_dev = be.to_device(s_np)
+    wiring_commits.append(dp.d_commit(be, dc, local_s_p, 4 * M // npar, net))  # 2.b
+    wiring_proofs.append(dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net))  # 2.c
+    wiring_opens.append(dp.c_open(be, cc, T["V"], 4 * M // l, pk.challenge_r1, pp, net))  # 2.d
+    wiring_opens.append(dp.c_open(be, cc, T["V"], 4 * M // l, pk.challenge_r2, pp, net))
+    wiring_opens.append(dp.d_open(be, dc, local_s_p, 4 * M // npar, pk.challenge_r2, net))
+    # 2.e (:322-340)
+    hlen = 4 * M // npar
+    num = be.fr_axpb(local_s_p, T["sid_p"], pk.alpha, pk.beta, hlen)
+    den = be.fr_axpb(T["eq_r1_p"], T["ssigma_p"], pk.alpha, pk.beta, hlen)
+    h_p = be.fr_batch_div(num, den, hlen)
+    subtree, top = dp.d_acc_product(be, h_p, hlen, net)  # :342
+    v1x = _at(subtree, 32 * hlen)  # tree[N..]
+    vx0, vx1 = be.fr_deinterleave(subtree, hlen)  # tree[0::2], tree[1::2]  :344-359
+    for tab in (T["ssigma_p"], T["sid_p"], h_p, num, den, v1x, vx0, vx1):  # :363-380
+        wiring_commits.append(dp.d_commit(be, dc, tab, hlen, net))
+    for tab in (T["ssigma_p"], T["sid_p"], h_p, num, den):  # :383-407
+        wiring_opens.append(dp.d_open(be, dc, tab, hlen, pk.challenge_r2, net))
+    dsp = lambda f, g, length, ch: dp.d_sumcheck_product(be, f, g, length, ch, net)
+    wiring_proofs.append(dsp(den, T["eq_r2_p"], hlen, pk.challenge_r2))  # 2.e.1 :411-413
+    wiring_proofs.append(dsp(h_p, den, hlen, pk.challenge_r2))
+    wiring_proofs.append(dsp(num, T["eq_r2_p"], hlen, pk.challenge_r2))
+    # 2.e.2 layered sumcheck + opens on halving slices (:417-478)
+    sbits = npar.bit_length() - 1
+    cur = {"v1x": v1x, "vx0": vx0, "vx1": vx1, "eq": T["eq_r2_p"]}
+    clen = hlen // 2  # current_* = first half
+    for i in range(1, n - sbits + 1):
+        ch = pk.challenge_r2[i:]
+        wiring_proofs.append(dsp(cur["eq"], cur["v1x"], clen, ch))
+        wiring_proofs.append(dsp(cur["eq"], cur["vx0"], clen, ch))
+        wiring_proofs.append(dsp(cur["vx0"], cur["vx1"], clen, ch))
+        for k in ("v1x", "vx0", "vx1"):
+            wiring_opens.append(dp.d_open(be, dc, cur[k], clen, ch, net))
+        for k in cur:  # current = current[len/2..]
+            cur[k] = _at(cur[k], 32 * (clen // 2))
+        clen //= 2
+    if top is not None:  # leader-only tail on the N_p-leaf top tree (:480-511)
+        tt = np.asarray(top, dtype=np.uint64).reshape(-1, 4)
+        half = len(tt) // 2
+        lv1x, lvx0, lvx1 = tt[half:], tt[0::2], tt[1::2]
+        chs = pk.challenge_r2[:sbits]
+        for v in (lvx0, lvx1, lv1x):
+            d = be.to_device(np.ascontiguousarray(v))
+            wiring_commits.append(dp.commit(be, dc, d, len(v)))
+            wiring_opens.append(dp.open_(be, dc, d, len(v), chs))
+        d1, d0, dd1 = be.to_device(np.ascontiguousarray(lv1x)), be.to_device(np.ascontiguousarray(lvx0)), be.to_device(np.ascontiguousarray(lvx1))
+        wiring_proofs.append(dp.sumcheck_product(be, eq_top, d1, len(lv1x), chs))
+        wiring_proofs.append(dp.sumcheck_product(be, eq_top, d0, len(lvx0), chs))
+        wiring_proofs.append(dp.sumcheck_product(be, d0, dd1, len(lvx0), chs))
+    tm.end()
+
+    # Open (:517-553)
+    tm.start("Open")
+    gate_commitments = []
+    for name in ("a_evals", "b_evals", "c_evals"):
+        gate_commitments.append((com[name], dp.c_open(be, cc, T[name], L[name], pk.challenge, pp, net)))
+    for name in ("I_p", "S1_p", "S2_p"):
+        gate_commitments.append((com[name], dp.d_open(be, dc, T[name], L[name], pk.challenge, net)))
+    tm.end()
+    tm.end()
+    return ((gate_proofs, gate_commitments), (wiring_proofs, wiring_commits, wiring_opens)), tm.t
