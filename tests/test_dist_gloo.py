@@ -41,6 +41,14 @@ if p == 0:
     assert ints(top) == po.d_acc_product_all(pf)[1]
 else:
     assert len(out) == 0 and top is None
+from zkhip import sharding as sh
+full_f, full_g, chs = rng.fr_vec(32), rng.fr_vec(32), rng.fr_vec(5)
+got = sh.sharded_sumcheck_product(be, be.to_device(sh.cyclic_shard(to_m(full_f), p, W)), be.to_device(sh.cyclic_shard(to_m(full_g), p, W)), 32 // W, to_m(chs), net)
+assert [tuple(ints(t)) for t in got] == po.sumcheck_product(full_f, full_g, chs)
+pts, scs = po.g1_bases(16, 77), rng.fr_vec(16)
+per = 16 // W
+got = sh.sharded_msm(be, OracleSrs(np.array([pt_mont(P) for P in pts[p*per:(p+1)*per]])), be.to_device(to_m(scs[p*per:(p+1)*per])), per, net)
+assert pt_ints(got[:12]) == po.g1_msm(pts, scs)
 if W == 8:                           # the l = 1, 8-party d_msm
     pp, opp = PackedSharingParams(1), po.PackedSharingParams(1)
     bases = [[po.g1_bases(4, 50 + q)] for q in range(W)]
