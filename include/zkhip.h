@@ -119,6 +119,13 @@ const void *zk_srs_device_ptr(const zk_srs *srs);
  * passes them; converted on device like `into_bigint`).  h_out: 18 u64 normalised Jacobian. */
 int zk_msm_g1(zk_ctx *ctx, const zk_srs *srs, size_t offset, const void *d_scalars, size_t n,
               uint64_t h_out[18]);
+/* A batch of independent MSMs in one pipeline pass -- the shape of d_msm's input
+ * (`bases: &Vec<Vec<Affine>>, scalars: &Vec<Vec<Fr>>`, dmsm.rs:9-24; c_open hands it n+2 MSMs of
+ * halving size, dpoly_comm.rs:435-436).  Items are grouped by window width and share the launch
+ * sequence; all host combines run after ONE synchronisation, in parallel host threads.
+ * offsets may be NULL (all zero).  h_out: count x 18 u64. */
+int zk_msm_g1_batch(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets,
+                    const void *const *d_scalars, const size_t *n, uint64_t *h_out);
 /* Drop-in for `G::msm(&[Affine], &[Fr]) -> Result<G, usize>` on host slices (dmsm.rs:23):
  * returns ZK_ERR_LENGTH when n_bases != n_scalars and stores min(n_bases, n_scalars) in *h_err_len. */
 int zk_msm_g1_host(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n_bases,

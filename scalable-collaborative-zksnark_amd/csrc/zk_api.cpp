@@ -236,6 +236,13 @@ int zk_msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scala
     NEED(ctx, srs && h_out && (n == 0 || d_scalars));
     return msm_g1(ctx, srs, offset, d_scalars, n, h_out);
 }
+int zk_msm_g1_batch(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* offsets, const void* const* d_scalars,
+                    const size_t* n, uint64_t* h_out) {
+    NEED(ctx, count == 0 || (srs && d_scalars && n && h_out));
+    std::vector<MsmItem> items(count);
+    for (size_t k = 0; k < count; k++) items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, d_scalars[k], n[k]};
+    return msm_g1_batch(ctx, items.data(), count, h_out);
+}
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n_bases, const uint64_t* h_scalars, size_t n_scalars,
                    uint64_t h_out[18], size_t* h_err_len) {
     NEED(ctx, h_out);

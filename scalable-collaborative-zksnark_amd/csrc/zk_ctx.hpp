@@ -58,6 +58,13 @@ int product_tree(zk_ctx* ctx, const void* d_x, size_t N, void* d_tree);
 int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n);
 
 // ---- zk_msm.hip ----
+struct MsmItem {
+    const zk_srs* srs;
+    size_t offset;
+    const void* d_scalars;
+    size_t n;
+};
+int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out);
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out);
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
 int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, zk_srs** out);

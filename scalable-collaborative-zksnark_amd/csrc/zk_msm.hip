@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace zk {
@@ -60,15 +61,25 @@ static WinLayout msm_layout(int c) {
 // ---------------------------------------------------------------------------------------
 // 1. digits: scalars out of Montgomery form, signed c-bit digits.  digits row stride = ns.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlk) k_digits(const void* __restrict__ scalars, size_t n, size_t ns, WinLayout L,
-                                               u32* __restrict__ digits) {
+// one MSM of a batch (all items of a launch share the window layout and the row stride ns)
+struct ItemDesc {
+    const void* scalars;
+    const void* bases;  // packed 96-B affine points, already offset
+    u32 n;
+    u32 pad;
+};
+
+__global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ items, size_t ns, WinLayout L,
+                                               u32* __restrict__ digits_all) {
     const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (i >= ns) return;
-    if (i >= n) {  // padding up to the row stride
+    const ItemDesc it = items[blockIdx.y];
+    u32* digits = digits_all + (size_t)blockIdx.y * L.W * ns;
+    if (i >= it.n) {  // padding up to the (class-wide) row stride
         for (int w = 0; w < L.W; w++) digits[(size_t)w * ns + i] = kSkip;
         return;
     }
-    Fr s = fp_from_mont<FrCfg>(fr_load(scalars, i));
+    Fr s = fp_from_mont<FrCfg>(fr_load(it.scalars, i));
     u32 carry = 0;
     for (int w = 0; w < L.W; w++) {
         const int cw = L.width(w);  // <= 16
@@ -197,13 +208,14 @@ __global__ void __launch_bounds__(kScanThreads) k_scan(const u32* __restrict__ c
 // sorted entries; runs that are whole buckets are stored directly, the (at most two) runs cut by
 // the tile boundary go to heads[] / tails[] and are stitched by k_fixup.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlk) k_accum_tiles(const void* __restrict__ bases, const u32* __restrict__ sorted,
+__global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict__ items, int W, const u32* __restrict__ sorted,
                                                     const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t ns,
                                                     size_t nb, u32 T, size_t tiles_per_w, size_t total_tiles,
                                                     void* __restrict__ buckets, void* __restrict__ heads, void* __restrict__ tails) {
     const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (g >= total_tiles) return;
-    const size_t w = g / tiles_per_w, t = g % tiles_per_w;
+    const size_t w = g / tiles_per_w, t = g % tiles_per_w;  // w = row = item * W + window
+    const void* __restrict__ bases = items[w / W].bases;
     const u32* off = offsets + w * nb;
     const u32* cnt = counts + w * nb;
     const u32 nw = off[nb - 1] + cnt[nb - 1];  // entries of this window (zero digits are skipped)
@@ -368,112 +380,15 @@ static zkhost::Jac load_xyzz_host(const uint64_t* p) {
     return zkhost::xyzz_to_jac(X, Y, ZZ, ZZZ);
 }
 
-int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out) {
-    if (!srs || !h_out) return fail(ctx, ZK_ERR_INVALID, "null argument");
-    if (offset + n > srs->n) return fail(ctx, ZK_ERR_LENGTH, "msm: %zu scalars but only %zu bases from offset %zu", n, srs->n - std::min(offset, srs->n), offset);
-    if (n >= ((size_t)1 << 31)) return fail(ctx, ZK_ERR_INVALID, "msm: n too large");
-    ZK_HIP(ctx, hipSetDevice(ctx->device));
-    if (n == 0) {
-        zkhost::write_normalised(zkhost::jac_inf(), h_out);
-        return ZK_OK;
-    }
-    const int c = ctx->msm_window_override > 0 ? ctx->msm_window_override : msm_pick_window(n);
-    const WinLayout L = msm_layout(c);
-    const int W = L.W;
-    const size_t nb = (size_t)1 << (c - 1);
-    const size_t total = (size_t)W * nb;
-    hipStream_t st = ctx->stream;
-
-    const size_t ns = (n + 3) & ~(size_t)3;  // row stride of digits / sorted (16-byte rows)
-    static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
-    static const u32 bpb_env = getenv("ZK_MSM_BPB") ? (u32)atoi(getenv("ZK_MSM_BPB")) : 0;
-    // sorted entries per lane in k_accum_tiles: 32 when there is enough work to fill the chip;
-    // for small MSMs balance the serial chain of a lane (T mixed adds, ~10 Fq-mul each) against
-    // the fix-up chain of a bucket (entries_per_bucket / T full adds, ~14 Fq-mul each)
-    u32 T = 32;
-    if ((size_t)W * n / T < (size_t)ctx->cu_count * 4 * 64 * 2) {
-        const double per_bucket = (double)n / (double)nb;
-        T = 4;
-        while (T < 32 && (double)T * T < 1.4 * per_bucket) T <<= 1;
-    }
-    if (T_env) T = T_env;
-    const size_t tiles_per_w = (n + T - 1) / T;
-    const size_t total_tiles = tiles_per_w * W;
-    u32* digits = (u32*)scratch(ctx, 0, (size_t)W * ns * 4);
-    u32* sorted = (u32*)scratch(ctx, 1, (size_t)W * ns * 4);
-    u32* cnts = (u32*)scratch(ctx, 2, 2 * total * 4);
-    void* bufA = scratch(ctx, 3, total * 192);
-    void* bufB = scratch(ctx, 4, total * 192);
-    char* parts = (char*)scratch(ctx, 5, 2 * total_tiles * 192);
-    const size_t long_cap = total_tiles / kLongSpan + 64;
-    u32* longs = (u32*)scratch(ctx, 6, (long_cap + 1) * 4);
-    if (!digits || !sorted || !cnts || !bufA || !bufB || !parts || !longs) return ZK_ERR_OOM;
-    u32* counts = cnts;
-    u32* offsets = cnts + total;
-    void* heads = parts;
-    void* tails = parts + total_tiles * 192;
-    const char* bases = (const char*)srs->d_bases + offset * 96;
-    // sort geometry: rows x chunks x bucket ranges; LDS counters <= 64 KiB per block
-    const size_t srows = W, row_len = ns;
-    const u32 bpb = (u32)std::min<size_t>(nb, bpb_env ? bpb_env : 16384);
-    const unsigned P = (unsigned)(nb / bpb);
-    u32 nchunks = (u32)std::max<size_t>(1, std::min<size_t>(512 / (srows * P) ? 512 / (srows * P) : 1, (row_len + 8191) / 8192));
-    size_t chunk_len = ((row_len + nchunks - 1) / nchunks + 3) & ~(size_t)3;
-    nchunks = (u32)((row_len + chunk_len - 1) / chunk_len);
-    u32* cc = (u32*)scratch(ctx, 8, srows * P * (size_t)nchunks * bpb * 4);
-    if (!cc) return ZK_ERR_OOM;
-
-    hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipEventRecord(ctx->ev[0], st);
-    ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
-    hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, d_scalars, n, ns, L, digits);
-    hipLaunchKernelGGL((k_sort_pass<false>), dim3(nchunks, P, (unsigned)srows), dim3(kSortThreads), bpb * 4, st, (const u32*)digits,
-                       row_len, chunk_len, nchunks, nb, bpb, cc, (u32*)nullptr);
-    hipLaunchKernelGGL(k_bucket_totals, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)cc, nchunks, nb, bpb,
-                       total, counts);
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)srows), dim3(kScanThreads), 0, st, (const u32*)counts, nb, offsets);
-    hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, cc, nchunks, nb, bpb, total,
-                       (const u32*)offsets);
-    hipLaunchKernelGGL((k_sort_pass<true>), dim3(nchunks, P, (unsigned)srows), dim3(kSortThreads), bpb * 4, st, (const u32*)digits,
-                       row_len, chunk_len, nchunks, nb, bpb, cc, sorted);
-    hipEventRecord(ctx->ev[1], st);
-    hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)bases,
-                       (const u32*)sorted, (const u32*)offsets, (const u32*)counts, ns, nb, T, tiles_per_w, total_tiles, bufA, heads,
-                       tails);
-    hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
-                       (const u32*)counts, nb, T, tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs, longs + 1);
-    hipLaunchKernelGGL(k_fixup_long, dim3(512), dim3(kBlk), 0, st, (const u32*)offsets, (const u32*)counts, nb, T, tiles_per_w, bufA,
-                       (const void*)heads, (const void*)tails, (const u32*)longs, (const u32*)(longs + 1));
-    hipEventRecord(ctx->ev[2], st);
-    void* in = bufA;
-    void* out = bufB;
-    int rows = 1;
-    size_t len = nb;
-    while (len > 1) {
-        size_t threads = (size_t)W * (rows + 1) * (len >> 1);
-        hipLaunchKernelGGL(k_halve, dim3((unsigned)((threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out, W, rows, len);
-        std::swap(in, out);
-        rows++;
-        len >>= 1;
-    }
-    ZK_HIP(ctx, hipGetLastError());
-    // W * rows points (rows == c), 192 B each
-    const size_t npts = (size_t)W * rows;
-    uint64_t* h = (uint64_t*)pinned(ctx, npts * 192);
-    if (!h) return ZK_ERR_OOM;
-    ZK_HIP(ctx, hipMemcpyAsync(h, in, npts * 192, hipMemcpyDeviceToHost, st));
-    hipEventRecord(ctx->ev[3], st);
-    ZK_HIP(ctx, hipStreamSynchronize(st));
-    auto t0 = std::chrono::steady_clock::now();
-    // host combine: position p = c*w + k carries weight 2^p
+// host combine of one item: rows of W x c points (planes T_0..T_{c-2}, T_all per window)
+static void combine_item(const uint64_t* h, const WinLayout& L, int c, uint64_t* h_out) {
     std::vector<zkhost::Jac> pos((size_t)256 + c + 1, zkhost::jac_inf());
-    for (int w = 0; w < W; w++) {
-        for (int k = 0; k < rows; k++) {
-            zkhost::Jac pt = load_xyzz_host(h + ((size_t)w * rows + k) * 24);
+    for (int w = 0; w < L.W; w++) {
+        for (int k = 0; k < c; k++) {
+            zkhost::Jac pt = load_xyzz_host(h + ((size_t)w * c + k) * 24);
             if (zkhost::is_zero(pt.z)) continue;
-            // rows 0..rows-2 are planes T_k (weight 2^k); the last row is T_all (weight 1)
-            size_t p = (size_t)L.bit_offset(w) + ((k == rows - 1) ? 0 : k);
+            // rows 0..c-2 are planes T_k (weight 2^k); the last row is T_all (weight 1)
+            size_t p = (size_t)L.bit_offset(w) + ((k == c - 1) ? 0 : k);
             pos[p] = zkhost::jac_add(pos[p], pt);
         }
     }
@@ -483,6 +398,198 @@ int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars,
         acc = zkhost::jac_add(acc, pos[p]);
     }
     zkhost::write_normalised(acc, h_out);
+}
+
+struct MsmClass {
+    int c = 0;
+    WinLayout L{};
+    std::vector<size_t> idx;  // items of the batch in this class
+    size_t ns = 0, nb = 0, rows = 0, total = 0, tiles_per_w = 0, total_tiles = 0, chunk_len = 0, cc_elems = 0;
+    u32 T = 32, bpb = 0, nchunks = 0;
+    unsigned P = 1;
+    size_t pinned_off = 0;  // byte offset of this class's results in the pinned staging area
+};
+
+static int quantised_window(int c) { return c <= 4 ? 4 : 4 + 3 * ((c - 4 + 2) / 3); }
+
+int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) {
+    if (!h_out && count) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
+    static const u32 bpb_env = getenv("ZK_MSM_BPB") ? (u32)atoi(getenv("ZK_MSM_BPB")) : 0;
+    hipStream_t st = ctx->stream;
+    // ---- validate + classify by window width ----
+    std::vector<MsmClass> classes;
+    for (size_t k = 0; k < count; k++) {
+        const MsmItem& it = items[k];
+        if (!it.srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
+        if (it.offset + it.n > it.srs->n)
+            return fail(ctx, ZK_ERR_LENGTH, "msm: %zu scalars but only %zu bases from offset %zu", it.n,
+                        it.srs->n - std::min(it.offset, it.srs->n), it.offset);
+        if (it.n >= ((size_t)1 << 31)) return fail(ctx, ZK_ERR_INVALID, "msm: n too large");
+        if (it.n == 0) {
+            zkhost::write_normalised(zkhost::jac_inf(), h_out + 18 * k);
+            continue;
+        }
+        int c = ctx->msm_window_override > 0 ? ctx->msm_window_override : msm_pick_window(it.n);
+        if (count > 1 && ctx->msm_window_override <= 0) c = quantised_window(c);
+        MsmClass* cl = nullptr;
+        for (auto& x : classes)
+            if (x.c == c) cl = &x;
+        if (!cl) {
+            classes.emplace_back();
+            cl = &classes.back();
+            cl->c = c;
+            cl->L = msm_layout(c);
+            cl->nb = (size_t)1 << (c - 1);
+        }
+        cl->idx.push_back(k);
+        cl->ns = std::max(cl->ns, (it.n + 3) & ~(size_t)3);
+    }
+    if (classes.empty()) return ZK_OK;
+    // ---- geometry per class, scratch high-water marks ----
+    size_t need[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pinned_bytes = 0;
+    for (auto& cl : classes) {
+        const int W = cl.L.W;
+        const size_t nitems = cl.idx.size();
+        cl.rows = nitems * W;
+        cl.total = cl.rows * cl.nb;
+        size_t nmax = 0;
+        for (size_t k : cl.idx) nmax = std::max(nmax, items[k].n);
+        // sorted entries per lane in k_accum_tiles: 32 when there is enough work to fill the chip;
+        // for small MSMs balance the serial chain of a lane (T mixed adds, ~10 Fq-mul each) against
+        // the fix-up chain of a bucket (entries_per_bucket / T full adds, ~14 Fq-mul each)
+        cl.T = 32;
+        if ((size_t)cl.rows * nmax / 32 < (size_t)ctx->cu_count * 4 * 64 * 2) {
+            const double per_bucket = (double)nmax / (double)cl.nb;
+            cl.T = 4;
+            while (cl.T < 32 && (double)cl.T * cl.T < 1.4 * per_bucket) cl.T <<= 1;
+        }
+        if (T_env) cl.T = T_env;
+        cl.tiles_per_w = (cl.ns + cl.T - 1) / cl.T;
+        cl.total_tiles = cl.tiles_per_w * cl.rows;
+        // sort geometry: rows x chunks x bucket ranges; LDS counters <= 64 KiB per block
+        cl.bpb = (u32)std::min<size_t>(cl.nb, bpb_env ? bpb_env : 16384);
+        cl.P = (unsigned)(cl.nb / cl.bpb);
+        size_t want = 512 / (cl.rows * cl.P);
+        cl.nchunks = (u32)std::max<size_t>(1, std::min<size_t>(want ? want : 1, (cl.ns + 8191) / 8192));
+        cl.chunk_len = ((cl.ns + cl.nchunks - 1) / cl.nchunks + 3) & ~(size_t)3;
+        cl.nchunks = (u32)((cl.ns + cl.chunk_len - 1) / cl.chunk_len);
+        cl.cc_elems = cl.rows * cl.P * (size_t)cl.nchunks * cl.bpb;
+        need[0] = std::max(need[0], cl.rows * cl.ns * 4);
+        need[1] = std::max(need[1], cl.rows * cl.ns * 4);
+        need[2] = std::max(need[2], 2 * cl.total * 4);
+        need[3] = std::max(need[3], cl.total * 192);
+        need[4] = std::max(need[4], cl.total * 192);
+        need[5] = std::max(need[5], 2 * cl.total_tiles * 192);
+        need[6] = std::max(need[6], (cl.total_tiles / kLongSpan + 64 + 1) * 4);
+        need[7] = std::max(need[7], nitems * sizeof(ItemDesc));
+        need[8] = std::max(need[8], cl.cc_elems * 4);
+        cl.pinned_off = pinned_bytes;
+        pinned_bytes += cl.rows * (size_t)cl.c * 192 + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
+    }
+    // allocate every arena once, before anything is enqueued (no reallocation between classes)
+    static const int slot[9] = {0, 1, 2, 3, 4, 5, 6, 9, 8};
+    void* buf[9];
+    for (int i = 0; i < 9; i++) {
+        buf[i] = scratch(ctx, slot[i], need[i]);
+        if (!buf[i]) return ZK_ERR_OOM;
+    }
+    char* hpin = (char*)pinned(ctx, pinned_bytes);
+    if (!hpin) return ZK_ERR_OOM;
+    hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+
+    // ---- enqueue every class back to back on the stream (no host synchronisation in between) ----
+    bool first = true;
+    for (auto& cl : classes) {
+        const int W = cl.L.W;
+        const size_t nitems = cl.idx.size(), ns = cl.ns, nb = cl.nb, total = cl.total;
+        u32* digits = (u32*)buf[0];
+        u32* sorted = (u32*)buf[1];
+        u32* counts = (u32*)buf[2];
+        u32* offsets = counts + total;
+        void* bufA = buf[3];
+        void* bufB = buf[4];
+        void* heads = buf[5];
+        void* tails = (char*)buf[5] + cl.total_tiles * 192;
+        u32* longs = (u32*)buf[6];
+        ItemDesc* d_items = (ItemDesc*)buf[7];
+        u32* cc = (u32*)buf[8];
+        uint64_t* h_pts = (uint64_t*)(hpin + cl.pinned_off);
+        ItemDesc* h_items = (ItemDesc*)(hpin + cl.pinned_off + cl.rows * (size_t)cl.c * 192);
+        for (size_t j = 0; j < nitems; j++) {
+            const MsmItem& it = items[cl.idx[j]];
+            h_items[j].scalars = it.d_scalars;
+            h_items[j].bases = (const char*)it.srs->d_bases + it.offset * 96;
+            h_items[j].n = (u32)it.n;
+            h_items[j].pad = 0;
+        }
+        if (first) hipEventRecord(ctx->ev[0], st);
+        ZK_HIP(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
+        ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
+        hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
+                           (const ItemDesc*)d_items, ns, cl.L, digits);
+        hipLaunchKernelGGL((k_sort_pass<false>), dim3(cl.nchunks, cl.P, (unsigned)cl.rows), dim3(kSortThreads), cl.bpb * 4, st,
+                           (const u32*)digits, ns, cl.chunk_len, cl.nchunks, nb, cl.bpb, cc, (u32*)nullptr);
+        hipLaunchKernelGGL(k_bucket_totals, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)cc, cl.nchunks,
+                           nb, cl.bpb, total, counts);
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)cl.rows), dim3(kScanThreads), 0, st, (const u32*)counts, nb, offsets);
+        hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, cc, cl.nchunks, nb, cl.bpb,
+                           total, (const u32*)offsets);
+        hipLaunchKernelGGL((k_sort_pass<true>), dim3(cl.nchunks, cl.P, (unsigned)cl.rows), dim3(kSortThreads), cl.bpb * 4, st,
+                           (const u32*)digits, ns, cl.chunk_len, cl.nchunks, nb, cl.bpb, cc, sorted);
+        if (first) hipEventRecord(ctx->ev[1], st);
+        hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
+                           (const ItemDesc*)d_items, W, (const u32*)sorted, (const u32*)offsets, (const u32*)counts, ns, nb, cl.T,
+                           cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
+        hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
+                           (const u32*)counts, nb, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
+                           longs + 1);
+        hipLaunchKernelGGL(k_fixup_long, dim3(512), dim3(kBlk), 0, st, (const u32*)offsets, (const u32*)counts, nb, cl.T,
+                           cl.tiles_per_w, bufA, (const void*)heads, (const void*)tails, (const u32*)longs, (const u32*)(longs + 1));
+        if (first) hipEventRecord(ctx->ev[2], st);
+        void* in = bufA;
+        void* out = bufB;
+        int rows = 1;
+        size_t len = nb;
+        while (len > 1) {
+            size_t threads = cl.rows * (size_t)(rows + 1) * (len >> 1);
+            hipLaunchKernelGGL(k_halve, dim3((unsigned)((threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
+                               (int)cl.rows, rows, len);
+            std::swap(in, out);
+            rows++;
+            len >>= 1;
+        }
+        ZK_HIP(ctx, hipGetLastError());
+        // rows == c planes per window row
+        ZK_HIP(ctx, hipMemcpyAsync(h_pts, in, cl.rows * (size_t)cl.c * 192, hipMemcpyDeviceToHost, st));
+        if (first) hipEventRecord(ctx->ev[3], st);
+        first = false;
+    }
+    ZK_HIP(ctx, hipStreamSynchronize(st));
+    // ---- host combine: ~255 doublings per item, items in parallel threads ----
+    auto t0 = std::chrono::steady_clock::now();
+    struct Job {
+        const uint64_t* h;
+        const MsmClass* cl;
+        uint64_t* out;
+    };
+    std::vector<Job> jobs;
+    for (auto& cl : classes)
+        for (size_t j = 0; j < cl.idx.size(); j++)
+            jobs.push_back(Job{(const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.L.W * cl.c * 24, &cl, h_out + 18 * cl.idx[j]});
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; j++) combine_item(jobs[j].h, jobs[j].cl->L, jobs[j].cl->c, jobs[j].out);
+    };
+    if (jobs.size() == 1) {
+        work(0, 1);
+    } else {
+        size_t nth = std::min<size_t>({jobs.size(), (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)32});
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nth; t++) th.emplace_back(work, jobs.size() * t / nth, jobs.size() * (t + 1) / nth);
+        for (auto& x : th) x.join();
+    }
     auto t1 = std::chrono::steady_clock::now();
     float ms;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
@@ -494,6 +601,12 @@ int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars,
     ctx->msm_ms[3] = std::chrono::duration<float, std::milli>(t1 - t0).count();
     ctx->msm_ms[4] = ctx->msm_ms[0] + ctx->msm_ms[1] + ctx->msm_ms[2] + ctx->msm_ms[3];
     return ZK_OK;
+}
+
+int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out) {
+    if (!srs || !h_out) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    MsmItem it{srs, offset, d_scalars, n};
+    return msm_g1_batch(ctx, &it, 1, h_out);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -45,6 +45,7 @@ SYMBOLS = [
     ("zk_srs_len", _sz, [_vp]),
     ("zk_srs_device_ptr", _vp, [_vp]),
     ("zk_msm_g1", _i, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    ("zk_msm_g1_batch", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zk_msm_g1_host", _i, [_vp, _vp, _sz, _sz, _vp, _sz, _vp, ctypes.POINTER(ctypes.c_size_t)]),
     ("zk_g1_lincomb", _i, [_vp, _vp, _vp, _sz, _vp]),
     ("zk_msm_window", _i, [_sz]),

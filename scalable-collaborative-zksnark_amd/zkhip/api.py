@@ -254,6 +254,22 @@ class Ctx:
         self._check(rc)
         return out
 
+    def msm_g1_batch(self, srs_list, scalars_list, lens, offsets=None) -> np.ndarray:
+        """a batch of independent MSMs in one pipeline pass -> [count, 18]"""
+        count = len(lens)
+        out = np.zeros((count, 18), dtype=np.uint64)
+        if count == 0:
+            return out
+        h = (ctypes.c_void_p * count)(*[s.h for s in srs_list])
+        sp = (ctypes.c_void_p * count)(*[_ptr(s) for s in scalars_list])
+        nn = (ctypes.c_size_t * count)(*[int(x) for x in lens])
+        off = (ctypes.c_size_t * count)(*[int(x) for x in (offsets or [0] * count)])
+        rc = self.lib.zk_msm_g1_batch(self.h, count, h, off, sp, nn, _h(out))
+        if rc == ZK_ERR_LENGTH:
+            raise MsmLengthError(rc, (self.lib.zk_last_error(self.h) or b"").decode(), 0)
+        self._check(rc)
+        return out
+
     def msm_g1_host(self, bases: np.ndarray, scalars: np.ndarray, stride: int = 96) -> np.ndarray:
         """drop-in for G::msm(&[Affine], &[Fr]) on host arrays"""
         b = np.ascontiguousarray(bases)

@@ -51,7 +51,7 @@ def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: Packe
     every party to the all-gathered results for its own slot.
     """
     assert len(bases) == len(scalars) == len(lens)  # dmsm.rs:16
-    c_shares = np.stack([be.msm_g1(b, s, n) for b, s, n in zip(bases, scalars, lens)]) if len(lens) else np.zeros((0, 18), np.uint64)
+    c_shares = be.msm_g1_batch(list(bases), list(scalars), list(lens))  # one pipeline pass for the whole batch
     gathered = net.all_gather(c_shares)  # [party][batch,18]
     coeff = np.array([int_to_limbs(c, 4) for c in pp.dmsm_coeffs(net.party_id)], dtype=np.uint64)
     out = np.zeros_like(c_shares)
@@ -208,13 +208,16 @@ def open_(be, powers_of_g, peval, length: int, point: np.ndarray):
     """dpoly_comm.rs:299-325 (= d_local_open :327-353) -> (value [4], proofs [n,18])"""
     n = length.bit_length() - 1
     q, value = be.open_rounds(peval, length, point[:n])
-    proofs, off, m = [], 0, length
+    srs, bufs, lens, off, m = [], [], [], 0, length
     for _ in range(n):
         h = m // 2
-        proofs.append(be.msm_g1(powers_of_g[h.bit_length() - 1], q.at(32 * off), h))
+        srs.append(powers_of_g[h.bit_length() - 1])
+        bufs.append(q.at(32 * off))
+        lens.append(h)
         off += h
         m = h
-    return value, (np.stack(proofs) if proofs else np.zeros((0, 18), np.uint64))
+    # the n commitments of one open are independent: one batched pass (the reference commits them one by one)
+    return value, be.msm_g1_batch(srs, bufs, lens)
 
 
 def d_commit(be, powers_of_g, peval, length: int, net: Net) -> np.ndarray:

@@ -58,6 +58,12 @@ class OracleBackend:
     def msm_g1(self, srs, scalars, n, offset=0):
         return _jac(co.msm_g1(srs.bases[offset : offset + n], _arr(scalars)[:n]))
 
+    def msm_g1_batch(self, srs_list, scalars_list, lens, offsets=None):
+        out = np.zeros((len(lens), 18), dtype=np.uint64)
+        for k, (s, sc, n) in enumerate(zip(srs_list, scalars_list, lens)):
+            out[k] = self.msm_g1(s, sc, n, (offsets or [0] * len(lens))[k])
+        return out
+
     def g1_lincomb(self, points, scalars_canon):
         acc = None
         for p, k in zip(np.asarray(points).reshape(-1, 18), np.asarray(scalars_canon).reshape(-1, 4)):

@@ -122,3 +122,26 @@ def test_msm_skewed_scalars_long_buckets(ctx, co):
     small[:, 0] = np.arange(n) % 7
     sm = co.fr_to_mont(small)
     assert (jac_norm_to_affine(ctx.msm_g1(srs, ctx.to_device(sm), n)) == co.msm_g1(bases, sm)).all()
+
+
+def test_msm_batch_matches_individual(ctx, co):
+    """zk_msm_g1_batch: heterogeneous sizes (the halving batch of c_open / open) in one pass"""
+    sizes = [1 << 13, 1 << 12, 1 << 11, 700, 64, 33, 8, 4, 2, 1, 0, 1 << 13]
+    srs, scal, exp = [], [], []
+    for k, n in enumerate(sizes):
+        bases, _ = synthetic_bases(max(n, 1), 600 + k)
+        sc = rand_fr(max(n, 1), 700 + k)
+        srs.append(ctx.srs_register(bases))
+        scal.append(ctx.to_device(sc))
+        exp.append(co.msm_g1(bases[:n], sc[:n]) if n else np.zeros(12, dtype=np.uint64))
+    got = ctx.msm_g1_batch(srs, scal, sizes)
+    for k in range(len(sizes)):
+        assert (jac_norm_to_affine(got[k]) == exp[k]).all(), (k, sizes[k])
+    # offsets into one SRS: sub-ranges of the same level
+    bases, _ = synthetic_bases(4096, 650)
+    big = ctx.srs_register(bases)
+    sc = rand_fr(4096, 651)
+    d = ctx.to_device(sc)
+    got = ctx.msm_g1_batch([big, big], [d, d.at(32 * 1024)], [1024, 512], offsets=[0, 1024])
+    assert (jac_norm_to_affine(got[0]) == co.msm_g1(bases[:1024], sc[:1024])).all()
+    assert (jac_norm_to_affine(got[1]) == co.msm_g1(bases[1024:1536], sc[1024:1536])).all()
