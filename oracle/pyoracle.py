@@ -806,3 +806,70 @@ def digest(objs) -> str:
 
     feed(objs)
     return h.hexdigest()
+
+
+# --------------------------------------------------------------------------
+# c_acc_product_and_share (dacc_product.rs:66-292), all parties in-process, `comm` semantics
+# --------------------------------------------------------------------------
+def merge(results):
+    """dacc_product.rs:416-428: interleave the per-party vectors level by level"""
+    merged = []
+    n = len(results[0])
+    num = 1
+    while num < n + 1:
+        num <<= 1
+    num >>= 1  # (len + 1).next_power_of_two() >> 1
+    start = 0
+    while num > 0 and start + num <= n:  # (the reference spins forever once num reaches 0, i.e. for len = 2^k - 1)
+        for r in results:
+            merged.extend(r[start : start + num])
+        start += num
+        num >>= 1
+    return merged
+
+
+def c_acc_product_and_share_all(shares, masks, unmask0, unmask1, unmask2, pp: PackedSharingParams):
+    """
+    shares[p] etc.: party p's vectors (length S).  Returns per-party (share0, share1, share2).
+    Follows the reference literally, including: the v(1,x) leader share packs the WHOLE leader tree
+    (:243-250), and the three degree_reduce_many calls at the end discard their results (:278-285).
+    """
+    N = pp.n
+    S = len(shares[0])
+    assert S > N
+    bs = S // N
+    masked = [[x * m % R_MOD for x, m in zip(shares[p], masks[p])] for p in range(N)]
+    # d_unpack2_many to receiver i of everyone's i-th block (:94-104)
+    masked_x = []
+    for i in range(N):
+        blocks = [masked[p][i * bs : (i + 1) * bs] for p in range(N)]
+        out = []
+        for k in range(bs):
+            out.extend(pp.unpack2([blocks[p][k] for p in range(N)]))
+        masked_x.append(out)
+    subtrees, leader_tree = c_acc_product_all(masked_x, pp)
+
+    def pack_chunks(vals):
+        return transpose([pp.pack_from_public(vals[i : i + pp.l]) for i in range(0, len(vals), pp.l)]) if vals else [[] for _ in range(N)]
+
+    sh0, sh1, sh2 = [], [], []
+    for p in range(N):
+        st = subtrees[p]
+        num_to_send = min(N, len(st))
+        to_share = st[: len(st) - num_to_send]
+        sh0.append(pack_chunks(to_share[0::2]))
+        sh1.append(pack_chunks(to_share[1::2]))
+        sh2.append(pack_chunks(to_share[len(st) // 2 :]))
+    lt0 = pack_chunks(leader_tree[0::2])
+    lt1 = pack_chunks(leader_tree[1::2])
+    lt2 = pack_chunks(leader_tree)  # whole tree (:243-250)
+    outs = []
+    for me in range(N):
+        s0 = merge([sh0[i][me] for i in range(N)]) + lt0[me]
+        s1 = merge([sh1[i][me] for i in range(N)]) + lt1[me]
+        s2 = merge([sh2[i][me] for i in range(N)]) + lt2[me]
+        s0 = [v * unmask0[me][i] % R_MOD for i, v in enumerate(s0)]
+        s1 = [v * unmask1[me][i] % R_MOD for i, v in enumerate(s1)]
+        s2 = [v * unmask2[me][i] % R_MOD for i, v in enumerate(s2)]
+        outs.append((s0, s1, s2))
+    return outs

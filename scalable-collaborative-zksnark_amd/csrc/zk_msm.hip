@@ -673,7 +673,14 @@ int g1_lincomb_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h
     }
     if (n) H::batch_to_affine(tmp, pts.data());
     H::Jac acc = H::jac_inf();
-    for (int b = 255; b >= 0; b--) {
+    int top = -1;  // highest set bit over all scalars (coefficients 1 of d_commit / d_open sums: top = 0)
+    for (size_t i = 0; i < n; i++)
+        for (int b = 255; b > top; b--)
+            if ((h_scalars_canon[4 * i + b / 64] >> (b % 64)) & 1) {
+                top = b;
+                break;
+            }
+    for (int b = top; b >= 0; b--) {
         acc = H::jac_dbl(acc);
         for (size_t i = 0; i < n; i++)
             if ((h_scalars_canon[4 * i + b / 64] >> (b % 64)) & 1) acc = H::jac_add_mixed(acc, pts[i]);

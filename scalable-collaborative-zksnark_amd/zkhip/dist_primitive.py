@@ -402,3 +402,88 @@ def c_acc_product(be, inputs, N: int, pp: PackedSharingParams, net: Net):
         tree.append(tree[a] * tree[b] % R_MOD)
     tree.append(0)
     return subtree, _ints_to_fr(tree)
+
+
+def merge(results: Sequence[np.ndarray]) -> np.ndarray:
+    """dacc_product.rs:416-428: interleave per-party vectors level by level ([k,4] each)"""
+    n = len(results[0])
+    num = 1
+    while num < n + 1:
+        num <<= 1
+    num >>= 1
+    parts, start = [], 0
+    while num > 0 and start + num <= n:  # num == 0 would spin forever in the reference (len = 2^k - 1)
+        for r in results:
+            parts.append(r[start : start + num])
+        start += num
+        num >>= 1
+    return np.concatenate(parts) if parts else np.zeros((0, 4), dtype=np.uint64)
+
+
+def _pack_chunks(be, vals: np.ndarray, pp: PackedSharingParams) -> List[np.ndarray]:
+    """
+    `vals.chunks(l).map(pack_from_public)` transposed: out[p] = party p's share of every chunk.
+    l = 1: share_p = c_p * x -- one scalar multiplication of the whole vector per party, on the GPU.
+    """
+    vals = np.asarray(vals, dtype=np.uint64).reshape(-1, 4)
+    if len(vals) == 0:
+        return [np.zeros((0, 4), dtype=np.uint64) for _ in range(pp.n)]
+    if pp.l == 1:
+        k = len(vals)
+        d_v = be.to_device(vals)
+        d_z = be.to_device(np.zeros((k, 4), dtype=np.uint64))
+        zero = fr_mont(0)
+        return [be.fr_axpb(d_z, d_v, fr_mont(pp.pack_matrix[p][0]), zero, k).download((k, 4)) for p in range(pp.n)]
+    ints = _fr_vec_to_ints(vals)
+    packed = [pp.pack_from_public(ints[i : i + pp.l]) for i in range(0, len(ints), pp.l)]
+    return [_ints_to_fr([c[p] for c in packed]) for p in range(pp.n)]
+
+
+def c_acc_product_and_share(be, shares, masks, unmask0, unmask1, unmask2, S: int, pp: PackedSharingParams, net: Net):
+    """
+    dacc_product.rs:66-292 -> (share0, share1, share2) as [S,4] host arrays (un-reduced, exactly as
+    the reference returns them: its three trailing degree_reduce_many calls discard their results).
+    GPU: mask / unmask multiplications, the product tree, the l = 1 packing; exchanges: one
+    all-to-all of masked blocks, one all-to-all per share vector, the leader-tree scatter.
+    """
+    N = pp.n
+    assert S > N  # :82
+    bs = S // N
+    masked = be.fr_mul(shares, masks, S).download((S, 4))  # :88-92
+    # every party receives everyone's i-th block and unpack2s it element-wise (:94-104)
+    recv = net.all_to_all([np.ascontiguousarray(masked[i * bs : (i + 1) * bs]) for i in range(N)], echo="slot0")
+    cols = [_fr_vec_to_ints(r) for r in recv]
+    mx = []
+    for k in range(bs):
+        mx.extend(pp.unpack2([cols[p][k] for p in range(N)]))
+    mlen = len(mx)
+    subtree, leader_tree = c_acc_product(be, be.to_device(_ints_to_fr(mx)), mlen, pp, net)
+    st = subtree.download((2 * mlen, 4))
+    num_to_send = min(N, 2 * mlen)
+    to_share = st[: 2 * mlen - num_to_send]
+    outs = []
+    for sel in (to_share[0::2], to_share[1::2], to_share[mlen:]):  # v(x,0), v(x,1), v(1,x)  (:118-150)
+        mine = _pack_chunks(be, np.ascontiguousarray(sel), pp)
+        got = net.all_to_all(mine, echo="identity")  # (:155-203)
+        outs.append(merge(got))
+    # leader-tree shares (:213-263): note the v(1,x) share packs the WHOLE leader tree (:243-250)
+    if net.is_leader:
+        lt = np.asarray(leader_tree, dtype=np.uint64).reshape(-1, 4)
+        rows = [_pack_chunks(be, np.ascontiguousarray(v), pp) for v in (lt[0::2], lt[1::2], lt)]
+        payload = [np.concatenate([rows[0][p], rows[1][p], rows[2][p]]) for p in range(N)]
+        k0, k1 = len(rows[0][0]), len(rows[1][0])
+    else:
+        ltlen = num_to_send * N
+        k0 = k1 = (ltlen // 2 + pp.l - 1) // pp.l
+        k2 = (ltlen + pp.l - 1) // pp.l
+        payload = [np.zeros((k0 + k1 + k2, 4), dtype=np.uint64) for _ in range(N)]
+    mine = net.all_to_all(payload, echo="identity")[0]  # what the leader (party 0) sent to me
+    lead = (mine[:k0], mine[k0 : k0 + k1], mine[k0 + k1 :])
+    res = []
+    for sh, le, um in zip(outs, lead, (unmask0, unmask1, unmask2)):
+        full = np.concatenate([sh, le])
+        k = len(full)
+        res.append(be.fr_mul(be.to_device(full), um, k).download((k, 4)))  # unmask (:266-275)
+    for r in res:  # :278-285 -- communication only; the results are dropped by the reference too
+        degree_reduce_many(r[: len(r) // N * 2], pp, net)
+    return tuple(res)

@@ -9,6 +9,8 @@ import numpy as np
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 Q_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 _M64 = (1 << 64) - 1
+_FR_RINV = pow(1 << 256, -1, R_MOD)
+_FQ_RINV = pow(1 << 384, -1, Q_MOD)
 _R_LIMBS = np.array([(R_MOD >> (64 * i)) & _M64 for i in range(4)], dtype=np.uint64)
 
 
@@ -27,7 +29,7 @@ def fr_mont(x: int) -> np.ndarray:
 
 
 def fr_from_mont(a) -> int:
-    return limbs_to_int(a) * pow(1 << 256, -1, R_MOD) % R_MOD
+    return limbs_to_int(a) * _FR_RINV % R_MOD
 
 
 def fq_mont(x: int) -> np.ndarray:
@@ -35,7 +37,7 @@ def fq_mont(x: int) -> np.ndarray:
 
 
 def fq_from_mont(a) -> int:
-    return limbs_to_int(a) * pow(1 << 384, -1, Q_MOD) % Q_MOD
+    return limbs_to_int(a) * _FQ_RINV % Q_MOD
 
 
 def random_fr(n: int, seed: int) -> np.ndarray:

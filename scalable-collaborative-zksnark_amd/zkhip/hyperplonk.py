@@ -93,50 +93,12 @@ def _at(buf, byte_off):
     return buf.at(byte_off) if hasattr(buf, "at") else buf + byte_off
 
 
-def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be, net: Net, seed: int = 1, data_parallel: bool = False):
-    """
-    dhyperplonk.rs:159-571 (data_parallel=True: dhyperplonk_data_parallel :573-960, which differs
-    only at step 2.a -- `s` is local random data, no exchange, :603).
-    Returns ((gate_identity_proofs, gate_identity_commitments), (wiring_proofs, wiring_commits, wiring_opens)), timers.
-    """
+def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_np, eq_top):
+    """step 2 of dhyperplonk (:262-514) == the body of dpermcheck (:992-1245)"""
     T, L = pk.tables, pk.lens
     l, npar = pp.l, net.n_parties
     M = 1 << n
-    tm = Timers(net.is_leader)
-    # "Jump from sky" (:187-190)
-    local_s_p = be.to_device(random_fr(4 * M // npar, seed * 31 + 1))
-    local_s_np = random_fr(4 * M // npar // l, seed * 31 + 2)
-    eq_top = be.to_device(random_fr(pp.n, seed * 31 + 3))
-    net.sync()
-    tm.start("Distributed HyperPlonk")
-
-    # Step 1: commit (:198-215)
-    tm.start("Commit")
     cc, dc = pk.c_commitment, pk.d_commitment
-    com = {}
-    for name in ("a_evals", "b_evals", "c_evals"):
-        com[name] = dp.c_commit(be, cc, [T[name]], [L[name]], pp, net)[0]
-    for name in ("I_p", "S1_p", "S2_p"):
-        com[name] = dp.d_commit(be, dc, T[name], L[name], net)
-    tm.end()
-
-    # Step 3: gate identity (:223-260)
-    tm.start("Gate identity")
-    gate_proofs = []
-    csp = lambda f, g, length: dp.c_sumcheck_product(be, f, g, length, pk.challenge, pp, net)
-    Ml = M // l
-    gate_proofs.append(csp(T["eq"], T["S1"], Ml))
-    sum_ab = be.fr_add(T["a_evals"], T["b_evals"], Ml)  # :233-238
-    gate_proofs.append(csp(T["S1"], sum_ab, Ml))
-    gate_proofs.append(csp(T["eq"], T["S2"], Ml))
-    gate_proofs.append(csp(T["a_evals"], T["b_evals"], Ml))
-    gate_proofs.append(csp(T["S2"], T["a_evals"], Ml))
-    sum_ci = be.fr_sub(T["I"], T["c_evals"], Ml)  # -c + I  :251-256
-    gate_proofs.append(csp(T["eq"], sum_ci, Ml))
-    tm.end()
-
-    # Step 2: wiring identity
-    tm.start("Wire identity")
     wiring_proofs, wiring_commits, wiring_opens = [], [], []
     # 2.a (:268-294): every party broadcasts local_s; s = concatenation over parties (an all-gather)
     if data_parallel:
@@ -192,6 +154,54 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
         wiring_proofs.append(dp.sumcheck_product(be, eq_top, d1, len(lv1x), chs))
         wiring_proofs.append(dp.sumcheck_product(be, eq_top, d0, len(lvx0), chs))
         wiring_proofs.append(dp.sumcheck_product(be, d0, dd1, len(lvx0), chs))
+    return wiring_proofs, wiring_commits, wiring_opens
+
+
+def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be, net: Net, seed: int = 1, data_parallel: bool = False):
+    """
+    dhyperplonk.rs:159-571 (data_parallel=True: dhyperplonk_data_parallel :573-960, which differs
+    only at step 2.a -- `s` is local random data, no exchange, :603).
+    Returns ((gate_identity_proofs, gate_identity_commitments), (wiring_proofs, wiring_commits, wiring_opens)), timers.
+    """
+    T, L = pk.tables, pk.lens
+    l, npar = pp.l, net.n_parties
+    M = 1 << n
+    tm = Timers(net.is_leader)
+    # "Jump from sky" (:187-190)
+    local_s_p = be.to_device(random_fr(4 * M // npar, seed * 31 + 1))
+    local_s_np = random_fr(4 * M // npar // l, seed * 31 + 2)
+    eq_top = be.to_device(random_fr(pp.n, seed * 31 + 3))
+    net.sync()
+    tm.start("Distributed HyperPlonk")
+
+    # Step 1: commit (:198-215)
+    tm.start("Commit")
+    cc, dc = pk.c_commitment, pk.d_commitment
+    com = {}
+    for name in ("a_evals", "b_evals", "c_evals"):
+        com[name] = dp.c_commit(be, cc, [T[name]], [L[name]], pp, net)[0]
+    for name in ("I_p", "S1_p", "S2_p"):
+        com[name] = dp.d_commit(be, dc, T[name], L[name], net)
+    tm.end()
+
+    # Step 3: gate identity (:223-260)
+    tm.start("Gate identity")
+    gate_proofs = []
+    csp = lambda f, g, length: dp.c_sumcheck_product(be, f, g, length, pk.challenge, pp, net)
+    Ml = M // l
+    gate_proofs.append(csp(T["eq"], T["S1"], Ml))
+    sum_ab = be.fr_add(T["a_evals"], T["b_evals"], Ml)  # :233-238
+    gate_proofs.append(csp(T["S1"], sum_ab, Ml))
+    gate_proofs.append(csp(T["eq"], T["S2"], Ml))
+    gate_proofs.append(csp(T["a_evals"], T["b_evals"], Ml))
+    gate_proofs.append(csp(T["S2"], T["a_evals"], Ml))
+    sum_ci = be.fr_sub(T["I"], T["c_evals"], Ml)  # -c + I  :251-256
+    gate_proofs.append(csp(T["eq"], sum_ci, Ml))
+    tm.end()
+
+    # Step 2: wiring identity (shared with dpermcheck)
+    tm.start("Wire identity")
+    wiring_proofs, wiring_commits, wiring_opens = _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_np, eq_top)
     tm.end()
 
     # Open (:517-553)
@@ -204,3 +214,59 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     tm.end()
     tm.end()
     return ((gate_proofs, gate_commitments), (wiring_proofs, wiring_commits, wiring_opens)), tm.t
+
+
+def dpermcheck(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be, net: Net, seed: int = 1):
+    """hyperplonk/src/dhyperplonk.rs:962-1247: the distributed permutation check alone (= step 2 of dhyperplonk)"""
+    l, npar = pp.l, net.n_parties
+    M = 1 << n
+    tm = Timers(net.is_leader)
+    local_s_np = random_fr(4 * M // npar // l, seed * 31 + 2)
+    local_s_p = be.to_device(random_fr(4 * M // npar, seed * 31 + 1))
+    eq_top = be.to_device(random_fr(pp.n, seed * 31 + 3))
+    net.sync()
+    tm.start("Distributed Permcheck")
+    res = _wiring_identity(n, pk, pp, be, net, seed, False, local_s_p, local_s_np, eq_top)
+    tm.end()
+    return res, tm.t
+
+
+def cpermcheck(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be, net: Net, seed: int = 1):
+    """
+    hyperplonk/src/dhyperplonk.rs:1249-1385: the collaborative (packed) permutation check:
+    num/den maps, c_commit/c_open of the public wires, and per polynomial the masked product tree
+    (c_acc_product_and_share) with its commits, opens and three product sumchecks.
+    """
+    T = pk.tables
+    l = pp.l
+    G4 = 4 * ((1 << n) // l)  # gate_count * 4 with gate_count = 2^n / l (:1270)
+    tm = Timers(net.is_leader)
+    # masks (PackedProvingParameters::new :124-127), generated on first use
+    for i, name in enumerate(("mask", "unmask0", "unmask1", "unmask2")):
+        if name not in T:
+            T[name] = be.to_device(random_fr(G4, seed * 977 + 50 + i))
+            pk.lens[name] = G4
+    net.sync()
+    tm.start("Collaborative Permcheck")
+    cc = pk.c_commitment
+    num = be.fr_axpb(T["V"], T["sid"], pk.alpha, pk.beta, G4)  # :1277-1279
+    den = be.fr_axpb(T["eq_r1"], T["ssigma"], pk.alpha, pk.beta, G4)  # :1280-1282
+    proofs, commits, opens = [], [], []
+    ccommit = lambda tab: dp.c_commit(be, cc, [tab], [G4], pp, net)[0]
+    copen = lambda tab: dp.c_open(be, cc, tab, G4, pk.challenge_r1, pp, net)
+    for name in ("ssigma", "sid"):  # :1289-1308
+        commits.append(ccommit(T[name]))
+        opens.append(copen(T[name]))
+    for ev in (num, den):
+        vx0, vx1, v1x = dp.c_acc_product_and_share(be, ev, T["mask"], T["unmask0"], T["unmask1"], T["unmask2"], G4, pp, net)
+        d0, d1, d2 = be.to_device(vx0), be.to_device(vx1), be.to_device(v1x)
+        for tab in (ev, d0, d1, d2):  # :1324-1363
+            commits.append(ccommit(tab))
+            opens.append(copen(tab))
+        csp = lambda f, g: dp.c_sumcheck_product(be, f, g, G4, pk.challenge_r1, pp, net)
+        proofs.append(csp(T["eq_r1"], d2))  # :1365-1369
+        proofs.append(csp(T["eq_r1"], d0))
+        proofs.append(csp(d0, d1))
+        opens.append(copen(ev))  # :1371-1375
+    tm.end()
+    return (proofs, commits, opens), tm.t

@@ -34,6 +34,15 @@ class Net:
         """every party contributes `a` (same shape everywhere); returns the list ordered by party id"""
         raise NotImplementedError
 
+    def all_to_all(self, chunks: List[np.ndarray], echo: str = "slot0") -> List[np.ndarray]:
+        """
+        party p sends chunks[q] to party q; returns [what party q sent to me for q < n].  Replaces the
+        reference's loops of dynamic gathers / scatters over every root (dacc_product.rs:94-104,
+        :155-203).  Default: all-gather of the stacked chunks, then select (backends override).
+        """
+        allc = self.all_gather(np.stack(chunks))
+        return [allc[q][self.party_id] for q in range(self.n_parties)]
+
     def sync(self):
         self.all_gather(np.zeros(1, dtype=np.uint64))
 
@@ -56,6 +65,17 @@ class LeaderEchoNet(Net):
     def all_gather(self, a):
         self._count(a.nbytes)
         return [np.array(a, copy=True) for _ in range(self.n_parties)]
+
+    def all_to_all(self, chunks, echo="slot0"):
+        """
+        the fake's two behaviours: a dynamic GATHER to self returns n copies of the own message
+        (serializing_net.rs:159-162 -> echo="slot0"); for the looped dynamic SCATTERs the callers
+        substitute their local data per destination (dacc_product.rs:194-202 -> echo="identity")
+        """
+        self._count(sum(c.nbytes for c in chunks) // max(len(chunks), 1))
+        if echo == "identity":
+            return [np.array(c, copy=True) for c in chunks]
+        return [np.array(chunks[0], copy=True) for _ in range(self.n_parties)]
 
 
 class TorchDistNet(Net):
@@ -82,6 +102,19 @@ class TorchDistNet(Net):
         self._count(a.nbytes)
         return [o.cpu().numpy().view(a.dtype).reshape(a.shape) for o in outs]
 
+    def all_to_all(self, chunks, echo="slot0"):
+        import torch
+
+        if self.dist.get_backend(self.group) != "nccl":
+            return super().all_to_all(chunks)
+        a = np.ascontiguousarray(np.stack(chunks))
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(self.device)
+        out = torch.empty_like(t)
+        self.dist.all_to_all_single(out, t, group=self.group)
+        self._count(a.nbytes // self.n_parties)
+        r = out.cpu().numpy().view(a.dtype).reshape(a.shape)
+        return [r[q] for q in range(self.n_parties)]
+
 
 class _LocalHub:
     def __init__(self, n):
@@ -100,6 +133,14 @@ class LocalTestNet(Net):
         out = [np.array(s, copy=True) for s in self.hub.slots]
         self.hub.barrier.wait()
         self._count(a.nbytes)
+        return out
+
+    def all_to_all(self, chunks, echo="slot0"):
+        self.hub.slots[self.party_id] = [np.array(c, copy=True) for c in chunks]
+        self.hub.barrier.wait()
+        out = [np.array(self.hub.slots[q][self.party_id], copy=True) for q in range(self.n_parties)]
+        self.hub.barrier.wait()
+        self._count(sum(c.nbytes for c in chunks) // max(len(chunks), 1))
         return out
 
     @staticmethod

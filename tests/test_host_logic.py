@@ -229,3 +229,24 @@ def test_d_fix_variable():
     for p in range(pp.n):
         assert ints(res[p][0]) == po.fix_variable(shares[p], pts[:2])
         assert ints(res[p][1]) == po.fold(ss[p], pts[0])  # one extra round re-using points[0] (mle.rs:78)
+
+
+@pytest.mark.parametrize("l", [1, 2])
+def test_c_acc_product_and_share(l):
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    be = OracleBackend()
+    rng = po.SplitMix64(180 + l)
+    S = 16 * pp.n
+    vec = lambda: [rng.fr_vec(S) for _ in range(pp.n)]
+    shares, masks, u0, u1, u2 = vec(), vec(), vec(), vec(), vec()
+
+    def party(net):
+        p = net.party_id
+        d = lambda v: be.to_device(to_m(v[p]))
+        return dp.c_acc_product_and_share(be, d(shares), d(masks), d(u0), d(u1), d(u2), S, pp, net)
+
+    res = LocalTestNet.simulate_network_round(pp.n, party)
+    exp = po.c_acc_product_and_share_all(shares, masks, u0, u1, u2, opp)
+    for p in range(pp.n):
+        for k in range(3):
+            assert ints(res[p][k]) == exp[p][k], (p, k)

@@ -105,3 +105,40 @@ def test_dhyperplonk_data_parallel_gpu():
     exp = LocalTestNet.simulate_network_round(8, party_with(OracleBackend))
     got = LocalTestNet.simulate_network_round(8, party_with(lambda: zkhip.Ctx(0)))
     assert _digest(got[0]) == _digest(exp[0])
+
+
+def _run_perm(make_backend, n, which):
+    from zkhip.hyperplonk import cpermcheck, dpermcheck
+
+    pp = PackedSharingParams(1)
+    fn = {"d": dpermcheck, "c": cpermcheck}[which]
+
+    def party(net):
+        be = make_backend()
+        pk = PackedProvingParameters.new(n, pp, be, seed=500 + net.party_id)
+        return fn(n, pk, pp, be, net, seed=600 + net.party_id)[0]
+
+    return LocalTestNet.simulate_network_round(8, party)
+
+
+def test_permchecks_structure_cpu():
+    n = 5
+    dres = _run_perm(OracleBackend, n, "d")
+    full = _run_threads(OracleBackend, n)
+    # dpermcheck is exactly the wiring-identity step of dhyperplonk: same shapes
+    assert [len(x) for x in dres[0]] == [len(x) for x in full[0][1]]
+    cres = _run_perm(OracleBackend, n, "c")
+    proofs, commits, opens = cres[0]
+    assert len(proofs) == 6 and len(commits) == 2 + 2 * 4 and len(opens) == 2 + 2 * 5  # dhyperplonk.rs:1289-1375
+    assert proofs[0].shape == (n + 2 + 1, 3, 4) and opens[0][1].shape == (n + 2, 18)
+
+
+@pytest.mark.gpu
+def test_permchecks_gpu_match_oracle_backed_run():
+    import zkhip
+
+    n = 5
+    for which in ("d", "c"):
+        exp = _run_perm(OracleBackend, n, which)
+        got = _run_perm(lambda: zkhip.Ctx(0), n, which)
+        assert _digest(got[0]) == _digest(exp[0]) and _digest(got[3]) == _digest(exp[3]), which
