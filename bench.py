@@ -32,6 +32,26 @@ FQ_MUL_PEAK = 60.0e9  # measured Fq Montgomery mul/s, whole chip (profiles/r01_u
 FR_MUL_PEAK = 133.0e9  # measured Fr Montgomery mul/s
 
 
+def pmc_traffic_bytes(kernel: str):
+    """
+    HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/*pmc_hbm_traffic.csv: FETCH_SIZE and WRITE_SIZE, KB per dispatch, separate passes).
+    Raw counters: the guide's gfx950 note says FETCH_SIZE can under-report wide streaming reads by
+    up to 2x; the gather pattern here is uncalibrated, so the raw sum is reported.
+    """
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))
+    if not files:
+        return None
+    tot = 0.0
+    for row in csv.reader(open(files[-1])):
+        if len(row) == 4 and row[1] == kernel:
+            tot += float(row[3]) * 1024.0
+    return tot or None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,15 +71,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ZK_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than
+    # ranks (ranks then share GPUs round-robin); the real runs use nccl (= RCCL over xGMI).
+    backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
+    gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n = 1 << args.log2n
-    ctx = zkhip.Ctx(local_rank)  # raises if libzkhip.so / the GPU is missing (no fallback)
+    ctx = zkhip.Ctx(gpu)  # raises if libzkhip.so / the GPU is missing (no fallback)
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     seed = 0x5CA1AB1E + 1000 * 2 + rank
@@ -76,7 +103,7 @@ def main():
         from zkhip.net import TorchDistNet
         from zkhip.pss import PackedSharingParams
 
-        net = TorchDistNet(device=dev)
+        net = TorchDistNet(device=dev if backend == "nccl" else None)
         pp = PackedSharingParams(1) if world == 8 else None
 
     def barrier():
@@ -98,7 +125,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    phase = np.zeros(5)
+    phase = np.zeros(6)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -107,7 +134,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     phase /= max(args.steps, 1)
@@ -156,15 +183,15 @@ def main():
             "exchange": "none" if world == 1 else ("d_msm all-gather + PSS unpack2/pack map" if world == 8 else "all-gather only (partial party set)"),
             "pippenger_window_bits": c,
         },
-        "msm_phase_ms": {"digits_sort": float(phase[0]), "bucket_accumulate": accum_ms, "bucket_reduce": float(phase[2]), "host_combine": float(phase[3])},
+        "msm_phase_ms": {"digits_sort": float(phase[0]), "k_accum_tiles": accum_ms, "fixup": float(phase[2]), "bucket_reduce": float(phase[3]), "host_combine": float(phase[4])},
         "roofline": {
-            "kernel": "k_accum (bucket accumulation)",
+            "kernel": "zk::k_accum_tiles (bucket accumulation)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic_bytes("zk::k_accum_tiles") if args.log2n == 20 else None,
             "note": "integer-VALU bound, not HBM bound: see int_alu",
             "int_alu": {
                 "achieved_fq_mul_per_s": fq_mul_equiv / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,

@@ -111,6 +111,11 @@ int zk_srs_wrap_device(zk_ctx *ctx, const void *d_bases96, size_t n, zk_srs **ou
 /* Synthetic SRS on device: P_i = (k0 + i*k1)*G, the generator G1; mirrors the random-point SRS of
  * PolynomialCommitmentCub::new_single/new_random (dpoly_comm.rs:197-233). k0,k1 canonical 4xu64. */
 int zk_srs_generate(zk_ctx *ctx, const uint64_t h_k0[4], const uint64_t h_k1[4], size_t n, zk_srs **out);
+/* Optional, once per SRS level (setup, like uploading it): build the table 2^{o_w} * P_i for every
+ * window offset o_w of a `window_bits`-wide signed-digit decomposition (0 = pick for the level's
+ * length).  MSMs on this SRS then use ONE bucket set for all windows: 1/W of the bucket-reduction
+ * and fix-up work and no cross-window doubling chain.  Costs W x the level's memory (W ~ 16). */
+int zk_srs_precompute(zk_ctx *ctx, zk_srs *srs, int window_bits);
 int zk_srs_free(zk_ctx *ctx, zk_srs *srs);
 size_t zk_srs_len(const zk_srs *srs);
 const void *zk_srs_device_ptr(const zk_srs *srs);
@@ -140,9 +145,10 @@ int zk_g1_lincomb(zk_ctx *ctx, const uint64_t *h_points, const uint64_t *h_scala
 /* window size (bits) the device Pippenger picks for n points; 0 < override <= 20 forces it */
 int zk_msm_window(size_t n);
 int zk_msm_set_window(zk_ctx *ctx, int c_override);
-/* per-phase device time of the last zk_msm_g1 on this ctx, in ms:
- * [0] digits+sort, [1] bucket accumulation, [2] bucket reduction, [3] host combine, [4] total */
-int zk_msm_last_timing(zk_ctx *ctx, float h_ms[5]);
+/* per-phase time of the last zk_msm_g1 (first window class of a batch) on this ctx, in ms, HIP
+ * events on the ctx stream: [0] digits+sort, [1] k_accum_tiles (bucket accumulation kernel alone),
+ * [2] fix-up, [3] bucket reduction + D2H, [4] host combine (wall), [5] total */
+int zk_msm_last_timing(zk_ctx *ctx, float h_ms[6]);
 
 /* ---- test hooks (used by tests/ only; stable but not part of the drop-in surface) --- */
 int zk_dbg_fq_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);

@@ -220,8 +220,16 @@ int zk_srs_generate(zk_ctx* ctx, const uint64_t k0[4], const uint64_t k1[4], siz
     NEED(ctx, out && k0 && k1);
     return srs_generate(ctx, k0, k1, n, out);
 }
+int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs, int window_bits) {
+    NEED(ctx, srs);
+    return srs_precompute(ctx, srs, window_bits);
+}
 int zk_srs_free(zk_ctx* ctx, zk_srs* srs) {
     if (!srs) return ZK_OK;
+    if (srs->d_table) {
+        if (ctx) hipStreamSynchronize(ctx->stream);
+        hipFree(srs->d_table);
+    }
     if (srs->owned && srs->d_bases) {
         if (ctx) hipStreamSynchronize(ctx->stream);
         hipFree(srs->d_bases);
@@ -281,7 +289,7 @@ int zk_msm_set_window(zk_ctx* ctx, int c) {
     ctx->msm_window_override = c;
     return ZK_OK;
 }
-int zk_msm_last_timing(zk_ctx* ctx, float h_ms[5]) {
+int zk_msm_last_timing(zk_ctx* ctx, float h_ms[6]) {
     if (!ctx || !h_ms) return ZK_ERR_INVALID;
     std::memcpy(h_ms, ctx->msm_ms, sizeof(ctx->msm_ms));
     return ZK_OK;

@@ -11,6 +11,10 @@ struct zk_srs {
     void* d_bases = nullptr;  // packed 96-B affine points (x||y Montgomery, x=y=0: infinity)
     size_t n = 0;
     bool owned = true;
+    // optional precomputed table: copy w of point i = 2^{bit_offset(w)} * P_i at d_table[w * table_stride + i]
+    void* d_table = nullptr;
+    int table_c = 0;
+    size_t table_stride = 0;
 };
 
 struct zk_ctx {
@@ -27,7 +31,7 @@ struct zk_ctx {
     void* h_pinned = nullptr;  // pinned host staging
     size_t h_pinned_cap = 0;
     int msm_window_override = 0;
-    float msm_ms[5] = {0, 0, 0, 0, 0};
+    float msm_ms[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int cu_count = 256;
 };
@@ -67,6 +71,7 @@ struct MsmItem {
 int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out);
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out);
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
+int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c);
 int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, zk_srs** out);
 int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n);
 int msm_pick_window(size_t n);

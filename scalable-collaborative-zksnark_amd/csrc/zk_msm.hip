@@ -66,7 +66,8 @@ struct ItemDesc {
     const void* scalars;
     const void* bases;  // packed 96-B affine points, already offset
     u32 n;
-    u32 pad;
+    u32 pstride;  // 0: one base vector for every window (entry value = point index);
+                  // else: precomputed table, copy w of point i at bases[w * pstride + i]
 };
 
 __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ items, size_t ns, WinLayout L,
@@ -208,14 +209,24 @@ __global__ void __launch_bounds__(kScanThreads) k_scan(const u32* __restrict__ c
 // sorted entries; runs that are whole buckets are stored directly, the (at most two) runs cut by
 // the tile boundary go to heads[] / tails[] and are stitched by k_fixup.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict__ items, int W, const u32* __restrict__ sorted,
-                                                    const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t ns,
-                                                    size_t nb, u32 T, size_t tiles_per_w, size_t total_tiles,
-                                                    void* __restrict__ buckets, void* __restrict__ heads, void* __restrict__ tails) {
+__global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict__ items, int rows_per_item,
+                                                    const u32* __restrict__ sorted, const u32* __restrict__ offsets,
+                                                    const u32* __restrict__ counts, size_t ns, u32 nsi, size_t nb, u32 T,
+                                                    size_t tiles_per_w, size_t total_tiles, void* __restrict__ buckets,
+                                                    void* __restrict__ heads, void* __restrict__ tails) {
     const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (g >= total_tiles) return;
-    const size_t w = g / tiles_per_w, t = g % tiles_per_w;  // w = row = item * W + window
-    const void* __restrict__ bases = items[w / W].bases;
+    const size_t w = g / tiles_per_w, t = g % tiles_per_w;  // w = row
+    const ItemDesc it = items[w / rows_per_item];
+    const void* __restrict__ bases = it.bases;
+    // entry value v = index inside the row; with a precomputed table the row spans all windows:
+    // window = v / nsi, point = v % nsi  ->  table index window * pstride + point
+    auto pidx = [&](u32 v) -> size_t {
+        v &= 0x7fffffffu;
+        if (it.pstride == 0) return v;
+        u32 win = v / nsi;
+        return (size_t)win * it.pstride + (v - win * nsi);
+    };
     const u32* off = offsets + w * nb;
     const u32* cnt = counts + w * nb;
     const u32 nw = off[nb - 1] + cnt[nb - 1];  // entries of this window (zero digits are skipped)
@@ -236,7 +247,7 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
     Xyzz acc;
     xyzz_set_inf(acc);
     u32 v = run[e0];
-    Aff p = aff_load(bases, v & 0x7fffffffu);
+    Aff p = aff_load(bases, pidx(v));
     for (u32 e = e0; e < e1; e++) {
         if (e == bend) {  // run finished: flush and move to the next non-empty bucket
             if (ps == bstart) xyzz_store(buckets, w * nb + b, acc);  // whole bucket
@@ -253,7 +264,7 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
         Aff cur = p;
         if (e + 1 < e1) {  // prefetch the next point while this one is being added
             v = run[e + 1];
-            p = aff_load(bases, v & 0x7fffffffu);
+            p = aff_load(bases, pidx(v));
         }
         xyzz_madd(acc, cur, neg);
     }
@@ -348,6 +359,36 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
     xyzz_store(out, t, res);
 }
 
+// SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine, packed 96 B), one lane per point.
+// With it every window's digit can use the SAME bucket set (the factor 2^{c w} is in the base).
+__global__ void __launch_bounds__(kBlk) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
+                                                   void* __restrict__ table) {
+    const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n) return;
+    Aff p = aff_load(bases, i);
+    char* out = reinterpret_cast<char*>(table);
+    Xyzz acc;
+    xyzz_set_inf(acc);
+    xyzz_madd(acc, p, false);
+    for (int w = 0; w < L.W; w++) {
+        if (w > 0)
+            for (int k = 0; k < L.width(w - 1); k++) acc = xyzz_dbl(acc);
+        Aff a;
+        if (xyzz_is_inf(acc)) {
+            a.x = fp_zero<FqCfg>();
+            a.y = fp_zero<FqCfg>();
+        } else {
+            Fq i3 = fp_inv<FqCfg>(acc.zzz);   // 1/Z^3
+            Fq iz = fq_mul(acc.zz, i3);       // Z^2/Z^3 = 1/Z
+            a.x = fq_mul(acc.x, fq_sqr(iz));  // X/Z^2
+            a.y = fq_mul(acc.y, i3);          // Y/Z^3
+        }
+        char* dst = out + ((size_t)w * nsr + i) * 96;
+        fp_store<FqCfg>(dst, 0, a.x);
+        fp_store<FqCfg>(dst + 48, 0, a.y);
+    }
+}
+
 // test hook: XYZZ arithmetic on pairs of affine points
 __global__ void __launch_bounds__(kBlk) k_dbg_g1(const void* __restrict__ p, const void* __restrict__ q, void* __restrict__ out,
                                                size_t n, int mode) {
@@ -401,6 +442,9 @@ static void combine_item(const uint64_t* h, const WinLayout& L, int c, uint64_t*
 }
 
 struct MsmClass {
+    bool shared = false;  // precomputed-table mode: one bucket row per item spanning all windows
+    int rpi = 0;          // bucket rows per item (W, or 1 when shared)
+    size_t row_len = 0;   // entries per row (ns, or W * ns when shared)
     int c = 0;
     WinLayout L{};
     std::vector<size_t> idx;  // items of the batch in this class
@@ -433,13 +477,16 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         }
         int c = ctx->msm_window_override > 0 ? ctx->msm_window_override : msm_pick_window(it.n);
         if (count > 1 && ctx->msm_window_override <= 0) c = quantised_window(c);
+        const bool shared = it.srs->d_table != nullptr && ctx->msm_window_override <= 0;
+        if (shared) c = it.srs->table_c;
         MsmClass* cl = nullptr;
         for (auto& x : classes)
-            if (x.c == c) cl = &x;
+            if (x.c == c && x.shared == shared) cl = &x;
         if (!cl) {
             classes.emplace_back();
             cl = &classes.back();
             cl->c = c;
+            cl->shared = shared;
             cl->L = msm_layout(c);
             cl->nb = (size_t)1 << (c - 1);
         }
@@ -452,7 +499,9 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     for (auto& cl : classes) {
         const int W = cl.L.W;
         const size_t nitems = cl.idx.size();
-        cl.rows = nitems * W;
+        cl.rpi = cl.shared ? 1 : W;
+        cl.row_len = cl.shared ? (size_t)W * cl.ns : cl.ns;
+        cl.rows = nitems * cl.rpi;
         cl.total = cl.rows * cl.nb;
         size_t nmax = 0;
         for (size_t k : cl.idx) nmax = std::max(nmax, items[k].n);
@@ -460,24 +509,27 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         // for small MSMs balance the serial chain of a lane (T mixed adds, ~10 Fq-mul each) against
         // the fix-up chain of a bucket (entries_per_bucket / T full adds, ~14 Fq-mul each)
         cl.T = 32;
-        if ((size_t)cl.rows * nmax / 32 < (size_t)ctx->cu_count * 4 * 64 * 2) {
-            const double per_bucket = (double)nmax / (double)cl.nb;
+        const double per_bucket = (double)nmax * (cl.shared ? W : 1) / (double)cl.nb;
+        if ((size_t)nitems * W * nmax / 32 < (size_t)ctx->cu_count * 4 * 64 * 2) {
             cl.T = 4;
             while (cl.T < 32 && (double)cl.T * cl.T < 1.4 * per_bucket) cl.T <<= 1;
+        } else if (cl.shared) {
+            // long buckets (every window lands in the same row): longer tiles keep the fix-up chain short
+            while (cl.T < 128 && (double)cl.T * 4 < per_bucket && (size_t)nitems * W * nmax / (2 * cl.T) >= (size_t)ctx->cu_count * 4 * 64 * 2) cl.T <<= 1;
         }
         if (T_env) cl.T = T_env;
-        cl.tiles_per_w = (cl.ns + cl.T - 1) / cl.T;
+        cl.tiles_per_w = (cl.row_len + cl.T - 1) / cl.T;
         cl.total_tiles = cl.tiles_per_w * cl.rows;
         // sort geometry: rows x chunks x bucket ranges; LDS counters <= 64 KiB per block
         cl.bpb = (u32)std::min<size_t>(cl.nb, bpb_env ? bpb_env : 16384);
         cl.P = (unsigned)(cl.nb / cl.bpb);
         size_t want = 512 / (cl.rows * cl.P);
-        cl.nchunks = (u32)std::max<size_t>(1, std::min<size_t>(want ? want : 1, (cl.ns + 8191) / 8192));
-        cl.chunk_len = ((cl.ns + cl.nchunks - 1) / cl.nchunks + 3) & ~(size_t)3;
-        cl.nchunks = (u32)((cl.ns + cl.chunk_len - 1) / cl.chunk_len);
+        cl.nchunks = (u32)std::max<size_t>(1, std::min<size_t>(want ? want : 1, (cl.row_len + 8191) / 8192));
+        cl.chunk_len = ((cl.row_len + cl.nchunks - 1) / cl.nchunks + 3) & ~(size_t)3;
+        cl.nchunks = (u32)((cl.row_len + cl.chunk_len - 1) / cl.chunk_len);
         cl.cc_elems = cl.rows * cl.P * (size_t)cl.nchunks * cl.bpb;
-        need[0] = std::max(need[0], cl.rows * cl.ns * 4);
-        need[1] = std::max(need[1], cl.rows * cl.ns * 4);
+        need[0] = std::max(need[0], cl.rows * cl.row_len * 4);
+        need[1] = std::max(need[1], cl.rows * cl.row_len * 4);
         need[2] = std::max(need[2], 2 * cl.total * 4);
         need[3] = std::max(need[3], cl.total * 192);
         need[4] = std::max(need[4], cl.total * 192);
@@ -521,9 +573,9 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         for (size_t j = 0; j < nitems; j++) {
             const MsmItem& it = items[cl.idx[j]];
             h_items[j].scalars = it.d_scalars;
-            h_items[j].bases = (const char*)it.srs->d_bases + it.offset * 96;
+            h_items[j].bases = (const char*)(cl.shared ? it.srs->d_table : it.srs->d_bases) + it.offset * 96;
             h_items[j].n = (u32)it.n;
-            h_items[j].pad = 0;
+            h_items[j].pstride = cl.shared ? (u32)it.srs->table_stride : 0;
         }
         if (first) hipEventRecord(ctx->ev[0], st);
         ZK_HIP(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
@@ -531,18 +583,19 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, ns, cl.L, digits);
         hipLaunchKernelGGL((k_sort_pass<false>), dim3(cl.nchunks, cl.P, (unsigned)cl.rows), dim3(kSortThreads), cl.bpb * 4, st,
-                           (const u32*)digits, ns, cl.chunk_len, cl.nchunks, nb, cl.bpb, cc, (u32*)nullptr);
+                           (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, cc, (u32*)nullptr);
         hipLaunchKernelGGL(k_bucket_totals, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)cc, cl.nchunks,
                            nb, cl.bpb, total, counts);
         hipLaunchKernelGGL(k_scan, dim3((unsigned)cl.rows), dim3(kScanThreads), 0, st, (const u32*)counts, nb, offsets);
         hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, cc, cl.nchunks, nb, cl.bpb,
                            total, (const u32*)offsets);
         hipLaunchKernelGGL((k_sort_pass<true>), dim3(cl.nchunks, cl.P, (unsigned)cl.rows), dim3(kSortThreads), cl.bpb * 4, st,
-                           (const u32*)digits, ns, cl.chunk_len, cl.nchunks, nb, cl.bpb, cc, sorted);
+                           (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, cc, sorted);
         if (first) hipEventRecord(ctx->ev[1], st);
         hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
-                           (const ItemDesc*)d_items, W, (const u32*)sorted, (const u32*)offsets, (const u32*)counts, ns, nb, cl.T,
-                           cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
+                           (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const u32*)offsets, (const u32*)counts, cl.row_len,
+                           (u32)ns, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
+        if (first) hipEventRecord(ctx->ev[4], st);
         hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
                            (const u32*)counts, nb, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                            longs + 1);
@@ -578,9 +631,12 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     std::vector<Job> jobs;
     for (auto& cl : classes)
         for (size_t j = 0; j < cl.idx.size(); j++)
-            jobs.push_back(Job{(const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.L.W * cl.c * 24, &cl, h_out + 18 * cl.idx[j]});
+            jobs.push_back(Job{(const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.rpi * cl.c * 24, &cl, h_out + 18 * cl.idx[j]});
     auto work = [&](size_t lo, size_t hi) {
-        for (size_t j = lo; j < hi; j++) combine_item(jobs[j].h, jobs[j].cl->L, jobs[j].cl->c, jobs[j].out);
+        for (size_t j = lo; j < hi; j++) {
+            WinLayout one{1, 0, 0};  // shared buckets: a single row, the window factors live in the table
+            combine_item(jobs[j].h, jobs[j].cl->shared ? one : jobs[j].cl->L, jobs[j].cl->c, jobs[j].out);
+        }
     };
     if (jobs.size() == 1) {
         work(0, 1);
@@ -593,13 +649,15 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     auto t1 = std::chrono::steady_clock::now();
     float ms;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
-    ctx->msm_ms[0] = ms;
-    hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]);
-    ctx->msm_ms[1] = ms;
+    ctx->msm_ms[0] = ms;  // digits + sort
+    hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]);
+    ctx->msm_ms[1] = ms;  // k_accum_tiles alone (the dominant kernel)
+    hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[2]);
+    ctx->msm_ms[2] = ms;  // fix-up
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]);
-    ctx->msm_ms[2] = ms;
-    ctx->msm_ms[3] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    ctx->msm_ms[4] = ctx->msm_ms[0] + ctx->msm_ms[1] + ctx->msm_ms[2] + ctx->msm_ms[3];
+    ctx->msm_ms[3] = ms;  // bucket reduction + D2H
+    ctx->msm_ms[4] = std::chrono::duration<float, std::milli>(t1 - t0).count();  // host combine
+    ctx->msm_ms[5] = ctx->msm_ms[0] + ctx->msm_ms[1] + ctx->msm_ms[2] + ctx->msm_ms[3] + ctx->msm_ms[4];
     return ZK_OK;
 }
 
@@ -633,6 +691,30 @@ int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs**
         }
     }
     *out = s;
+    return ZK_OK;
+}
+
+int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
+    if (!srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
+    if (c == 0) c = msm_pick_window(srs->n ? srs->n : 1);
+    if (c < 2 || c > 20) return fail(ctx, ZK_ERR_INVALID, "window bits out of range");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    if (srs->d_table) {
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(srs->d_table);
+        srs->d_table = nullptr;
+    }
+    if (srs->n == 0) return ZK_OK;
+    const WinLayout L = msm_layout(c);
+    const size_t nsr = (srs->n + 3) & ~(size_t)3;
+    ZK_HIP(ctx, hipMalloc(&srs->d_table, (size_t)L.W * nsr * 96));
+    ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * 96, ctx->stream));
+    hipLaunchKernelGGL(k_precompute, dim3((unsigned)((srs->n + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream,
+                       (const void*)srs->d_bases, srs->n, nsr, L, srs->d_table);
+    ZK_HIP(ctx, hipGetLastError());
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    srs->table_c = c;
+    srs->table_stride = nsr;
     return ZK_OK;
 }
 

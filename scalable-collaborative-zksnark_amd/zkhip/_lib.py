@@ -41,6 +41,7 @@ SYMBOLS = [
     ("zk_srs_register", _i, [_vp, _vp, _sz, _sz, _pp]),
     ("zk_srs_wrap_device", _i, [_vp, _vp, _sz, _pp]),
     ("zk_srs_generate", _i, [_vp, _vp, _vp, _sz, _pp]),
+    ("zk_srs_precompute", _i, [_vp, _vp, _i]),
     ("zk_srs_free", _i, [_vp, _vp]),
     ("zk_srs_len", _sz, [_vp]),
     ("zk_srs_device_ptr", _vp, [_vp]),

@@ -90,6 +90,11 @@ class Srs:
     def device_ptr(self) -> int:
         return self.ctx.lib.zk_srs_device_ptr(self.h) or 0
 
+    def precompute(self, window_bits: int = 0):
+        """build the per-window tables (setup): MSMs on this SRS then share one bucket set"""
+        self.ctx._check(self.ctx.lib.zk_srs_precompute(self.ctx.h, self.h, window_bits))
+        return self
+
     def download(self) -> np.ndarray:
         n = len(self)
         out = np.empty((n, 12), dtype=np.uint64)
@@ -296,7 +301,7 @@ class Ctx:
         self._check(self.lib.zk_msm_set_window(self.h, c))
 
     def msm_last_timing(self) -> np.ndarray:
-        t = np.zeros(5, dtype=np.float32)
+        t = np.zeros(6, dtype=np.float32)
         self._check(self.lib.zk_msm_last_timing(self.h, _h(t)))
         return t
 

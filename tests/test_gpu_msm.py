@@ -145,3 +145,23 @@ def test_msm_batch_matches_individual(ctx, co):
     got = ctx.msm_g1_batch([big, big], [d, d.at(32 * 1024)], [1024, 512], offsets=[0, 1024])
     assert (jac_norm_to_affine(got[0]) == co.msm_g1(bases[:1024], sc[:1024])).all()
     assert (jac_norm_to_affine(got[1]) == co.msm_g1(bases[1024:1536], sc[1024:1536])).all()
+
+
+@pytest.mark.parametrize("n,c", [(1, 0), (100, 5), (5000, 0), (5000, 13), (1 << 15, 0), (1 << 15, 16)])
+def test_msm_precomputed_srs_matches_oracle(ctx, co, n, c):
+    """shared-bucket mode (zk_srs_precompute): same result as the oracle, also on sub-ranges and in batches"""
+    bases, _ = synthetic_bases(n, 800 + n)
+    bases[n // 2] = 0  # an infinity base must stay infinity in every table copy
+    scalars = rand_fr(n, 801 + n)
+    srs = ctx.srs_register(bases).precompute(c)
+    d = ctx.to_device(scalars)
+    assert (jac_norm_to_affine(ctx.msm_g1(srs, d, n)) == co.msm_g1(bases, scalars)).all()
+    if n >= 100:
+        off, m = n // 4, n // 2
+        got = ctx.msm_g1(srs, d.at(32 * off), m, offset=off)
+        assert (jac_norm_to_affine(got) == co.msm_g1(bases[off : off + m], scalars[off : off + m])).all()
+        plain = ctx.srs_register(bases)
+        got = ctx.msm_g1_batch([srs, plain, srs], [d, d, d.at(32 * off)], [n, n, m], offsets=[0, 0, off])
+        exp = co.msm_g1(bases, scalars)
+        assert (jac_norm_to_affine(got[0]) == exp).all() and (jac_norm_to_affine(got[1]) == exp).all()
+        assert (jac_norm_to_affine(got[2]) == co.msm_g1(bases[off : off + m], scalars[off : off + m])).all()
