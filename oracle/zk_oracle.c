@@ -69,15 +69,20 @@ static inline __attribute__((always_inline)) u64 add_n(u64 *r, const u64 *a, con
     return carry;
 }
 static inline __attribute__((always_inline)) void mod_add(u64 *r, const u64 *a, const u64 *b, const u64 *p, int n) {
-    u64 t[NQ];
+    u64 t[NQ], d[NQ];
     u64 c = add_n(t, a, b, n);
-    if (c || ge_n(t, p, n)) sub_n(t, t, p, n);
-    memcpy(r, t, 8 * n);
+    u64 bw = sub_n(d, t, p, n);
+    u64 keep = (u64)0 - (u64)((bw != 0) & (c == 0)); /* all ones: keep t (t < p) */
+#pragma GCC unroll 6
+    for (int i = 0; i < n; i++) r[i] = (t[i] & keep) | (d[i] & ~keep);
 }
 static inline __attribute__((always_inline)) void mod_sub(u64 *r, const u64 *a, const u64 *b, const u64 *p, int n) {
-    u64 t[NQ];
-    if (sub_n(t, a, b, n)) add_n(t, t, p, n);
-    memcpy(r, t, 8 * n);
+    u64 t[NQ], pm[NQ];
+    u64 bw = sub_n(t, a, b, n);
+    u64 mask = (u64)0 - bw;
+#pragma GCC unroll 6
+    for (int i = 0; i < n; i++) pm[i] = p[i] & mask;
+    add_n(r, t, pm, n);
 }
 static inline int is_zero_n(const u64 *a, int n) {
     u64 o = 0;
