@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=LOG2_N)
-    ap.add_argument("--cpu-log2n", type=int, default=17, help="size of the bounded CPU-baseline MSM sample")
+    ap.add_argument("--cpu-log2n", type=int, default=20, help="size of the bounded CPU-baseline MSM sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

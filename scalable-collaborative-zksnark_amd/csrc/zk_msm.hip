@@ -726,16 +726,38 @@ int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, 
     H::Aff step = H::jac_to_aff(H::scalar_mul(G, k1));
     std::vector<H::Aff> pts(n);
     const size_t CH = 4096;
-    std::vector<H::Jac> chunk;
-    H::Jac cur = H::aff_inf(start) ? H::jac_inf() : H::Jac{start.x, start.y, H::ONE};
-    for (size_t base = 0; base < n; base += CH) {
-        size_t m = std::min(CH, n - base);
-        chunk.resize(m);
-        for (size_t i = 0; i < m; i++) {
-            chunk[i] = cur;
-            cur = H::jac_add_mixed(cur, step);
+    // chunk k starts at start + k*CH*step; chunks are independent -> host threads (setup only)
+    const size_t nchunk = (n + CH - 1) / CH;
+    std::vector<H::Jac> chunk_start(nchunk);
+    {
+        uint64_t chs[4] = {CH, 0, 0, 0};
+        H::Aff stride = H::jac_to_aff(H::scalar_mul(step, chs));
+        H::Jac cur = H::aff_inf(start) ? H::jac_inf() : H::Jac{start.x, start.y, H::ONE};
+        for (size_t k = 0; k < nchunk; k++) {
+            chunk_start[k] = cur;
+            cur = H::jac_add_mixed(cur, stride);
         }
-        H::batch_to_affine(chunk, &pts[base]);
+    }
+    auto work = [&](size_t k0c, size_t k1c) {
+        std::vector<H::Jac> chunk;
+        for (size_t k = k0c; k < k1c; k++) {
+            const size_t base = k * CH, m = std::min(CH, n - base);
+            chunk.resize(m);
+            H::Jac cur = chunk_start[k];
+            for (size_t i = 0; i < m; i++) {
+                chunk[i] = cur;
+                cur = H::jac_add_mixed(cur, step);
+            }
+            H::batch_to_affine(chunk, &pts[base]);
+        }
+    };
+    const size_t nth = std::min<size_t>({nchunk, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)64});
+    if (nth <= 1) {
+        work(0, nchunk);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nth; t++) th.emplace_back(work, nchunk * t / nth, nchunk * (t + 1) / nth);
+        for (auto& x : th) x.join();
     }
     return srs_pack(ctx, pts.data(), 96, n, out);
 }
