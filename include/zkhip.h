@@ -142,6 +142,10 @@ int zk_msm_g1_host(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n_bas
  * the host: n is N_p = 8l and the work is one ~255-step dependency chain. */
 int zk_g1_lincomb(zk_ctx *ctx, const uint64_t *h_points, const uint64_t *h_scalars, size_t n,
                   uint64_t h_out[18]);
+/* `count` combinations with one shared scalar vector: out[r] = sum_i k_i * P[r*n + i]
+ * (the per-proof-element sums of d_open, dpoly_comm.rs:372-376); inversions are batched. */
+int zk_g1_lincomb_batch(zk_ctx *ctx, const uint64_t *h_points, const uint64_t *h_scalars, size_t n,
+                        size_t count, uint64_t *h_out);
 /* window size (bits) the device Pippenger picks for n points; 0 < override <= 20 forces it */
 int zk_msm_window(size_t n);
 int zk_msm_set_window(zk_ctx *ctx, int c_override);

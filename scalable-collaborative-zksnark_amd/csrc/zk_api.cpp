@@ -283,6 +283,10 @@ int zk_g1_lincomb(zk_ctx* ctx, const uint64_t* h_points, const uint64_t* h_scala
     NEED(ctx, h_out && (n == 0 || (h_points && h_scalars)));
     return g1_lincomb_host(ctx, h_points, h_scalars, n, h_out);
 }
+int zk_g1_lincomb_batch(zk_ctx* ctx, const uint64_t* h_points, const uint64_t* h_scalars, size_t n, size_t count, uint64_t* h_out) {
+    NEED(ctx, (count == 0 || h_out) && (n == 0 || count == 0 || (h_points && h_scalars)));
+    return g1_lincomb_batch_host(ctx, h_points, h_scalars, n, count, h_out);
+}
 int zk_msm_window(size_t n) { return msm_pick_window(n); }
 int zk_msm_set_window(zk_ctx* ctx, int c) {
     if (!ctx || c < 0 || c > 20) return ZK_ERR_INVALID;

@@ -75,6 +75,8 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c);
 int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, zk_srs** out);
 int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n);
 int msm_pick_window(size_t n);
+int g1_lincomb_batch_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h_scalars_canon, size_t n, size_t count,
+                          uint64_t* h_out);
 int g1_lincomb_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h_scalars_canon, size_t n, uint64_t* h_out);
 
 }  // namespace zk

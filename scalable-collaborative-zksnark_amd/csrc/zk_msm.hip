@@ -766,17 +766,26 @@ int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, 
 // dmsm.rs:30-39; sums of N_p commitments dpoly_comm.rs:289-292): sum_i k_i * P_i for a handful
 // of points.  A joint double-and-add on the host: it is a ~255-step dependency chain, the same
 // shape as the MSM's final combine.
-int g1_lincomb_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h_scalars_canon, size_t n, uint64_t* h_out) {
+// count independent combinations sharing the scalar vector: out[r] = sum_i k_i * P[r][i].
+// One batch inversion normalises all inputs that need it, one more all outputs.
+int g1_lincomb_batch_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h_scalars_canon, size_t n, size_t count,
+                          uint64_t* h_out) {
     namespace H = zkhost;
-    std::vector<H::Aff> pts(n);
-    std::vector<H::Jac> tmp(n);
-    for (size_t i = 0; i < n; i++) {
+    const size_t total = n * count;
+    std::vector<H::Aff> pts(total);
+    std::vector<H::Jac> tmp(total);
+    bool all_affine = true;
+    for (size_t i = 0; i < total; i++) {
         std::memcpy(tmp[i].x.data(), h_points_jac + 18 * i, 48);
         std::memcpy(tmp[i].y.data(), h_points_jac + 18 * i + 6, 48);
         std::memcpy(tmp[i].z.data(), h_points_jac + 18 * i + 12, 48);
+        if (!(tmp[i].z == H::ONE) && !H::is_zero(tmp[i].z)) all_affine = false;
     }
-    if (n) H::batch_to_affine(tmp, pts.data());
-    H::Jac acc = H::jac_inf();
+    if (all_affine) {  // library outputs are already normalised: no inversion needed
+        for (size_t i = 0; i < total; i++) pts[i] = H::is_zero(tmp[i].z) ? H::Aff{H::ZERO, H::ZERO} : H::Aff{tmp[i].x, tmp[i].y};
+    } else if (total) {
+        H::batch_to_affine(tmp, pts.data());
+    }
     int top = -1;  // highest set bit over all scalars (coefficients 1 of d_commit / d_open sums: top = 0)
     for (size_t i = 0; i < n; i++)
         for (int b = 255; b > top; b--)
@@ -784,14 +793,31 @@ int g1_lincomb_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h
                 top = b;
                 break;
             }
-    for (int b = top; b >= 0; b--) {
-        acc = H::jac_dbl(acc);
-        for (size_t i = 0; i < n; i++)
-            if ((h_scalars_canon[4 * i + b / 64] >> (b % 64)) & 1) acc = H::jac_add_mixed(acc, pts[i]);
+    std::vector<H::Jac> acc(count, H::jac_inf());
+    for (size_t r = 0; r < count; r++) {
+        for (int b = top; b >= 0; b--) {
+            acc[r] = H::jac_dbl(acc[r]);
+            for (size_t i = 0; i < n; i++)
+                if ((h_scalars_canon[4 * i + b / 64] >> (b % 64)) & 1) acc[r] = H::jac_add_mixed(acc[r], pts[r * n + i]);
+        }
     }
-    H::write_normalised(acc, h_out);
+    std::vector<H::Aff> outa(count);
+    if (count) H::batch_to_affine(acc, outa.data());
+    for (size_t r = 0; r < count; r++) {
+        if (H::aff_inf(outa[r])) {
+            H::write_normalised(H::jac_inf(), h_out + 18 * r);
+        } else {
+            std::memcpy(h_out + 18 * r, outa[r].x.data(), 48);
+            std::memcpy(h_out + 18 * r + 6, outa[r].y.data(), 48);
+            std::memcpy(h_out + 18 * r + 12, H::ONE.data(), 48);
+        }
+    }
     (void)ctx;
     return ZK_OK;
+}
+
+int g1_lincomb_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h_scalars_canon, size_t n, uint64_t* h_out) {
+    return g1_lincomb_batch_host(ctx, h_points_jac, h_scalars_canon, n, 1, h_out);
 }
 
 int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n) {

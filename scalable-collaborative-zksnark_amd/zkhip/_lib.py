@@ -49,6 +49,7 @@ SYMBOLS = [
     ("zk_msm_g1_batch", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zk_msm_g1_host", _i, [_vp, _vp, _sz, _sz, _vp, _sz, _vp, ctypes.POINTER(ctypes.c_size_t)]),
     ("zk_g1_lincomb", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("zk_g1_lincomb_batch", _i, [_vp, _vp, _vp, _sz, _sz, _vp]),
     ("zk_msm_window", _i, [_sz]),
     ("zk_msm_set_window", _i, [_vp, _i]),
     ("zk_msm_last_timing", _i, [_vp, _vp]),

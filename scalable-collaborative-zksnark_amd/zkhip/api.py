@@ -297,6 +297,17 @@ class Ctx:
         self._check(self.lib.zk_g1_lincomb(self.h, _h(pts), _h(sc), len(pts), _h(out)))
         return out
 
+    def g1_lincomb_batch(self, points: np.ndarray, scalars_canon: np.ndarray) -> np.ndarray:
+        """points [count, n, 18], scalars [n, 4] shared by every row -> [count, 18]"""
+        pts = np.ascontiguousarray(points, dtype=np.uint64)
+        count, n = pts.shape[0], pts.shape[1]
+        sc = np.ascontiguousarray(scalars_canon, dtype=np.uint64).reshape(-1, 4)
+        assert len(sc) == n
+        out = np.zeros((count, 18), dtype=np.uint64)
+        if count:
+            self._check(self.lib.zk_g1_lincomb_batch(self.h, _h(pts), _h(sc), n, count, _h(out)))
+        return out
+
     def msm_set_window(self, c: int):
         self._check(self.lib.zk_msm_set_window(self.h, c))
 

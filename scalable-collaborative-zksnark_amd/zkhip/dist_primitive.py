@@ -54,11 +54,9 @@ def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: Packe
     c_shares = be.msm_g1_batch(list(bases), list(scalars), list(lens))  # one pipeline pass for the whole batch
     gathered = net.all_gather(c_shares)  # [party][batch,18]
     coeff = np.array([int_to_limbs(c, 4) for c in pp.dmsm_coeffs(net.party_id)], dtype=np.uint64)
-    out = np.zeros_like(c_shares)
-    for k in range(len(lens)):
-        pts = np.stack([gathered[p][k] for p in range(net.n_parties)])
-        out[k] = be.g1_lincomb(pts, coeff)
-    return out
+    if not len(lens):
+        return c_shares
+    return be.g1_lincomb_batch(np.stack([np.stack([gathered[p][k] for p in range(net.n_parties)]) for k in range(len(lens))]), coeff)
 
 
 # ---------------------------------------------------------------------------------------
@@ -251,7 +249,7 @@ def d_open(be, powers_of_g, peval, length: int, point: np.ndarray, net: Net):
     if not net.is_leader:
         return ZERO.copy(), np.zeros((0, 18), dtype=np.uint64)
     ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
-    pi = [be.g1_lincomb(np.stack([prfs[p][i] for p in range(net.n_parties)]), ones) for i in range(len(proofs))]
+    pi = list(be.g1_lincomb_batch(np.stack([np.stack([prfs[p][i] for p in range(net.n_parties)]) for i in range(len(proofs))]), ones)) if len(proofs) else []
     root_val, root_proofs = open_(be, powers_of_g, be.to_device(np.stack(vals)), net.n_parties, point[:plog])
     allp = list(root_proofs) + pi
     return root_val, (np.stack(allp) if allp else np.zeros((0, 18), dtype=np.uint64))

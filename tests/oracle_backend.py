@@ -72,6 +72,10 @@ class OracleBackend:
             acc = po.g1_add(acc, po.g1_mul(P, kk))
         return _jac(pt_mont(acc))
 
+    def g1_lincomb_batch(self, points, scalars_canon):
+        pts = np.asarray(points, dtype=np.uint64)
+        return np.stack([self.g1_lincomb(pts[r], scalars_canon) for r in range(pts.shape[0])]) if pts.shape[0] else np.zeros((0, 18), np.uint64)
+
     def sumcheck(self, tab, length, chal):
         r = co.sumcheck(_arr(tab)[:length], np.asarray(chal).reshape(-1, 4)) if length > 1 else None
         if length == 1:
