@@ -82,6 +82,9 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     }
     c->own_stream = true;
     for (auto& e : c->ev) hipEventCreate(&e);
+    for (auto& s2 : c->aux) hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    for (auto& e : c->ev_join) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     *out = c;
     return ZK_OK;
 }
@@ -93,6 +96,11 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         if (a.p) hipFree(a.p);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     for (auto& e : ctx->ev)
+        if (e) hipEventDestroy(e);
+    for (auto& s2 : ctx->aux)
+        if (s2) hipStreamDestroy(s2);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    for (auto& e : ctx->ev_join)
         if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -452,6 +452,7 @@ struct MsmClass {
     u32 T = 32, bpb = 0, nchunks = 0;
     unsigned P = 1;
     size_t pinned_off = 0;  // byte offset of this class's results in the pinned staging area
+    size_t off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets of this class inside the scratch arenas
 };
 
 static int quantised_window(int c) { return c <= 4 ? 4 : 4 + 3 * ((c - 4 + 2) / 3); }
@@ -461,7 +462,6 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
     static const u32 bpb_env = getenv("ZK_MSM_BPB") ? (u32)atoi(getenv("ZK_MSM_BPB")) : 0;
-    hipStream_t st = ctx->stream;
     // ---- validate + classify by window width ----
     std::vector<MsmClass> classes;
     for (size_t k = 0; k < count; k++) {
@@ -528,15 +528,14 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         cl.chunk_len = ((cl.row_len + cl.nchunks - 1) / cl.nchunks + 3) & ~(size_t)3;
         cl.nchunks = (u32)((cl.row_len + cl.chunk_len - 1) / cl.chunk_len);
         cl.cc_elems = cl.rows * cl.P * (size_t)cl.nchunks * cl.bpb;
-        need[0] = std::max(need[0], cl.rows * cl.row_len * 4);
-        need[1] = std::max(need[1], cl.rows * cl.row_len * 4);
-        need[2] = std::max(need[2], 2 * cl.total * 4);
-        need[3] = std::max(need[3], cl.total * 192);
-        need[4] = std::max(need[4], cl.total * 192);
-        need[5] = std::max(need[5], 2 * cl.total_tiles * 192);
-        need[6] = std::max(need[6], (cl.total_tiles / kLongSpan + 64 + 1) * 4);
-        need[7] = std::max(need[7], nitems * sizeof(ItemDesc));
-        need[8] = std::max(need[8], cl.cc_elems * 4);
+        // classes run concurrently on separate streams: each gets its own region of every arena
+        const size_t want_b[9] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4, cl.total * 192, cl.total * 192,
+                                  2 * cl.total_tiles * 192, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
+                                  cl.cc_elems * 4};
+        for (int i = 0; i < 9; i++) {
+            cl.off[i] = need[i];
+            need[i] += (want_b[i] + 255) & ~(size_t)255;
+        }
         cl.pinned_off = pinned_bytes;
         pinned_bytes += cl.rows * (size_t)cl.c * 192 + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
     }
@@ -552,22 +551,31 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 
-    // ---- enqueue every class back to back on the stream (no host synchronisation in between) ----
+    // ---- enqueue every class without host synchronisation; independent classes go to separate
+    // streams (the small ones are pure launch/latency chains and overlap with the big one) ----
     bool first = true;
+    const bool multi = classes.size() > 1;
+    if (multi) {
+        hipEventRecord(ctx->ev_fork, ctx->stream);
+        for (int k = 0; k < zk_ctx::kAux; k++) hipStreamWaitEvent(ctx->aux[k], ctx->ev_fork, 0);
+    }
+    size_t cls_i = 0;
     for (auto& cl : classes) {
         const int W = cl.L.W;
         const size_t nitems = cl.idx.size(), ns = cl.ns, nb = cl.nb, total = cl.total;
-        u32* digits = (u32*)buf[0];
-        u32* sorted = (u32*)buf[1];
-        u32* counts = (u32*)buf[2];
+        hipStream_t st = (!multi || cls_i == 0) ? ctx->stream : ctx->aux[(cls_i - 1) % zk_ctx::kAux];
+        cls_i++;
+        u32* digits = (u32*)((char*)buf[0] + cl.off[0]);
+        u32* sorted = (u32*)((char*)buf[1] + cl.off[1]);
+        u32* counts = (u32*)((char*)buf[2] + cl.off[2]);
         u32* offsets = counts + total;
-        void* bufA = buf[3];
-        void* bufB = buf[4];
-        void* heads = buf[5];
-        void* tails = (char*)buf[5] + cl.total_tiles * 192;
-        u32* longs = (u32*)buf[6];
-        ItemDesc* d_items = (ItemDesc*)buf[7];
-        u32* cc = (u32*)buf[8];
+        void* bufA = (char*)buf[3] + cl.off[3];
+        void* bufB = (char*)buf[4] + cl.off[4];
+        void* heads = (char*)buf[5] + cl.off[5];
+        void* tails = (char*)heads + cl.total_tiles * 192;
+        u32* longs = (u32*)((char*)buf[6] + cl.off[6]);
+        ItemDesc* d_items = (ItemDesc*)((char*)buf[7] + cl.off[7]);
+        u32* cc = (u32*)((char*)buf[8] + cl.off[8]);
         uint64_t* h_pts = (uint64_t*)(hpin + cl.pinned_off);
         ItemDesc* h_items = (ItemDesc*)(hpin + cl.pinned_off + cl.rows * (size_t)cl.c * 192);
         for (size_t j = 0; j < nitems; j++) {
@@ -620,7 +628,13 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         if (first) hipEventRecord(ctx->ev[3], st);
         first = false;
     }
-    ZK_HIP(ctx, hipStreamSynchronize(st));
+    if (multi) {  // join: later work on the ctx stream is ordered after every class
+        for (int k = 0; k < zk_ctx::kAux; k++) {
+            hipEventRecord(ctx->ev_join[k], ctx->aux[k]);
+            hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0);
+        }
+    }
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // ---- host combine: ~255 doublings per item, items in parallel threads ----
     auto t0 = std::chrono::steady_clock::now();
     struct Job {
