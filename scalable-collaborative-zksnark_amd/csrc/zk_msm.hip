@@ -117,10 +117,13 @@ __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ it
 static constexpr int kSortThreads = 1024;
 template <bool SCATTER>
 __global__ void __launch_bounds__(kSortThreads) k_sort_pass(const u32* __restrict__ digits, size_t row_len, size_t chunk_len,
-                                                          u32 nchunks, size_t nb, u32 bpb, u32* __restrict__ cc,
+                                                          u32 nchunks, size_t nb, u32 bpb, u32 P, u32* __restrict__ cc,
                                                           u32* __restrict__ sorted) {
     extern __shared__ u32 cnt[];
-    const u32 chunk = blockIdx.x, p = blockIdx.y, row = blockIdx.z, P = gridDim.y;
+    // grid.x = (row, bucket range), grid.y = chunk: blocks that scatter into the same output region get
+    // consecutive-by-8 linear ids, i.e. the same XCD (block b -> XCD b % 8), so their 4-byte stores
+    // merge into full lines in ONE L2 instead of partial lines in eight
+    const u32 chunk = blockIdx.y, p = blockIdx.x % P, row = blockIdx.x / P;
     const u32 lo = p * bpb;
     u32* glob = cc + (((size_t)row * P + p) * nchunks + chunk) * bpb;
     for (u32 i = threadIdx.x; i < bpb; i += kSortThreads) cnt[i] = SCATTER ? glob[i] : 0u;
@@ -590,15 +593,15 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
         hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, ns, cl.L, digits);
-        hipLaunchKernelGGL((k_sort_pass<false>), dim3(cl.nchunks, cl.P, (unsigned)cl.rows), dim3(kSortThreads), cl.bpb * 4, st,
-                           (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, cc, (u32*)nullptr);
+        hipLaunchKernelGGL((k_sort_pass<false>), dim3((unsigned)(cl.rows * cl.P), cl.nchunks), dim3(kSortThreads), cl.bpb * 4, st,
+                           (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, (u32)cl.P, cc, (u32*)nullptr);
         hipLaunchKernelGGL(k_bucket_totals, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)cc, cl.nchunks,
                            nb, cl.bpb, total, counts);
         hipLaunchKernelGGL(k_scan, dim3((unsigned)cl.rows), dim3(kScanThreads), 0, st, (const u32*)counts, nb, offsets);
         hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, cc, cl.nchunks, nb, cl.bpb,
                            total, (const u32*)offsets);
-        hipLaunchKernelGGL((k_sort_pass<true>), dim3(cl.nchunks, cl.P, (unsigned)cl.rows), dim3(kSortThreads), cl.bpb * 4, st,
-                           (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, cc, sorted);
+        hipLaunchKernelGGL((k_sort_pass<true>), dim3((unsigned)(cl.rows * cl.P), cl.nchunks), dim3(kSortThreads), cl.bpb * 4, st,
+                           (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, (u32)cl.P, cc, sorted);
         if (first) hipEventRecord(ctx->ev[1], st);
         hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const u32*)offsets, (const u32*)counts, cl.row_len,

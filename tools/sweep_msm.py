@@ -14,11 +14,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     for c in cs:
         ctx.msm_set_window(c)
         ctx.msm_g1(srs, sc, n)
-        ph = np.zeros(5); t0 = time.perf_counter(); R = 5
+        ph = np.zeros(6); t0 = time.perf_counter(); R = 5
         for _ in range(R):
             ctx.msm_g1(srs, sc, n); ph += ctx.msm_last_timing()
         dt = (time.perf_counter() - t0) / R
-        print(f"  log2n={log2n} c={c} T={os.environ.get('ZK_MSM_TILE','-')} bpb={os.environ.get('ZK_MSM_BPB','-')}: {dt*1e3:7.3f} ms  sort={ph[0]/R:.3f} acc={ph[1]/R:.3f} red={ph[2]/R:.3f} host={ph[3]/R:.3f}", flush=True)
+        print(f"  log2n={log2n} c={c} T={os.environ.get('ZK_MSM_TILE','-')} bpb={os.environ.get('ZK_MSM_BPB','-')}: {dt*1e3:7.3f} ms  sort={ph[0]/R:.3f} acc={ph[1]/R:.3f} fix={ph[2]/R:.3f} red={ph[3]/R:.3f} host={ph[4]/R:.3f}", flush=True)
 else:
     for log2n, cs in ((20, "13,14,15,16"),):
         for T in ("32", "64"):
