@@ -72,6 +72,14 @@ int zk_fr_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t
 /* out[i] = a[i] + alpha*b[i] + beta          (`s + alpha*sid + beta`, dhyperplonk.rs:326-337) */
 int zk_fr_axpb(zk_ctx *ctx, const void *d_a, const void *d_b, const uint64_t h_alpha[4],
                const uint64_t h_beta[4], void *d_out, size_t n);
+/* A small PUBLIC Fr matrix applied to k vectors at once -- the PSS maps on field elements
+ * (pack_from_public / unpack / unpack2, secret-sharing/src/pss.rs:93-171; degree reduction
+ * degree_reduce.rs:17-23) for any packing factor l:
+ *   out[j*out_vec_stride + r*out_row_stride] = sum_c M[r*cols + c] * in[j*in_vec_stride + c*in_comp_stride]
+ * strides in elements; h_matrix = rows*cols Fr (Montgomery) on the host. */
+int zk_fr_apply_matrix(zk_ctx *ctx, const uint64_t *h_matrix, size_t rows, size_t cols, const void *d_in,
+                       size_t in_vec_stride, size_t in_comp_stride, void *d_out, size_t out_vec_stride,
+                       size_t out_row_stride, size_t k);
 /* strided views of the product tree (dacc_product.rs:41-55, dhyperplonk.rs:344-359):
  * even[i] = t[2i] (v(x,0)), odd[i] = t[2i+1] (v(x,1)), i < n; v(1,x) is the contiguous upper half. */
 int zk_fr_deinterleave(zk_ctx *ctx, const void *d_t, void *d_even, void *d_odd, size_t n);

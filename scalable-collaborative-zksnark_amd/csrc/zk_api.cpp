@@ -172,6 +172,11 @@ int zk_fr_axpb(zk_ctx* ctx, const void* a, const void* b, const uint64_t alpha[4
     NEED(ctx, alpha && beta && (n == 0 || (a && b && out)));
     return fr_axpb(ctx, a, b, alpha, beta, out, n);
 }
+int zk_fr_apply_matrix(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_t cols, const void* d_in, size_t in_vec_stride,
+                       size_t in_comp_stride, void* d_out, size_t out_vec_stride, size_t out_row_stride, size_t k) {
+    NEED(ctx, k == 0 || rows == 0 || (h_matrix && d_in && d_out));
+    return fr_apply_matrix(ctx, h_matrix, rows, cols, d_in, in_vec_stride, in_comp_stride, d_out, out_vec_stride, out_row_stride, k);
+}
 int zk_fr_deinterleave(zk_ctx* ctx, const void* d_t, void* d_even, void* d_odd, size_t n) {
     NEED(ctx, n == 0 || (d_t && d_even && d_odd));
     return fr_deinterleave(ctx, d_t, d_even, d_odd, n);

@@ -450,6 +450,22 @@ __global__ void __launch_bounds__(kBlock) k_fp_binary(const void* __restrict__ a
     }
 }
 
+// K9 on Fr: a small PUBLIC matrix (PSS pack / unpack / unpack2 / degree-reduction maps,
+// secret-sharing/src/pss.rs:93-171, degree_reduce.rs:17-23) applied to k vectors at once:
+//   out[j*osv + r*osr] = sum_c M[r][c] * in[j*isv + c*isc]        (strides in elements)
+// One lane per output element; the matrix (rows*cols*32 B) is read through L2.
+__global__ void __launch_bounds__(kBlock) k_fr_apply_matrix(const void* __restrict__ M, size_t rows, size_t cols,
+                                                          const void* __restrict__ in, size_t isv, size_t isc,
+                                                          void* __restrict__ out, size_t osv, size_t osr, size_t k) {
+    const size_t total = k * rows;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t r = t / k, j = t % k;  // consecutive lanes -> consecutive vectors of the same row
+        Fr acc = fp_zero<FrCfg>();
+        for (size_t c = 0; c < cols; c++) acc = fr_add(acc, fr_mul(fr_load(M, r * cols + c), fr_load(in, j * isv + c * isc)));
+        fr_store(out, j * osv + r * osr, acc);
+    }
+}
+
 // K7 strided splits (dacc_product.rs:41-55, dhyperplonk.rs:344-359): even[i] = t[2i], odd[i] = t[2i+1]
 __global__ void __launch_bounds__(kBlock) k_fr_deinterleave(const void* __restrict__ t, void* __restrict__ even,
                                                           void* __restrict__ odd, size_t n) {
@@ -483,6 +499,19 @@ int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t 
     if (op == 0) hipLaunchKernelGGL((k_fp_binary<FqCfg, 0>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
     else if (op == 1) hipLaunchKernelGGL((k_fp_binary<FqCfg, 1>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
     else hipLaunchKernelGGL((k_fp_binary<FqCfg, 2>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+int fr_apply_matrix(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_t cols, const void* d_in, size_t isv, size_t isc,
+                    void* d_out, size_t osv, size_t osr, size_t k) {
+    if (k == 0 || rows == 0) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    void* d_m = scratch(ctx, 10, rows * cols * 32);
+    if (!d_m) return ZK_ERR_OOM;
+    ZK_HIP(ctx, hipMemcpyAsync(d_m, h_matrix, rows * cols * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_matrix is caller memory (pageable)
+    hipLaunchKernelGGL(k_fr_apply_matrix, dim3(grid_for(ctx, k * rows)), dim3(kBlock), 0, ctx->stream, (const void*)d_m, rows, cols,
+                       d_in, isv, isc, d_out, osv, osr, k);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }

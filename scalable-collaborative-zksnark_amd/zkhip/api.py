@@ -168,6 +168,15 @@ class Ctx:
     def fr_mul(self, a, b, n, out=None):
         return self._binary(self.lib.zk_fr_mul, a, b, n, out)
 
+    def fr_apply_matrix(self, matrix: np.ndarray, d_in, in_vec_stride: int, in_comp_stride: int, k: int, out_vec_stride: int, out_row_stride: int, out=None):
+        """out[j*osv + r*osr] = sum_c M[r][c] * in[j*isv + c*isc]; matrix [rows, cols, 4] Montgomery limbs"""
+        m = np.ascontiguousarray(matrix, dtype=np.uint64)
+        rows, cols = m.shape[0], m.shape[1]
+        span = (k - 1) * out_vec_stride + (rows - 1) * out_row_stride + 1 if k and rows else 1
+        out = out or self.alloc(32 * span)
+        self._check(self.lib.zk_fr_apply_matrix(self.h, _h(m), rows, cols, _ptr(d_in), in_vec_stride, in_comp_stride, _ptr(out), out_vec_stride, out_row_stride, k))
+        return out
+
     def fr_deinterleave(self, t, n):
         """(t[0::2], t[1::2]) for a table of 2n Fr -> two device buffers of n Fr"""
         even, odd = self.alloc(max(32 * n, 1)), self.alloc(max(32 * n, 1))

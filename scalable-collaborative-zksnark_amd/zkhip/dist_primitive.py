@@ -305,6 +305,21 @@ def d_fix_variable(be, shares, length: int, points: np.ndarray, pp: PackedSharin
     return _ints_to_fr([cur[0]])
 
 
+def _mont_matrix(rows: Sequence[Sequence[int]]) -> np.ndarray:
+    """python-int matrix -> [rows, cols, 4] Montgomery limbs for zk_fr_apply_matrix"""
+    return np.array([[fr_mont(v) for v in r] for r in rows], dtype=np.uint64).reshape(len(rows), -1, 4)
+
+
+def _unpack2_many_device(be, gathered: Sequence[np.ndarray], pp: PackedSharingParams) -> np.ndarray:
+    """gathered[i] = party i's [k,4] vector -> transpose(.).flat_map(unpack2): [k*l, 4] (unpack.rs:55-70)"""
+    k = len(gathered[0])
+    if k == 0:
+        return np.zeros((0, 4), dtype=np.uint64)
+    d_in = be.to_device(np.concatenate([np.asarray(g, dtype=np.uint64).reshape(-1, 4) for g in gathered]))  # [n][k]
+    out = be.fr_apply_matrix(_mont_matrix(pp.unpack2_matrix), d_in, 1, k, k, pp.l, 1)  # out[j*l + r]
+    return out.download((k * pp.l, 4))
+
+
 # ---------------------------------------------------------------------------------------
 # small exchanges: degree reduction and unpacking (degree_reduce.rs, unpack.rs)
 # ---------------------------------------------------------------------------------------
@@ -316,21 +331,21 @@ def _apply_rows(rows: Sequence[Sequence[int]], columns: Sequence[np.ndarray]) ->
     return np.stack([_ints_to_fr(o) for o in out]) if k else np.zeros((len(rows), 0, 4), dtype=np.uint64)
 
 
-def degree_reduce_many(shares: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
-    """degree_reduce.rs:10-26: element-wise pack_from_public(unpack2(.))[party] over the batch ([k,4] -> [k,4])"""
+def degree_reduce_many(shares: np.ndarray, pp: PackedSharingParams, net: Net, be=None) -> np.ndarray:
+    """
+    degree_reduce.rs:10-26: element-wise pack_from_public(unpack2(.))[party] over the batch ([k,4] -> [k,4]).
+    The composite D = pack o unpack2 is one public n x n matrix; this party needs only its row.
+    With a backend the row is applied on the GPU (zk_fr_apply_matrix), otherwise with host big-ints.
+    """
     shares = np.asarray(shares, dtype=np.uint64).reshape(-1, 4)
     allp = net.all_gather(shares)
-    # D = pack o unpack2 restricted to this party's row: out = sum_i D[p][i] * v_i
-    p, l = net.party_id, pp.l
-    if l == 1:
-        row = [pp.pack_matrix[p][0] * pp.unpack2_matrix[0][i] % R_MOD for i in range(pp.n)]
-        return _apply_rows([row], allp)[0]
-    # general l: the batch is processed per element exactly as the reference does (vector per item)
-    cols = [_fr_vec_to_ints(a) for a in allp]
-    out = []
-    for k in range(len(shares)):
-        out.append(pp.pack_from_public(pp.unpack2([cols[i][k] for i in range(pp.n)]))[p])
-    return _ints_to_fr(out)
+    p, l, n = net.party_id, pp.l, pp.n
+    row = [sum(pp.pack_matrix[p][j] * pp.unpack2_matrix[j][i] for j in range(l)) % R_MOD for i in range(n)]
+    k = len(shares)
+    if be is not None and k:
+        d_in = be.to_device(np.concatenate(allp))  # [n][k]
+        return be.fr_apply_matrix(_mont_matrix([row]), d_in, 1, k, k, 1, k).download((k, 4))
+    return _apply_rows([row], allp)[0]
 
 
 def degree_reduce(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
@@ -361,12 +376,14 @@ def d_unpack2(share: np.ndarray, receiver: int, pp: PackedSharingParams, net: Ne
     return _ints_to_fr(pp.unpack2(_fr_vec_to_ints(np.stack(vals))))
 
 
-def d_unpack2_many(share: np.ndarray, receiver: int, pp: PackedSharingParams, net: Net) -> np.ndarray:
+def d_unpack2_many(share: np.ndarray, receiver: int, pp: PackedSharingParams, net: Net, be=None) -> np.ndarray:
     """unpack.rs:55-70: receiver gets transpose(shares).flat_map(unpack2) = [k*l, 4]"""
     share = np.asarray(share, dtype=np.uint64).reshape(-1, 4)
     allp = net.all_gather(share)
     if net.party_id != receiver:
         return np.zeros((0, 4), dtype=np.uint64)
+    if be is not None:
+        return _unpack2_many_device(be, allp, pp)
     cols = [_fr_vec_to_ints(a) for a in allp]
     out = []
     for k in range(len(share)):
@@ -421,20 +438,19 @@ def merge(results: Sequence[np.ndarray]) -> np.ndarray:
 def _pack_chunks(be, vals: np.ndarray, pp: PackedSharingParams) -> List[np.ndarray]:
     """
     `vals.chunks(l).map(pack_from_public)` transposed: out[p] = party p's share of every chunk.
-    l = 1: share_p = c_p * x -- one scalar multiplication of the whole vector per party, on the GPU.
+    One application of the n x l public pack matrix to all chunks on the GPU (any l; a short last
+    chunk is zero-padded exactly as pack_from_public pads).
     """
     vals = np.asarray(vals, dtype=np.uint64).reshape(-1, 4)
     if len(vals) == 0:
         return [np.zeros((0, 4), dtype=np.uint64) for _ in range(pp.n)]
-    if pp.l == 1:
-        k = len(vals)
-        d_v = be.to_device(vals)
-        d_z = be.to_device(np.zeros((k, 4), dtype=np.uint64))
-        zero = fr_mont(0)
-        return [be.fr_axpb(d_z, d_v, fr_mont(pp.pack_matrix[p][0]), zero, k).download((k, 4)) for p in range(pp.n)]
-    ints = _fr_vec_to_ints(vals)
-    packed = [pp.pack_from_public(ints[i : i + pp.l]) for i in range(0, len(ints), pp.l)]
-    return [_ints_to_fr([c[p] for c in packed]) for p in range(pp.n)]
+    l = pp.l
+    k = (len(vals) + l - 1) // l
+    if len(vals) != k * l:
+        vals = np.concatenate([vals, np.zeros((k * l - len(vals), 4), dtype=np.uint64)])
+    m = _mont_matrix([row[:l] for row in pp.pack_matrix])  # [n, l]
+    out = be.fr_apply_matrix(m, be.to_device(vals), l, 1, k, 1, k).download((pp.n * k, 4))  # out[p*k + j]
+    return [np.ascontiguousarray(out[p * k : (p + 1) * k]) for p in range(pp.n)]
 
 
 def c_acc_product_and_share(be, shares, masks, unmask0, unmask1, unmask2, S: int, pp: PackedSharingParams, net: Net):
@@ -450,12 +466,9 @@ def c_acc_product_and_share(be, shares, masks, unmask0, unmask1, unmask2, S: int
     masked = be.fr_mul(shares, masks, S).download((S, 4))  # :88-92
     # every party receives everyone's i-th block and unpack2s it element-wise (:94-104)
     recv = net.all_to_all([np.ascontiguousarray(masked[i * bs : (i + 1) * bs]) for i in range(N)], echo="slot0")
-    cols = [_fr_vec_to_ints(r) for r in recv]
-    mx = []
-    for k in range(bs):
-        mx.extend(pp.unpack2([cols[p][k] for p in range(N)]))
+    mx = _unpack2_many_device(be, recv, pp)
     mlen = len(mx)
-    subtree, leader_tree = c_acc_product(be, be.to_device(_ints_to_fr(mx)), mlen, pp, net)
+    subtree, leader_tree = c_acc_product(be, be.to_device(mx), mlen, pp, net)
     st = subtree.download((2 * mlen, 4))
     num_to_send = min(N, 2 * mlen)
     to_share = st[: 2 * mlen - num_to_send]
@@ -483,5 +496,5 @@ def c_acc_product_and_share(be, shares, masks, unmask0, unmask1, unmask2, S: int
         k = len(full)
         res.append(be.fr_mul(be.to_device(full), um, k).download((k, 4)))  # unmask (:266-275)
     for r in res:  # :278-285 -- communication only; the results are dropped by the reference too
-        degree_reduce_many(r[: len(r) // N * 2], pp, net)
+        degree_reduce_many(r[: len(r) // N * 2], pp, net, be)
     return tuple(res)

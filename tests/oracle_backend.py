@@ -113,6 +113,20 @@ class OracleBackend:
     def fr_batch_div(self, num, den, n, out=None):
         return NumpyBuf(co.fr_div(_arr(num)[:n], _arr(den)[:n]))
 
+    def fr_apply_matrix(self, matrix, d_in, in_vec_stride, in_comp_stride, k, out_vec_stride, out_row_stride, out=None):
+        m = np.asarray(matrix, dtype=np.uint64)
+        rows, cols = m.shape[0], m.shape[1]
+        src = _arr(d_in)
+        span = (k - 1) * out_vec_stride + (rows - 1) * out_row_stride + 1 if k and rows else 1
+        res = np.zeros((span, 4), dtype=np.uint64)
+        for r in range(rows):
+            acc = np.zeros((k, 4), dtype=np.uint64)
+            for c in range(cols):
+                col = src[c * in_comp_stride : c * in_comp_stride + (k - 1) * in_vec_stride + 1 : in_vec_stride]
+                acc = co.fr_add(acc, co.fr_mul(np.tile(m[r, c].reshape(1, 4), (k, 1)), np.ascontiguousarray(col)))
+            res[r * out_row_stride : r * out_row_stride + (k - 1) * out_vec_stride + 1 : out_vec_stride] = acc
+        return NumpyBuf(res)
+
     def fr_deinterleave(self, t, n):
         a = _arr(t)[: 2 * n]
         return NumpyBuf(a[0::2].copy()), NumpyBuf(a[1::2].copy())

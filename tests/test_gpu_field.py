@@ -98,3 +98,33 @@ def test_g1_group_law(ctx, co):
         got = ctx.dbg_g1_op(mode, dP, dQ, n)
         for i in range(n):
             assert (jac_norm_to_affine(got[i]) == ref(mode, P[i], Q[i])).all(), (mode, i)
+
+
+def test_fr_apply_matrix_pss_maps(ctx, co):
+    """zk_fr_apply_matrix == pack_from_public / unpack2 on chunks, for l = 1, 2, 4 (pss.rs:93-171)"""
+    import pyoracle as po
+    from zkhip.dist_primitive import _mont_matrix, _pack_chunks, _unpack2_many_device
+    from zkhip.pss import PackedSharingParams
+
+    for l in (1, 2, 4):
+        pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+        rng = po.SplitMix64(30 + l)
+        k = 37
+        vals = rng.fr_vec(k * l - (1 if l > 1 else 0))  # a short last chunk is zero-padded
+        vm = np.array([po.fr_to_mont_limbs(v) for v in vals], dtype=np.uint64)
+        got = _pack_chunks(ctx, vm, pp)
+        exp = po.transpose([opp.pack_from_public(vals[i : i + l]) for i in range(0, len(vals), l)])
+        for p in range(pp.n):
+            assert [po.fr_from_mont_limbs(x) for x in got[p]] == exp[p], (l, p)
+        shares = [rng.fr_vec(k) for _ in range(pp.n)]
+        sm = [np.array([po.fr_to_mont_limbs(v) for v in s], dtype=np.uint64) for s in shares]
+        got = _unpack2_many_device(ctx, sm, pp)
+        exp = [v for j in range(k) for v in opp.unpack2([shares[i][j] for i in range(pp.n)])]
+        assert [po.fr_from_mont_limbs(x) for x in got] == exp, l
+
+
+def test_fr_deinterleave(ctx):
+    n = 3001
+    t = rand_fr(2 * n, 77)
+    ev, od = ctx.fr_deinterleave(ctx.to_device(t), n)
+    assert (ev.download((n, 4)) == t[0::2]).all() and (od.download((n, 4)) == t[1::2]).all()
