@@ -32,19 +32,19 @@ struct ChalArgs {
 // lds: NS * 256 Fr.  Result for sum s is returned to the thread with (tid == 32*s) ... see use.
 // ---------------------------------------------------------------------------------------
 template <int NS>
-__device__ __forceinline__ void block_reduce_sums(Fr (&acc)[NS], uint4* lds, Fr& result, bool& has_result, int& which) {
-    static_assert(NS <= 8, "one 32-lane group per sum");
+__device__ __forceinline__ void block_reduce_store(Fr (&acc)[NS], uint4* lds, void* dst, size_t base, size_t stride) {
+    // sum s of the block is written to dst[base + s*stride].  8 groups of 32 lanes; group g owns
+    // sums g, g+8, ...: 8 strided LDS loads per lane, then a 32-lane shuffle reduction.
+    static_assert(NS <= 16, "two sums per 32-lane group at most");
     const int tid = threadIdx.x;
 #pragma unroll
     for (int s = 0; s < NS; s++) fr_store(lds, (size_t)s * kBlock + tid, acc[s]);
     __syncthreads();
     const int grp = tid >> 5, l32 = tid & 31;
-    has_result = false;
-    which = grp;
-    if (grp < NS) {
-        Fr v = fr_load(lds, (size_t)grp * kBlock + l32);
+    for (int s = grp; s < NS; s += 8) {
+        Fr v = fr_load(lds, (size_t)s * kBlock + l32);
 #pragma unroll
-        for (int i = 1; i < 8; i++) v = fr_add(v, fr_load(lds, (size_t)grp * kBlock + l32 + 32 * i));
+        for (int i = 1; i < 8; i++) v = fr_add(v, fr_load(lds, (size_t)s * kBlock + l32 + 32 * i));
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) {
             Fr o;
@@ -52,8 +52,7 @@ __device__ __forceinline__ void block_reduce_sums(Fr (&acc)[NS], uint4* lds, Fr&
             for (int k = 0; k < 8; k++) o.l[k] = __shfl_down(v.l[k], off, 32);
             v = fr_add(v, o);
         }
-        result = v;
-        has_result = (l32 == 0);
+        if (l32 == 0) fr_store(dst, base + (size_t)s * stride, v);
     }
     __syncthreads();
 }
@@ -92,7 +91,7 @@ struct ModeTraits {
 // partials layout: [(rd*W + w) * gridDim.x + blockIdx.x]
 // ---------------------------------------------------------------------------------------
 template <int K, int MODE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, (K == 3 && MODE == 1) ? 1 : 2))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
                                                void* __restrict__ go, size_t m, ChalArgs ch, void* __restrict__ partials,
                                                void* __restrict__ qbase) {
     constexpr int W = ModeTraits<MODE>::W;
@@ -134,13 +133,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
         fr_store(fo, j, ef[0]);
         if (TWO) fr_store(go, j, eg[0]);
     }
-    if (W != 0) {
-        Fr res;
-        bool has;
-        int which;
-        block_reduce_sums<NS>(acc, lds, res, has, which);
-        if (has) fr_store(partials, (size_t)which * gridDim.x + blockIdx.x, res);
-    }
+    if (W != 0) block_reduce_store<NS>(acc, lds, partials, blockIdx.x, gridDim.x);
 }
 
 // sums partials[s][0..nb) -> out[s]; one block per s
@@ -150,11 +143,7 @@ __global__ void __launch_bounds__(kBlock) k_reduce_partials(const void* __restri
     Fr acc[1];
     acc[0] = fp_zero<FrCfg>();
     for (size_t i = threadIdx.x; i < nb; i += kBlock) acc[0] = fr_add(acc[0], fr_load(partials, (size_t)s * nb + i));
-    Fr res;
-    bool has;
-    int which;
-    block_reduce_sums<1>(acc, lds, res, has, which);
-    if (has) fr_store(out, s, res);
+    block_reduce_store<1>(acc, lds, out, s, 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -166,52 +155,106 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_tail(const void* __restrict__ f, const void* __restrict__ g, size_t m, int rounds,
                                                const void* __restrict__ chal, void* __restrict__ sums_out,
                                                void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go) {
+    // One barrier per round: the per-lane partial sums of every round are parked in LDS and ALL
+    // rounds are reduced together at the end (the sums of round i are not an input of round i+1).
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     constexpr int NS = (W == 0) ? 1 : W;
     extern __shared__ uint4 lds[];
     uint4* tf = lds;
-    uint4* tg = lds + 2 * m;                    // 2 uint4 per Fr
-    uint4* red = lds + (TWO ? 4 : 2) * m;       // NS*256 Fr reduction area
+    uint4* tg = lds + 2 * m;                 // 2 uint4 per Fr
+    uint4* part = lds + (TWO ? 4 : 2) * m;   // parked partial sums
     const int tid = threadIdx.x;
     for (size_t i = tid; i < m; i += kBlock) {
         fr_store(tf, i, fr_load(f, i));
         if (TWO) fr_store(tg, i, fr_load(g, i));
     }
     __syncthreads();
-    size_t qoff = 0;
+    size_t qoff = 0, poff = 0;
+    size_t mm = m;
     for (int rd = 0; rd < rounds; rd++) {
-        const size_t h = m >> 1;
+        const size_t h = mm >> 1;
+        const size_t cnt = h < (size_t)kBlock ? h : (size_t)kBlock;
         const Fr r = fr_load(chal, rd);
         Fr acc[NS];
 #pragma unroll
         for (int s = 0; s < NS; s++) acc[s] = fp_zero<FrCfg>();
-        for (size_t j = tid; j < h; j += kBlock) {
-            Fr flo = fr_load(tf, j), fhi = fr_load(tf, j + h), glo, ghi, qv;
-            if (TWO) {
-                glo = fr_load(tg, j);
-                ghi = fr_load(tg, j + h);
+        if (MODE == 1 && 3 * h <= (size_t)kBlock) {
+            // late rounds: more lanes than pairs -> three lanes per pair, two dependent multiplications
+            // per lane instead of five (the round time is the latency of that chain)
+            const size_t role = (size_t)tid / h, j = (size_t)tid % h;
+            Fr nf, ng;
+            bool wf = false, wg = false;
+            if (role < 3) {
+                Fr flo = fr_load(tf, j), fhi = fr_load(tf, j + h), glo = fr_load(tg, j), ghi = fr_load(tg, j + h);
+                Fr df = fr_sub(fhi, flo), dg = fr_sub(ghi, glo);
+                if (role == 0) {
+                    acc[0] = fr_mul(flo, glo);
+                    nf = fr_add(flo, fr_mul(r, df));
+                    wf = true;
+                } else if (role == 1) {
+                    acc[0] = fr_mul(fhi, ghi);
+                    ng = fr_add(glo, fr_mul(r, dg));
+                    wg = true;
+                } else {
+                    acc[0] = fr_mul(fr_add(fhi, df), fr_add(ghi, dg));
+                }
             }
-            round_pair<MODE>(flo, fhi, glo, ghi, r, acc, qv);
-            if (MODE == 3) fr_store(qbase, qoff + j, qv);
-            fr_store(tf, j, flo);
-            if (TWO) fr_store(tg, j, glo);
-        }
-        if (W != 0) {
-            Fr res;
-            bool has;
-            int which;
-            block_reduce_sums<NS>(acc, red, res, has, which);  // contains the barriers
-            if (has) fr_store(sums_out, (size_t)rd * W + which, res);
+            __syncthreads();  // every lane has read its operands before anyone overwrites the tables
+            if (wf) fr_store(tf, j, nf);
+            if (wg) fr_store(tg, j, ng);
+            if (role < 3) fr_store(part, poff + role * cnt + j, acc[0]);  // cnt == h here
+            __syncthreads();
         } else {
+            for (size_t j = tid; j < h; j += kBlock) {
+                Fr flo = fr_load(tf, j), fhi = fr_load(tf, j + h), glo, ghi, qv;
+                if (TWO) {
+                    glo = fr_load(tg, j);
+                    ghi = fr_load(tg, j + h);
+                }
+                round_pair<MODE>(flo, fhi, glo, ghi, r, acc, qv);
+                if (MODE == 3) fr_store(qbase, qoff + j, qv);
+                fr_store(tf, j, flo);
+                if (TWO) fr_store(tg, j, glo);
+            }
+            if (W != 0 && (size_t)tid < cnt) {
+#pragma unroll
+                for (int w = 0; w < NS; w++) fr_store(part, poff + (size_t)w * cnt + tid, acc[w]);
+            }
             __syncthreads();
         }
         qoff += h;
-        m = h;
+        poff += cnt * W;
+        mm = h;
     }
-    for (size_t i = tid; i < m; i += kBlock) {
+    for (size_t i = tid; i < mm; i += kBlock) {
         fr_store(fo, i, fr_load(tf, i));
         if (TWO) fr_store(go, i, fr_load(tg, i));
+    }
+    if (W != 0) {
+        // reduce every (round, w) vector of parked partials: 8 groups of 32 lanes
+        const int grp = tid >> 5, l32 = tid & 31;
+        size_t off = 0, m2 = m;
+        for (int rd = 0; rd < rounds; rd++) {
+            const size_t h = m2 >> 1;
+            const size_t cnt = h < (size_t)kBlock ? h : (size_t)kBlock;
+            for (int w = 0; w < W; w++) {
+                if (((rd * W + w) & 7) == grp) {  // wave-uniform per 32-lane group
+                    Fr v = fp_zero<FrCfg>();
+                    for (size_t t = l32; t < cnt; t += 32) v = fr_add(v, fr_load(part, off + (size_t)w * cnt + t));
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) {
+                        Fr x;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) x.l[k] = __shfl_down(v.l[k], o, 32);
+                        v = fr_add(v, x);
+                    }
+                    if (l32 == 0) fr_store(sums_out, (size_t)rd * W + w, v);
+                }
+            }
+            off += cnt * W;
+            m2 = h;
+        }
     }
 }
 
@@ -242,6 +285,7 @@ static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void
         if (!partials) return ZK_ERR_OOM;
         lds = (size_t)K * W * kBlock * 32;
     }
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_pass<K, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
                        qbase);
     if (W != 0)
@@ -256,7 +300,9 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
                     uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
-    constexpr int KMAX = (MODE == 0 || MODE == 2) ? 3 : 2;
+    constexpr int KMAX = 3;
+    // tail capacity: tables + parked partial sums must fit the CU's 160 KiB of LDS
+    const size_t tail_max = TWO ? 1024 : kTailMax;
     const size_t fr = 32;
     // result block on device: [sums rounds*W][last_f][last_g]
     const size_t res_elems = rounds * W + 2;
@@ -274,7 +320,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     size_t m = len, done = 0;
     int flip = 0;
     void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (len > kTailMax && rounds > 0) {
+    if (len > tail_max && rounds > 0) {
         bufs[0] = scratch(ctx, 0, (len / 2) * fr);
         bufs[1] = scratch(ctx, 1, (len / 4) * fr);
         if (!bufs[0] || !bufs[1]) return ZK_ERR_OOM;
@@ -284,15 +330,16 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
             if (!bufs[2] || !bufs[3]) return ZK_ERR_OOM;
         }
     }
-    while (done < rounds && m > kTailMax) {
-        int k = (int)std::min<size_t>({(size_t)KMAX, rounds - done, (size_t)(ilog2(m) - ilog2(kTailMax))});
+    while (done < rounds && m > tail_max) {
+        const size_t kcap = (MODE == 1) ? 2 : KMAX;  // measured: K = 3 product passes (35 dependent muls per lane) are no faster than K = 2
+        int k = (int)std::min<size_t>({kcap, rounds - done, (size_t)(ilog2(m) - ilog2(tail_max))});
         const bool final_out = (MODE == 2) && (done + k == rounds);
         void* fo = final_out ? d_out : bufs[flip];
         void* go = TWO ? bufs[2 + flip] : nullptr;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
         void* sums_at = d_res + done * W * fr;
         int rc;
-        if (k == 3) rc = launch_pass<(KMAX >= 3 ? 3 : 1), MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
+        if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
         else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
         else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
         if (rc) return rc;
@@ -305,8 +352,10 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     if (done < rounds || MODE != 2) {
         // tail: the remaining rounds (possibly zero) in one workgroup; also emits the final table
         const int rl = (int)(rounds - done);
-        if (m > kTailMax) return fail(ctx, ZK_ERR_INVALID, "internal: tail too large");
-        size_t lds = (TWO ? 2 : 1) * m * fr + (size_t)(W ? W : 1) * kBlock * fr;
+        if (m > tail_max) return fail(ctx, ZK_ERR_INVALID, "internal: tail too large");
+        size_t parked = 0;  // sum over rounds of W * min(h, 256) partials
+        for (size_t mm = m, r2 = 0; r2 < (size_t)rl; r2++, mm >>= 1) parked += (size_t)W * std::min<size_t>(mm >> 1, kBlock);
+        size_t lds = (TWO ? 2 : 1) * m * fr + std::max<size_t>(parked, 1) * fr;
         void* fo = (MODE == 2) ? d_out : d_last_f;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
         static bool attr_set = false;
