@@ -42,21 +42,41 @@ def pss2ss(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
 # ---------------------------------------------------------------------------------------
 # d_msm (dmsm.rs:9-43)
 # ---------------------------------------------------------------------------------------
-def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net) -> np.ndarray:
+def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net, prescale: bool = True) -> np.ndarray:
     """
     bases[k]: Srs (device-resident level), scalars[k]: device buffer of lens[k] Fr shares.
     Returns this party's share of every MSM result: [batch, 18] normalised Jacobian.
     Local: G::msm per batch item (dmsm.rs:19-24).  Exchange: the leader closure
-    unpack2 -> sum -> pack_from_public([sum; l]) (:29-40) is a public linear map, applied by
-    every party to the all-gathered results for its own slot.
+    unpack2 -> sum -> pack_from_public([sum; l]) (:29-40) is the public linear map
+        out_p = c_p * sum_i lambda_i * C_i,   lambda_i = sum_j unpack2[j][i],  c_p = sum_j pack[p][j].
+    prescale=True folds lambda_p into this party's SCALARS before its MSM (one element-wise Fr
+    multiplication on the GPU: MSM(b, lambda*s) = lambda*MSM(b, s)), so the exchange is an
+    all-gather, 7 point additions and ONE scalar multiplication by c_p instead of an 8-term
+    255-bit combination on the host.  Same group element, hence the same output bits.
     """
     assert len(bases) == len(scalars) == len(lens)  # dmsm.rs:16
-    c_shares = be.msm_g1_batch(list(bases), list(scalars), list(lens))  # one pipeline pass for the whole batch
-    gathered = net.all_gather(c_shares)  # [party][batch,18]
-    coeff = np.array([int_to_limbs(c, 4) for c in pp.dmsm_coeffs(net.party_id)], dtype=np.uint64)
     if not len(lens):
-        return c_shares
-    return be.g1_lincomb_batch(np.stack([np.stack([gathered[p][k] for p in range(net.n_parties)]) for k in range(len(lens))]), coeff)
+        return np.zeros((0, 18), dtype=np.uint64)
+    p, n = net.party_id, net.n_parties
+    # the no-`comm` echo net fabricates the other parties' messages from the local one, so the map must
+    # be applied exactly where the reference applies it
+    if not prescale or getattr(net, "echo", False):
+        c_shares = be.msm_g1_batch(list(bases), list(scalars), list(lens))  # one pipeline pass for the whole batch
+        gathered = net.all_gather(c_shares)  # [party][batch,18]
+        coeff = np.array([int_to_limbs(c, 4) for c in pp.dmsm_coeffs(p)], dtype=np.uint64)
+        return be.g1_lincomb_batch(np.stack([np.stack([gathered[q][k] for q in range(n)]) for k in range(len(lens))]), coeff)
+    lam = sum(pp.unpack2_matrix[j][p] for j in range(pp.l)) % R_MOD
+    c_p = sum(pp.pack_matrix[p][j] for j in range(pp.l)) % R_MOD
+    zero = fr_mont(0)
+    scaled = []
+    for s, m in zip(scalars, lens):
+        z = be.to_device(np.zeros((max(m, 1), 4), dtype=np.uint64)) if not hasattr(be, "zeros") else be.zeros(m)
+        scaled.append(be.fr_axpb(z, s, fr_mont(lam), zero, m))
+    c_shares = be.msm_g1_batch(list(bases), scaled, list(lens))
+    gathered = net.all_gather(c_shares)
+    ones = np.tile(int_to_limbs(1, 4), (n, 1))
+    sums = be.g1_lincomb_batch(np.stack([np.stack([gathered[q][k] for q in range(n)]) for k in range(len(lens))]), ones)
+    return be.g1_lincomb_batch(sums.reshape(len(lens), 1, 18), np.array([int_to_limbs(c_p, 4)], dtype=np.uint64))
 
 
 # ---------------------------------------------------------------------------------------

@@ -59,6 +59,8 @@ class Net:
 
 
 class LeaderEchoNet(Net):
+    echo = True
+
     def __init__(self, n_parties: int = 8):
         self.n_parties, self.party_id = n_parties, 0
 
