@@ -69,7 +69,8 @@ int zk_memcpy_d2h(zk_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int zk_fr_add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
 int zk_fr_sub(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
 int zk_fr_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
-/* out[i] = a[i] + alpha*b[i] + beta          (`s + alpha*sid + beta`, dhyperplonk.rs:326-337) */
+/* out[i] = a[i] + alpha*b[i] + beta          (`s + alpha*sid + beta`, dhyperplonk.rs:326-337);
+ * d_a may be NULL (taken as zero): out = alpha*b + beta */
 int zk_fr_axpb(zk_ctx *ctx, const void *d_a, const void *d_b, const uint64_t h_alpha[4],
                const uint64_t h_beta[4], void *d_out, size_t n);
 /* A small PUBLIC Fr matrix applied to k vectors at once -- the PSS maps on field elements

@@ -169,7 +169,7 @@ int zk_fr_mul(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) {
     return fr_binary(ctx, 2, a, b, out, n);
 }
 int zk_fr_axpb(zk_ctx* ctx, const void* a, const void* b, const uint64_t alpha[4], const uint64_t beta[4], void* out, size_t n) {
-    NEED(ctx, alpha && beta && (n == 0 || (a && b && out)));
+    NEED(ctx, alpha && beta && (n == 0 || (b && out)));  // a may be NULL (treated as zero)
     return fr_axpb(ctx, a, b, alpha, beta, out, n);
 }
 int zk_fr_apply_matrix(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_t cols, const void* d_in, size_t in_vec_stride,

@@ -485,7 +485,8 @@ __global__ void __launch_bounds__(kBlock) k_fr_binary(const void* __restrict__ a
 __global__ void __launch_bounds__(kBlock) k_fr_axpb(const void* __restrict__ a, const void* __restrict__ b, Fr alpha, Fr beta,
                                                   void* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-        Fr r = fr_add(fr_add(fr_load(a, i), fr_mul(alpha, fr_load(b, i))), beta);
+        Fr r = fr_add(fr_mul(alpha, fr_load(b, i)), beta);
+        if (a) r = fr_add(r, fr_load(a, i));  // a == nullptr: out = alpha*b + beta
         fr_store(out, i, r);
     }
 }

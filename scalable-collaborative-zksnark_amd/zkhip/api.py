@@ -149,6 +149,22 @@ class Ctx:
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
+    def temp(self, nbytes: int, key) -> DeviceBuffer:
+        """a cached device buffer of at least nbytes for `key` (avoids hipMalloc/hipFree per call)"""
+        cache = self.__dict__.setdefault("_temps", {})
+        buf = cache.get(key)
+        if buf is None or buf.nbytes < nbytes:
+            buf = cache[key] = DeviceBuffer(self, max(nbytes, 1))
+        return buf
+
+    def fr_scale(self, b, alpha: np.ndarray, n: int, out=None):
+        """out = alpha * b (element-wise, one public scalar)"""
+        out = out or self.alloc(max(32 * n, 1))
+        al = np.ascontiguousarray(alpha, dtype=np.uint64)
+        zero = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.zk_fr_axpb(self.h, 0, _ptr(b), _h(al), _h(zero), _ptr(out), n))
+        return out
+
     def to_device(self, a: np.ndarray) -> DeviceBuffer:
         a = np.ascontiguousarray(a)
         return DeviceBuffer(self, max(a.nbytes, 1)).upload(a) if a.nbytes else DeviceBuffer(self, 1)

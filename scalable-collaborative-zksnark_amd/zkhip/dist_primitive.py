@@ -67,11 +67,9 @@ def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: Packe
         return be.g1_lincomb_batch(np.stack([np.stack([gathered[q][k] for q in range(n)]) for k in range(len(lens))]), coeff)
     lam = sum(pp.unpack2_matrix[j][p] for j in range(pp.l)) % R_MOD
     c_p = sum(pp.pack_matrix[p][j] for j in range(pp.l)) % R_MOD
-    zero = fr_mont(0)
-    scaled = []
-    for s, m in zip(scalars, lens):
-        z = be.to_device(np.zeros((max(m, 1), 4), dtype=np.uint64)) if not hasattr(be, "zeros") else be.zeros(m)
-        scaled.append(be.fr_axpb(z, s, fr_mont(lam), zero, m))
+    lam_m = fr_mont(lam)
+    scaled = [be.fr_scale(s, lam_m, m, out=be.temp(32 * m, ("d_msm", k)) if hasattr(be, "temp") else None)
+              for k, (s, m) in enumerate(zip(scalars, lens))]
     c_shares = be.msm_g1_batch(list(bases), scaled, list(lens))
     gathered = net.all_gather(c_shares)
     ones = np.tile(int_to_limbs(1, 4), (n, 1))

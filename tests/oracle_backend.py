@@ -110,6 +110,10 @@ class OracleBackend:
         be = np.tile(np.asarray(beta, dtype=np.uint64).reshape(1, 4), (n, 1))
         return NumpyBuf(co.fr_add(co.fr_add(_arr(a)[:n], co.fr_mul(al, _arr(b)[:n])), be))
 
+    def fr_scale(self, b, alpha, n, out=None):
+        al = np.tile(np.asarray(alpha, dtype=np.uint64).reshape(1, 4), (n, 1))
+        return NumpyBuf(co.fr_mul(al, _arr(b)[:n]))
+
     def fr_batch_div(self, num, den, n, out=None):
         return NumpyBuf(co.fr_div(_arr(num)[:n], _arr(den)[:n]))
 
