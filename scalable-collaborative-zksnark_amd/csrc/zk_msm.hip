@@ -180,28 +180,45 @@ __global__ void __launch_bounds__(kBlk) k_chunk_offsets(u32* __restrict__ cc, u3
     }
 }
 
-// exclusive scan of counts[row][0..nb) -> offsets.  One block per row.
+// exclusive scan of counts[row][0..nb) -> offsets.  One block per row; the row is staged in LDS in
+// tiles of kScanTile counters (coalesced global loads/stores, the serial part runs out of LDS).
 static constexpr int kScanThreads = 1024;
+static constexpr int kScanTile = 16384;
 __global__ void __launch_bounds__(kScanThreads) k_scan(const u32* __restrict__ counts, size_t nb, u32* __restrict__ offsets) {
+    __shared__ u32 tile[kScanTile];
     __shared__ u32 part[kScanThreads];
-    const int w = blockIdx.x, tid = threadIdx.x;
-    const size_t per = (nb + kScanThreads - 1) / kScanThreads;
-    const size_t lo = (size_t)tid * per, hi = (lo + per < nb) ? lo + per : nb;
-    u32 s = 0;
-    for (size_t b = lo; b < hi; b++) s += counts[(size_t)w * nb + b];
-    part[tid] = s;
+    __shared__ u32 carry_s;
+    const int tid = threadIdx.x;
+    const u32* src = counts + (size_t)blockIdx.x * nb;
+    u32* dst = offsets + (size_t)blockIdx.x * nb;
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 per-thread sums
-    for (int off = 1; off < kScanThreads; off <<= 1) {
-        u32 v = (tid >= off) ? part[tid - off] : 0u;
+    for (size_t t0 = 0; t0 < nb; t0 += kScanTile) {
+        const size_t len = (nb - t0 < (size_t)kScanTile) ? nb - t0 : (size_t)kScanTile;
+        for (size_t i = tid; i < len; i += kScanThreads) tile[i] = src[t0 + i];
         __syncthreads();
-        part[tid] += v;
+        const size_t per = (len + kScanThreads - 1) / kScanThreads;
+        const size_t lo = (size_t)tid * per, hi = (lo + per < len) ? lo + per : len;
+        u32 s = 0;
+        for (size_t i = lo; i < hi; i++) s += tile[i];
+        part[tid] = s;
         __syncthreads();
-    }
-    u32 run = part[tid] - s;  // exclusive
-    for (size_t b = lo; b < hi; b++) {
-        offsets[(size_t)w * nb + b] = run;
-        run += counts[(size_t)w * nb + b];
+        for (int off = 1; off < kScanThreads; off <<= 1) {  // Hillis-Steele over the per-thread sums
+            u32 v = (tid >= off) ? part[tid - off] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        u32 run = carry_s + part[tid] - s;  // exclusive prefix of this thread's slice
+        for (size_t i = lo; i < hi; i++) {
+            u32 v = tile[i];
+            tile[i] = run;
+            run += v;
+        }
+        __syncthreads();
+        for (size_t i = tid; i < len; i += kScanThreads) dst[t0 + i] = tile[i];
+        if (tid == kScanThreads - 1) carry_s += part[tid];
+        __syncthreads();
     }
 }
 
@@ -424,7 +441,9 @@ static zkhost::Jac load_xyzz_host(const uint64_t* p) {
     return zkhost::xyzz_to_jac(X, Y, ZZ, ZZZ);
 }
 
-// host combine of one item: rows of W x c points (planes T_0..T_{c-2}, T_all per window)
+// host combine of one item: rows of W x c points (planes T_0..T_{c-2}, T_all per window):
+// result = sum_p 2^p * pos[p] over ~256 bit positions, a doubling chain.  (Splitting the chain over
+// host threads was measured: thread start-up costs what the shorter chain saves.)
 static void combine_item(const uint64_t* h, const WinLayout& L, int c, uint64_t* h_out) {
     std::vector<zkhost::Jac> pos((size_t)256 + c + 1, zkhost::jac_inf());
     for (int w = 0; w < L.W; w++) {
