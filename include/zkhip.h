@@ -115,7 +115,8 @@ int zk_product_tree(zk_ctx *ctx, const void *d_x, size_t N, void *d_tree);
 /* Upload a base vector once (the reference clones powers_of_g[level] per call, dpoly_comm.rs:258).
  * h_bases: n affine points at `stride` bytes (96 or 104); stored on device packed at 96 B. */
 int zk_srs_register(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n, zk_srs **out);
-/* Same from a device buffer already in the packed 96-B layout (no copy is made; caller keeps it alive) */
+/* Same from a device buffer in the packed 96-B reference layout.  The library keeps its own copy in
+ * its internal Montgomery form (one conversion pass); the caller's buffer is not referenced afterwards. */
 int zk_srs_wrap_device(zk_ctx *ctx, const void *d_bases96, size_t n, zk_srs **out);
 /* Synthetic SRS on device: P_i = (k0 + i*k1)*G, the generator G1; mirrors the random-point SRS of
  * PolynomialCommitmentCub::new_single/new_random (dpoly_comm.rs:197-233). k0,k1 canonical 4xu64. */
@@ -127,7 +128,10 @@ int zk_srs_generate(zk_ctx *ctx, const uint64_t h_k0[4], const uint64_t h_k1[4],
 int zk_srs_precompute(zk_ctx *ctx, zk_srs *srs, int window_bits);
 int zk_srs_free(zk_ctx *ctx, zk_srs *srs);
 size_t zk_srs_len(const zk_srs *srs);
+/* the library's device copy (INTERNAL Montgomery form, radix 2^390): for diagnostics only */
 const void *zk_srs_device_ptr(const zk_srs *srs);
+/* read the bases back in the reference layout (96 B per point, Montgomery radix 2^384) */
+int zk_srs_download(zk_ctx *ctx, const zk_srs *srs, void *h_out96);
 
 /* sum_i scalars[i] * bases[offset + i], i < n.  d_scalars: n Fr (Montgomery, as the reference
  * passes them; converted on device like `into_bigint`).  h_out: 18 u64 normalised Jacobian. */

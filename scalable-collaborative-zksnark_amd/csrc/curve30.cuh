@@ -1,0 +1,158 @@
+// curve30.cuh -- G1 XYZZ arithmetic over the unsaturated field (fq30.cuh), with static bounds.
+//
+// Value bounds (multiples of q) are invariants of the representation, documented per formula:
+//   affine SRS points:  x, y < q (canonical, internal Montgomery form 2^390)
+//   XYZZ points:        X < 8q, Y < 4q, ZZ < 2q, ZZZ < 2q   (in registers and in HBM; 8q < 2^384)
+// Every product below has input bounds multiplying to <= 256, hence result < 2q (fq30.cuh).
+// Infinity = all limbs of ZZ exactly zero (only ever produced by explicit assignment).
+#pragma once
+#include "fq30.cuh"
+
+namespace zk {
+
+struct Aff30 {
+    Fq30 x, y;
+};
+struct Xyzz30 {
+    Fq30 x, y, zz, zzz;
+};
+
+__device__ __forceinline__ bool aff30_is_inf(const Aff30& p) { return f30_all_zero(p.x) && f30_all_zero(p.y); }
+__device__ __forceinline__ bool xyzz30_is_inf(const Xyzz30& p) { return f30_all_zero(p.zz); }
+__device__ __forceinline__ void xyzz30_set_inf(Xyzz30& p) {
+    p.x = f30_zero();
+    p.y = f30_zero();
+    p.zz = f30_zero();
+    p.zzz = f30_zero();
+}
+__device__ __forceinline__ Aff30 aff30_load(const void* base, size_t idx) {
+    Aff30 p;
+    p.x = f30_load(base, idx * 96);
+    p.y = f30_load(base, idx * 96 + 48);
+    return p;
+}
+__device__ __forceinline__ Xyzz30 xyzz30_load(const void* base, size_t idx) {
+    Xyzz30 p;
+    p.x = f30_load(base, idx * 192);
+    p.y = f30_load(base, idx * 192 + 48);
+    p.zz = f30_load(base, idx * 192 + 96);
+    p.zzz = f30_load(base, idx * 192 + 144);
+    return p;
+}
+__device__ __forceinline__ void xyzz30_store(void* base, size_t idx, const Xyzz30& p) {
+    f30_store(base, idx * 192, p.x);
+    f30_store(base, idx * 192 + 48, p.y);
+    f30_store(base, idx * 192 + 96, p.zz);
+    f30_store(base, idx * 192 + 144, p.zzz);
+}
+
+// q - y for canonical y (0 -> 0): exact negation of an affine coordinate (rare paths only)
+__device__ __forceinline__ Fq30 f30_neg_canon(const Fq30& y) {
+    if (f30_all_zero(y)) return y;
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = Q30::KQ2(i) - y.l[i];  // 2q - y in (q, 2q)
+    f30_norm(r);
+    return f30_csub_q(r);
+}
+
+// 2*(x, y) for an affine point, x < 8q, y < 4q (mdbl-2008-s-1, a = 0).  Rare path.
+__device__ __noinline__ Xyzz30 xyzz30_dbl_affine(Fq30 x, Fq30 y) {
+    Xyzz30 r;
+    Fq30 U = f30_add(y, y);                   // < 8q
+    Fq30 V = f30_sqr(U);                      // < 2q
+    Fq30 W = f30_mul(U, V);                   // < 2q
+    Fq30 S = f30_mul(x, V);                   // < 2q
+    Fq30 xx = f30_sqr(x);                     // < 2q
+    Fq30 M = f30_add(f30_add(xx, xx), xx);    // < 6q
+    Fq30 S2 = f30_add(S, S);                  // < 4q
+    r.x = f30_sub4(f30_sqr(M), S2);           // M^2 + 4q - 2S < 6q
+    r.y = f30_sub2(f30_mul(M, f30_sub8(S, r.x)), f30_mul(W, y));  // M(S + 8q - X3) + 2q - W*y < 4q
+    r.zz = V;
+    r.zzz = W;
+    return r;
+}
+// 2*p for XYZZ p (dbl-2008-s-1, a = 0).  Rare path.
+__device__ __noinline__ Xyzz30 xyzz30_dbl(Xyzz30 p) {
+    if (xyzz30_is_inf(p)) return p;
+    Xyzz30 r;
+    Fq30 U = f30_add(p.y, p.y);               // < 8q
+    Fq30 V = f30_sqr(U);
+    Fq30 W = f30_mul(U, V);
+    Fq30 S = f30_mul(p.x, V);                 // 8q * 2q
+    Fq30 xx = f30_sqr(p.x);                   // 64 q^2
+    Fq30 M = f30_add(f30_add(xx, xx), xx);    // < 6q
+    Fq30 S2 = f30_add(S, S);
+    Fq30 X3 = f30_sub4(f30_sqr(M), S2);       // < 6q
+    r.y = f30_sub2(f30_mul(M, f30_sub8(S, X3)), f30_mul(W, p.y));
+    r.x = X3;
+    r.zz = f30_mul(V, p.zz);
+    r.zzz = f30_mul(W, p.zzz);
+    return r;
+}
+
+// acc += p (affine; `neg`: -p), madd-2008-s: 8M + 2S, no modular reduction on the hot path.
+// The doubling / cancellation case (same x) is detected AFTER the fact: then P == 0 (mod q), so
+// ZZ3 = ZZ1 * P^2 == 0 (mod q), which is a two-constant comparison on a value < 2q.
+__device__ __forceinline__ void xyzz30_madd(Xyzz30& acc, const Aff30& p, bool neg) {
+    if (aff30_is_inf(p)) return;
+    if (xyzz30_is_inf(acc)) {
+        acc.x = p.x;
+        acc.y = neg ? f30_neg_canon(p.y) : p.y;
+        acc.zz = f30_one();
+        acc.zzz = f30_one();
+        return;
+    }
+    const Fq30 U2 = f30_mul(p.x, acc.zz);     // q * 2q -> < 2q
+    const Fq30 S2 = f30_mul(p.y, acc.zzz);    // < 2q
+    const Fq30 P = f30_sub8(U2, acc.x);       // U2 + 8q - X1 < 10q
+    // R = +-S2 - Y1:  S2 + 4q - Y1 < 6q   or   (4q - Y1) + 2q - S2 < 6q
+    const Fq30 R = neg ? f30_sub2(f30_sub4(f30_zero(), acc.y), S2) : f30_sub4(S2, acc.y);
+    const Fq30 PP = f30_sqr(P);               // 100 q^2 -> < 2q
+    const Fq30 PPP = f30_mul(P, PP);          // < 2q
+    const Fq30 Q = f30_mul(acc.x, PP);        // 8q * 2q -> < 2q
+    const Fq30 ZZ3 = f30_mul(acc.zz, PP);     // < 2q
+    if (f30_is_zero_2q(ZZ3)) {                // same x coordinate: doubling or cancellation (adversarial inputs only)
+        const Fq30 Rc = f30_canon8(R);
+        if (f30_all_zero(Rc)) acc = xyzz30_dbl_affine(p.x, neg ? f30_neg_canon(p.y) : p.y);
+        else xyzz30_set_inf(acc);
+        return;
+    }
+    const Fq30 Q2 = f30_add(Q, Q);                              // < 4q
+    const Fq30 X3 = f30_sub4(f30_sub2(f30_sqr(R), PPP), Q2);    // (R^2 + 2q - PPP) + 4q - 2Q < 8q
+    const Fq30 Y3 = f30_sub2(f30_mul(R, f30_sub8(Q, X3)), f30_mul(acc.y, PPP));  // R(Q + 8q - X3) + 2q - Y1*PPP < 4q
+    acc.zzz = f30_mul(acc.zzz, PPP);
+    acc.zz = ZZ3;
+    acc.x = X3;
+    acc.y = Y3;
+}
+
+// r = a + b (XYZZ + XYZZ), add-2008-s: 12M + 2S
+__device__ __forceinline__ Xyzz30 xyzz30_add(const Xyzz30& a, const Xyzz30& b) {
+    if (xyzz30_is_inf(a)) return b;
+    if (xyzz30_is_inf(b)) return a;
+    const Fq30 U1 = f30_mul(a.x, b.zz);       // 8q * 2q
+    const Fq30 U2 = f30_mul(b.x, a.zz);
+    const Fq30 S1 = f30_mul(a.y, b.zzz);      // 4q * 2q
+    const Fq30 S2 = f30_mul(b.y, a.zzz);
+    const Fq30 P = f30_sub2(U2, U1);          // < 4q
+    const Fq30 R = f30_sub2(S2, S1);          // < 4q
+    const Fq30 PP = f30_sqr(P);
+    const Fq30 PPP = f30_mul(P, PP);
+    const Fq30 Q = f30_mul(U1, PP);
+    const Fq30 ZZ3 = f30_mul(f30_mul(a.zz, b.zz), PP);
+    Xyzz30 r;
+    if (f30_is_zero_2q(ZZ3)) {
+        if (f30_all_zero(f30_canon8(R))) r = xyzz30_dbl(a);
+        else xyzz30_set_inf(r);
+        return r;
+    }
+    const Fq30 Q2 = f30_add(Q, Q);
+    r.x = f30_sub4(f30_sub2(f30_sqr(R), PPP), Q2);                          // < 8q
+    r.y = f30_sub2(f30_mul(R, f30_sub8(Q, r.x)), f30_mul(S1, PPP));        // < 4q
+    r.zz = ZZ3;
+    r.zzz = f30_mul(f30_mul(a.zzz, b.zzz), PPP);
+    return r;
+}
+
+}  // namespace zk

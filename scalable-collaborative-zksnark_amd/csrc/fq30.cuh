@@ -1,0 +1,263 @@
+// fq30.cuh -- BLS12-381 Fq for the MSM kernels in UNSATURATED form: 13 limbs of 30 bits in
+// registers, Montgomery radix R' = 2^390.
+//
+// Why: with 32-bit saturated limbs every multiply-accumulate needs a carry instruction
+// (v_mad_u64_u32 + v_addc_co_u32: ~7.7 cycles per limb product).  With 30-bit limbs a limb
+// product is < 2^60, so up to 15 of them accumulate in a 64-bit register with NO carry handling:
+// plain C `acc += (u64)a*b` compiles to back-to-back v_mad_u64_u32 the compiler schedules freely.
+// Measured (tools/ubench_mul30.hip, MI355X): 65.7 vs 51.0 G mul/s at 2 waves/SIMD, 60.1 vs 41.7 at 1.
+//
+// Lazy reduction: q/R' < 2^-9, so a product of inputs < 16q is < 2q -- NO conditional
+// subtraction anywhere in the hot path.  Additions / subtractions are limb-wise followed by one
+// carry normalisation; subtraction adds a multiple of q written in redundant limbs (every limb
+// >= the largest limb it may have to absorb) so no limb ever goes negative.  Callers track the
+// static bound of every value (comments "< kq"); everything that is stored stays < 8q < 2^384.
+//
+// HBM format is unchanged in size and packing (48-byte little-endian integers); only the
+// Montgomery constant of INTERNAL data differs (2^390 instead of the reference's 2^384): the SRS is
+// converted once at registration (x 2^6) and results are converted back on the way out.
+#pragma once
+#include "fp.cuh"
+
+namespace zk {
+
+struct Fq30 {
+    u32 l[13];  // value = sum l[i] * 2^(30 i); "normalised": l[0..11] < 2^30
+};
+
+struct Q30 {
+    static constexpr u32 MASK = 0x3fffffffu;
+    static constexpr u32 QP = 0x3ffcfffdu;  // -q^{-1} mod 2^30
+    __host__ __device__ static constexpr u32 KQ2(int i) {
+        constexpr u32 t[13] = {0x7fff5556u, 0x4ff7fffeu, 0x6a7ffff6u, 0x55ffff57u, 0x61ec483cu, 0x469507b4u, 0x6257ece5u, 0x65c279c1u, 0x59aec8edu, 0x7db21a5cu, 0x53496373u, 0x751cbff2u, 0x00340222u};
+        return t[i];
+    }
+    __host__ __device__ static constexpr u32 KQ4(int i) {
+        constexpr u32 t[13] = {0x7ffeaaacu, 0x5feffffeu, 0x54ffffedu, 0x6bfffeb0u, 0x43d89079u, 0x4d2a0f6au, 0x44afd9cbu, 0x4b84f384u, 0x735d91dcu, 0x7b6434b9u, 0x6692c6e8u, 0x6a397fe5u, 0x00680446u};
+        return t[i];
+    }
+    __host__ __device__ static constexpr u32 KQ8(int i) {
+        constexpr u32 t[13] = {0x7ffd5558u, 0x7fdffffeu, 0x69ffffdbu, 0x57fffd61u, 0x47b120f4u, 0x5a541ed5u, 0x495fb397u, 0x5709e709u, 0x66bb23b9u, 0x76c86974u, 0x4d258dd2u, 0x5472ffccu, 0x00d0088eu};
+        return t[i];
+    }
+    __host__ __device__ static constexpr u32 Q(int i) {
+        constexpr u32 t[13] = {0x3fffaaabu, 0x27fbffffu, 0x153ffffbu, 0x2affffacu, 0x30f6241eu, 0x034a83dau, 0x112bf673u, 0x12e13ce1u, 0x2cd76477u, 0x1ed90d2eu, 0x29a4b1bau, 0x3a8e5ff9u, 0x001a0111u};
+        return t[i];
+    }
+    __host__ __device__ static constexpr u32 Q2(int i) {
+        constexpr u32 t[13] = {0x3fff5556u, 0x0ff7ffffu, 0x2a7ffff7u, 0x15ffff58u, 0x21ec483du, 0x069507b5u, 0x2257ece6u, 0x25c279c2u, 0x19aec8eeu, 0x3db21a5du, 0x13496374u, 0x351cbff3u, 0x00340223u};
+        return t[i];
+    }
+    __host__ __device__ static constexpr u32 Q4(int i) {
+        constexpr u32 t[13] = {0x3ffeaaacu, 0x1fefffffu, 0x14ffffeeu, 0x2bfffeb1u, 0x03d8907au, 0x0d2a0f6bu, 0x04afd9ccu, 0x0b84f385u, 0x335d91ddu, 0x3b6434bau, 0x2692c6e9u, 0x2a397fe6u, 0x00680447u};
+        return t[i];
+    }
+    __host__ __device__ static constexpr u32 ONE(int i) {
+        constexpr u32 t[13] = {0x00d1ff2eu, 0x19d80000u, 0x34800ac4u, 0x2e00cde6u, 0x02431c84u, 0x269f83a2u, 0x3dcf80ddu, 0x09b42da0u, 0x25eec26cu, 0x15d98f12u, 0x04b29f14u, 0x259fcfa0u, 0x00015de9u};
+        return t[i];
+    }
+    __host__ __device__ static constexpr u32 C396(int i) {
+        constexpr u32 t[13] = {0x3480cb7fu, 0x3e0c0000u, 0x2042b126u, 0x3f337aafu, 0x3de4b4d1u, 0x1e015cf1u, 0x005c540du, 0x3467b19au, 0x352a6da3u, 0x19d89d19u, 0x2fb9afe6u, 0x3848c817u, 0x0009772fu};
+        return t[i];
+    }
+    __host__ __device__ static constexpr u32 C384(int i) {
+        constexpr u32 t[13] = {0x0002fffdu, 0x18240000u, 0x00c00027u, 0x3d0002f1u, 0x0758baebu, 0x22615d4fu, 0x257455f4u, 0x1614dc14u, 0x2c6d77ceu, 0x2a5e895bu, 0x0935c071u, 0x30fea039u, 0x0015f65eu};
+        return t[i];
+    }
+};
+
+__device__ __forceinline__ Fq30 f30_zero() {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = 0;
+    return r;
+}
+__device__ __forceinline__ Fq30 f30_one() {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = Q30::ONE(i);
+    return r;
+}
+__device__ __forceinline__ bool f30_all_zero(const Fq30& a) {  // exact zero limbs (the infinity marker)
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) o |= a.l[i];
+    return o == 0;
+}
+// carry normalisation: limbs 0..11 back below 2^30 (value unchanged).  Inputs come from one limb-wise
+// add/sub of normalised operands: every limb < 3 * 2^30, so `+ carry` (<= 2) cannot wrap a u32.
+__device__ __forceinline__ void f30_norm(Fq30& a) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        a.l[i + 1] += a.l[i] >> 30;
+        a.l[i] &= Q30::MASK;
+    }
+}
+// a + b   (bounds add)
+__device__ __forceinline__ Fq30 f30_add(const Fq30& a, const Fq30& b) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = a.l[i] + b.l[i];
+    f30_norm(r);
+    return r;
+}
+// a + k*q - b  for a normalised b < k*q.  KQ = redundant limbs of k*q (Q30::KQ2 / KQ4 / KQ8)
+#define ZK_F30_SUB(name, KQ)                                                      \
+    __device__ __forceinline__ Fq30 name(const Fq30& a, const Fq30& b) {         \
+        Fq30 r;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 13; i++) r.l[i] = a.l[i] + Q30::KQ(i) - b.l[i]; \
+        f30_norm(r);                                                               \
+        return r;                                                                  \
+    }
+ZK_F30_SUB(f30_sub2, KQ2)  // a + 2q - b,  b < 2q
+ZK_F30_SUB(f30_sub4, KQ4)  // a + 4q - b,  b < 4q
+ZK_F30_SUB(f30_sub8, KQ8)  // a + 8q - b,  b < 8q
+// Montgomery product a*b*2^-390 (mod q) for normalised inputs whose bounds multiply to <= 256 q^2;
+// the result is normalised and < 2q.  Product scanning; a column holds at most 15 limb products
+// (15 * (2^30-1)^2 + carry < 2^64) before its high part is folded into the next column.
+__device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
+    u32 m[13];
+    Fq30 t;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 25; k++) {
+        int cnt = 0;
+        u64 nxt = 0;
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 13) {
+                acc += (u64)a.l[i] * b.l[j];
+                cnt++;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int j = k - i;
+            if (i < k && j >= 1 && j < 13) {
+                if (cnt == 15) {
+                    nxt += acc >> 30;
+                    acc &= Q30::MASK;
+                    cnt = 0;
+                }
+                acc += (u64)m[i] * Q30::Q(j);
+                cnt++;
+            }
+        }
+        if (k < 13) {
+            if (cnt >= 15) {
+                nxt += acc >> 30;
+                acc &= Q30::MASK;
+            }
+            const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;
+            m[k] = mk;
+            acc += (u64)mk * Q30::Q(0);
+        } else {
+            t.l[k - 13] = (u32)acc & Q30::MASK;
+        }
+        acc = (acc >> 30) + nxt;
+    }
+    t.l[12] = (u32)acc;
+    return t;
+}
+__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) { return f30_mul(a, a); }
+
+// v - c if v >= c else v, for a normalised constant c given by limb accessor
+#define ZK_F30_CSUB(name, C)                                                                         \
+    __device__ __forceinline__ Fq30 name(const Fq30& v) {                                           \
+        Fq30 d, r;                                                                                    \
+        u32 bw = 0;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 13; i++) {                                             \
+            u32 x = v.l[i] - Q30::C(i) - bw;                                                          \
+            bw = x >> 31;                                                                             \
+            d.l[i] = (i < 12) ? (x & Q30::MASK) : x;                                                  \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 13; i++) r.l[i] = bw ? v.l[i] : d.l[i];               \
+        return r;                                                                                     \
+    }
+ZK_F30_CSUB(f30_csub_q, Q)
+ZK_F30_CSUB(f30_csub_2q, Q2)
+ZK_F30_CSUB(f30_csub_4q, Q4)
+// canonical representative (< q) of a normalised value < 8q
+__device__ __forceinline__ Fq30 f30_canon8(const Fq30& v) { return f30_csub_q(f30_csub_2q(f30_csub_4q(v))); }
+// is a normalised value < 2q congruent to 0?  (only 0 and q qualify)
+__device__ __forceinline__ bool f30_is_zero_2q(const Fq30& v) {
+    u32 o0 = 0, o1 = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        o0 |= v.l[i];
+        o1 |= v.l[i] ^ Q30::Q(i);
+    }
+    return o0 == 0 || o1 == 0;
+}
+
+// ---- 48-byte packed integers in HBM <-> 30-bit limbs (pure re-limbing, value unchanged) ----
+__device__ __forceinline__ Fq30 f30_from_words(const u32 (&w)[12]) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int bit = 30 * i, wi = bit >> 5, s = bit & 31;
+        u32 v = w[wi] >> s;
+        if (s > 2 && wi + 1 < 12) v |= w[wi + 1] << (32 - s);
+        r.l[i] = (i < 12) ? (v & Q30::MASK) : v;
+    }
+    return r;
+}
+__device__ __forceinline__ void f30_to_words(const Fq30& a, u32 (&w)[12]) {  // a normalised, < 2^384
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const int bit = 32 * j, li = bit / 30, s = bit % 30;  // word j starts inside limb li at offset s
+        u32 v = a.l[li] >> s;
+        if (li + 1 < 13) v |= a.l[li + 1] << (30 - s);
+        if (s > 28 && li + 2 < 13) v |= a.l[li + 2] << (60 - s);
+        w[j] = v;
+    }
+}
+__device__ __forceinline__ Fq30 f30_load(const void* base, size_t byte_off) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + byte_off);
+    u32 w[12];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uint4 v = p[i];
+        w[4 * i] = v.x;
+        w[4 * i + 1] = v.y;
+        w[4 * i + 2] = v.z;
+        w[4 * i + 3] = v.w;
+    }
+    return f30_from_words(w);
+}
+__device__ __forceinline__ void f30_store(void* base, size_t byte_off, const Fq30& a) {
+    u32 w[12];
+    f30_to_words(a, w);
+    uint4* p = reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + byte_off);
+#pragma unroll
+    for (int i = 0; i < 3; i++) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+// reference form (x * 2^384, canonical) <-> internal form (x * 2^390)
+__device__ __forceinline__ Fq30 f30_from_ref(const Fq30& x_r384) {
+    Fq30 c;
+#pragma unroll
+    for (int i = 0; i < 13; i++) c.l[i] = Q30::C396(i);
+    return f30_canon8(f30_mul(x_r384, c));  // X * 2^396 * 2^-390 = X * 2^6
+}
+__device__ __forceinline__ Fq30 f30_to_ref(const Fq30& x_int) {  // input < 16q, output canonical
+    Fq30 c;
+#pragma unroll
+    for (int i = 0; i < 13; i++) c.l[i] = Q30::C384(i);
+    return f30_canon8(f30_mul(x_int, c));  // X' * 2^384 * 2^-390 = X' * 2^-6
+}
+// a^(q-2) (0 -> 0), input < 16q, output < 2q
+__device__ __noinline__ Fq30 f30_inv(Fq30 a) {
+    Fq30 acc = f30_one();
+    for (int i = 383; i >= 0; i--) {
+        acc = f30_sqr(acc);
+        u32 w = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            if ((i >> 5) == k) w = fp_pm2_limb<FqCfg>(k);
+        if ((w >> (i & 31)) & 1u) acc = f30_mul(acc, a);
+    }
+    return acc;
+}
+
+}  // namespace zk

@@ -24,6 +24,11 @@ static const Fq ONE = {0x760900000002fffdULL, 0xebf4000bc40c0002ULL, 0x5f4898575
 static const Fq R2 = {0xf4df1f341c341746ULL, 0x0a76e6a609d104f1ULL, 0x8de5476c4c95b6d5ULL,
                       0x67eb88a9939d83c0ULL, 0x9a793e85b519952dULL, 0x11988fe592cae3aaULL};
 static const Fq ZERO = {0, 0, 0, 0, 0, 0};
+// 2^378 (< q): the 2^384-Montgomery form of 2^-6, converts device-internal values (radix 2^390) back
+static inline const Fq& K378() {
+    static const Fq k = {0, 0, 0, 0, 0, 0x0400000000000000ULL};
+    return k;
+}
 // generator of G1 (affine, canonical): ark-bls12-381 G1_GENERATOR_X / _Y
 static const Fq GX_CANON = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL,
                             0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL};

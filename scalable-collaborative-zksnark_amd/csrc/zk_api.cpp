@@ -222,12 +222,11 @@ int zk_srs_register(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, z
 }
 int zk_srs_wrap_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out) {
     NEED(ctx, out && (n == 0 || d_bases96));
-    zk_srs* s = new zk_srs();
-    s->d_bases = const_cast<void*>(d_bases96);
-    s->n = n;
-    s->owned = false;
-    *out = s;
-    return ZK_OK;
+    return srs_from_device(ctx, d_bases96, n, out);
+}
+int zk_srs_download(zk_ctx* ctx, const zk_srs* srs, void* h_out96) {
+    NEED(ctx, srs);
+    return srs_download(ctx, srs, h_out96);
 }
 int zk_srs_generate(zk_ctx* ctx, const uint64_t k0[4], const uint64_t k1[4], size_t n, zk_srs** out) {
     NEED(ctx, out && k0 && k1);

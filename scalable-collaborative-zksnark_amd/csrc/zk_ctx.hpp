@@ -77,6 +77,8 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out);
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
 int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c);
+int srs_from_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out);
+int srs_download(zk_ctx* ctx, const zk_srs* srs, void* h_out96);
 int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, zk_srs** out);
 int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n);
 int msm_pick_window(size_t n);

@@ -542,16 +542,6 @@ int fr_binary(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
-int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n) {
-    if (n == 0) return ZK_OK;
-    ZK_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned g = grid_for(ctx, n);
-    if (op == 0) hipLaunchKernelGGL((k_fp_binary<FqCfg, 0>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
-    else if (op == 1) hipLaunchKernelGGL((k_fp_binary<FqCfg, 1>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
-    else hipLaunchKernelGGL((k_fp_binary<FqCfg, 2>), dim3(g), dim3(kBlock), 0, ctx->stream, a, b, out, n);
-    ZK_HIP(ctx, hipGetLastError());
-    return ZK_OK;
-}
 int fr_apply_matrix(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_t cols, const void* d_in, size_t isv, size_t isc,
                     void* d_out, size_t osv, size_t osr, size_t k) {
     if (k == 0 || rows == 0) return ZK_OK;

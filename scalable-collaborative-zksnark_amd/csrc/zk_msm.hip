@@ -16,7 +16,7 @@
 //                (host_curve.hpp), then normalisation to affine.
 // All additions are exact group operations, so the affine result is independent of the
 // (non-deterministic) order in which the sort places points inside a bucket.
-#include "curve.cuh"
+#include "curve30.cuh"
 #include "host_curve.hpp"
 #include "zk_ctx.hpp"
 
@@ -264,34 +264,34 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
     u32 bstart = off[b], bend = bstart + cnt[b];
     u32 ps = e0;  // start of the current run
     const u32* run = sorted + w * ns;
-    Xyzz acc;
-    xyzz_set_inf(acc);
+    Xyzz30 acc;
+    xyzz30_set_inf(acc);
     u32 v = run[e0];
-    Aff p = aff_load(bases, pidx(v));
+    Aff30 p = aff30_load(bases, pidx(v));
     for (u32 e = e0; e < e1; e++) {
         if (e == bend) {  // run finished: flush and move to the next non-empty bucket
-            if (ps == bstart) xyzz_store(buckets, w * nb + b, acc);  // whole bucket
-            else xyzz_store(heads, g, acc);                            // started before this tile
+            if (ps == bstart) xyzz30_store(buckets, w * nb + b, acc);  // whole bucket
+            else xyzz30_store(heads, g, acc);                            // started before this tile
             do {
                 b++;
                 bstart = off[b];
                 bend = bstart + cnt[b];
             } while (bend == bstart);
             ps = e;
-            xyzz_set_inf(acc);
+            xyzz30_set_inf(acc);
         }
         const bool neg = (v >> 31) != 0;
-        Aff cur = p;
+        Aff30 cur = p;
         if (e + 1 < e1) {  // prefetch the next point while this one is being added
             v = run[e + 1];
-            p = aff_load(bases, pidx(v));
+            p = aff30_load(bases, pidx(v));
         }
-        xyzz_madd(acc, cur, neg);
+        xyzz30_madd(acc, cur, neg);
     }
     // last run of the tile
-    if (ps == bstart && e1 == bend) xyzz_store(buckets, w * nb + b, acc);
-    else if (ps == e0) xyzz_store(heads, g, acc);  // single run covering the tile from its start
-    else xyzz_store(tails, g, acc);
+    if (ps == bstart && e1 == bend) xyzz30_store(buckets, w * nb + b, acc);
+    else if (ps == e0) xyzz30_store(heads, g, acc);  // single run covering the tile from its start
+    else xyzz30_store(tails, g, acc);
 }
 
 // stitch the runs cut by tile boundaries; also writes infinity for empty buckets.  Buckets that
@@ -306,9 +306,9 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets,
     const size_t w = g / nb;
     const u32 s = offsets[g], c = counts[g];
     if (c == 0) {
-        Xyzz z;
-        xyzz_set_inf(z);
-        xyzz_store(buckets, g, z);
+        Xyzz30 z;
+        xyzz30_set_inf(z);
+        xyzz30_store(buckets, g, z);
         return;
     }
     const u32 e = s + c;
@@ -319,9 +319,9 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets,
         return;
     }
     const size_t base = w * tiles_per_w;
-    Xyzz acc = (s == t0 * T) ? xyzz_load(heads, base + t0) : xyzz_load(tails, base + t0);
-    for (u32 t = t0 + 1; t <= t1; t++) acc = xyzz_add(acc, xyzz_load(heads, base + t));
-    xyzz_store(buckets, g, acc);
+    Xyzz30 acc = (s == t0 * T) ? xyzz30_load(heads, base + t0) : xyzz30_load(tails, base + t0);
+    for (u32 t = t0 + 1; t <= t1; t++) acc = xyzz30_add(acc, xyzz30_load(heads, base + t));
+    xyzz30_store(buckets, g, acc);
 }
 
 // one workgroup per long bucket: strided partial sums per lane, then an LDS tree
@@ -337,22 +337,22 @@ __global__ void __launch_bounds__(kBlk) k_fixup_long(const u32* __restrict__ off
         const u32 s = offsets[g], e = s + counts[g];
         const u32 t0 = s / T, t1 = (e - 1) / T;
         const size_t base = w * tiles_per_w;
-        Xyzz acc;
-        xyzz_set_inf(acc);
+        Xyzz30 acc;
+        xyzz30_set_inf(acc);
         for (u32 k = threadIdx.x; k <= t1 - t0; k += kBlk) {
-            Xyzz piece = (k == 0 && s != t0 * T) ? xyzz_load(tails, base + t0) : xyzz_load(heads, base + t0 + k);
-            acc = xyzz_add(acc, piece);
+            Xyzz30 piece = (k == 0 && s != t0 * T) ? xyzz30_load(tails, base + t0) : xyzz30_load(heads, base + t0 + k);
+            acc = xyzz30_add(acc, piece);
         }
-        xyzz_store(red, threadIdx.x, acc);
+        xyzz30_store(red, threadIdx.x, acc);
         __syncthreads();
         for (int stride = kBlk / 2; stride > 0; stride >>= 1) {
             if ((int)threadIdx.x < stride) {
-                Xyzz a = xyzz_load(red, threadIdx.x), b2 = xyzz_load(red, threadIdx.x + stride);
-                xyzz_store(red, threadIdx.x, xyzz_add(a, b2));
+                Xyzz30 a = xyzz30_load(red, threadIdx.x), b2 = xyzz30_load(red, threadIdx.x + stride);
+                xyzz30_store(red, threadIdx.x, xyzz30_add(a, b2));
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) xyzz_store(buckets, g, xyzz_load(red, 0));
+        if (threadIdx.x == 0) xyzz30_store(buckets, g, xyzz30_load(red, 0));
         __syncthreads();
     }
 }
@@ -368,15 +368,15 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
     const size_t j = rem % half;
     const size_t in_w = w * (size_t)rows * len;
     const size_t src_row = (r < rows - 1) ? (size_t)r : (size_t)(rows - 1);  // rows-1 = the L row
-    Xyzz b = xyzz_load(in, in_w + src_row * len + 2 * j + 1);
-    Xyzz res;
+    Xyzz30 b = xyzz30_load(in, in_w + src_row * len + 2 * j + 1);
+    Xyzz30 res;
     if (r == rows - 1) {
         res = b;  // odd elements of L become the new plane row
     } else {
-        Xyzz a = xyzz_load(in, in_w + src_row * len + 2 * j);
-        res = xyzz_add(a, b);
+        Xyzz30 a = xyzz30_load(in, in_w + src_row * len + 2 * j);
+        res = xyzz30_add(a, b);
     }
-    xyzz_store(out, t, res);
+    xyzz30_store(out, t, res);
 }
 
 // SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine, packed 96 B), one lane per point.
@@ -385,27 +385,43 @@ __global__ void __launch_bounds__(kBlk) k_precompute(const void* __restrict__ ba
                                                    void* __restrict__ table) {
     const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (i >= n) return;
-    Aff p = aff_load(bases, i);
-    char* out = reinterpret_cast<char*>(table);
-    Xyzz acc;
-    xyzz_set_inf(acc);
-    xyzz_madd(acc, p, false);
+    Aff30 p = aff30_load(bases, i);
+    Xyzz30 acc;
+    xyzz30_set_inf(acc);
+    xyzz30_madd(acc, p, false);
     for (int w = 0; w < L.W; w++) {
         if (w > 0)
-            for (int k = 0; k < L.width(w - 1); k++) acc = xyzz_dbl(acc);
-        Aff a;
-        if (xyzz_is_inf(acc)) {
-            a.x = fp_zero<FqCfg>();
-            a.y = fp_zero<FqCfg>();
+            for (int k = 0; k < L.width(w - 1); k++) acc = xyzz30_dbl(acc);
+        Aff30 a;
+        if (xyzz30_is_inf(acc)) {
+            a.x = f30_zero();
+            a.y = f30_zero();
         } else {
-            Fq i3 = fp_inv<FqCfg>(acc.zzz);   // 1/Z^3
-            Fq iz = fq_mul(acc.zz, i3);       // Z^2/Z^3 = 1/Z
-            a.x = fq_mul(acc.x, fq_sqr(iz));  // X/Z^2
-            a.y = fq_mul(acc.y, i3);          // Y/Z^3
+            Fq30 i3 = f30_inv(acc.zzz);                    // 1/Z^3
+            Fq30 iz = f30_mul(acc.zz, i3);                 // Z^2/Z^3 = 1/Z
+            a.x = f30_canon8(f30_mul(acc.x, f30_sqr(iz)));  // X/Z^2, canonical like every SRS coordinate
+            a.y = f30_canon8(f30_mul(acc.y, i3));           // Y/Z^3
         }
-        char* dst = out + ((size_t)w * nsr + i) * 96;
-        fp_store<FqCfg>(dst, 0, a.x);
-        fp_store<FqCfg>(dst + 48, 0, a.y);
+        f30_store(table, ((size_t)w * nsr + i) * 96, a.x);
+        f30_store(table, ((size_t)w * nsr + i) * 96 + 48, a.y);
+    }
+}
+
+// SRS format conversion: reference Montgomery form (x * 2^384) <-> internal (x * 2^390), in place or copy
+__global__ void __launch_bounds__(kBlk) k_srs_convert(const void* __restrict__ in, void* __restrict__ out, size_t ncoord, int to_internal) {
+    for (size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x; i < ncoord; i += (size_t)gridDim.x * kBlk) {
+        Fq30 v = f30_load(in, i * 48);
+        f30_store(out, i * 48, to_internal ? f30_from_ref(v) : f30_to_ref(v));
+    }
+}
+
+// test hooks: field ops on reference-form Fq vectors through the production (unsaturated) arithmetic
+__global__ void __launch_bounds__(kBlk) k_dbg_fq(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ out, size_t n,
+                                               int op) {
+    for (size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlk) {
+        Fq30 x = f30_from_ref(f30_load(a, i * 48)), y = f30_from_ref(f30_load(b, i * 48));
+        Fq30 r = (op == 0) ? f30_add(x, y) : (op == 1) ? f30_sub2(x, y) : f30_mul(x, y);
+        f30_store(out, i * 48, f30_to_ref(r));
     }
 }
 
@@ -414,31 +430,39 @@ __global__ void __launch_bounds__(kBlk) k_dbg_g1(const void* __restrict__ p, con
                                                size_t n, int mode) {
     const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (i >= n) return;
-    Aff a = aff_load(p, i), b = aff_load(q, i);
-    Xyzz s;
-    xyzz_set_inf(s);
-    xyzz_madd(s, a, false);
-    xyzz_madd(s, b, mode == 3);  // p + q   (mode 3: p - q)
-    Xyzz r = s;
+    Aff30 a, b;  // reference-form inputs -> internal form
+    a.x = f30_from_ref(f30_load(p, i * 96));
+    a.y = f30_from_ref(f30_load(p, i * 96 + 48));
+    b.x = f30_from_ref(f30_load(q, i * 96));
+    b.y = f30_from_ref(f30_load(q, i * 96 + 48));
+    Xyzz30 s;
+    xyzz30_set_inf(s);
+    xyzz30_madd(s, a, false);
+    xyzz30_madd(s, b, mode == 3);  // p + q   (mode 3: p - q)
+    Xyzz30 r = s;
     if (mode == 1) {  // (p+q) + p
-        Xyzz pa;
-        xyzz_set_inf(pa);
-        xyzz_madd(pa, a, false);
-        r = xyzz_add(s, pa);
+        Xyzz30 pa;
+        xyzz30_set_inf(pa);
+        xyzz30_madd(pa, a, false);
+        r = xyzz30_add(s, pa);
     } else if (mode == 2) {  // (p+q) + (p+q): doubling path of the full addition
-        r = xyzz_add(s, s);
+        r = xyzz30_add(s, s);
     }
-    xyzz_store(out, i, r);
+    xyzz30_store(out, i, r);
 }
 
 // ---------------------------------------------------------------------------------------
+// device XYZZ (internal Montgomery form 2^390, coordinates < 8q) -> host Jacobian in the reference form:
+// one host multiplication by 2^-6 per coordinate (K = 2^378 mod q = the 2^384-form of 2^-6)
 static zkhost::Jac load_xyzz_host(const uint64_t* p) {
     zkhost::Fq X, Y, ZZ, ZZZ;
     std::memcpy(X.data(), p, 48);
     std::memcpy(Y.data(), p + 6, 48);
     std::memcpy(ZZ.data(), p + 12, 48);
     std::memcpy(ZZZ.data(), p + 18, 48);
-    return zkhost::xyzz_to_jac(X, Y, ZZ, ZZZ);
+    if (zkhost::is_zero(ZZ)) return zkhost::jac_inf();
+    return zkhost::xyzz_to_jac(zkhost::mul(X, zkhost::K378()), zkhost::mul(Y, zkhost::K378()), zkhost::mul(ZZ, zkhost::K378()),
+                               zkhost::mul(ZZZ, zkhost::K378()));
 }
 
 // host combine of one item: rows of W x c points (planes T_0..T_{c-2}, T_all per window):
@@ -704,6 +728,15 @@ int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars,
 }
 
 // ---------------------------------------------------------------------------------------
+static void srs_convert(zk_ctx* ctx, const void* in, void* out, size_t npoints, bool to_internal) {
+    const size_t ncoord = 2 * npoints;
+    size_t blocks = std::min<size_t>((ncoord + kBlk - 1) / kBlk, (size_t)ctx->cu_count * 8);
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_srs_convert, dim3((unsigned)blocks), dim3(kBlk), 0, ctx->stream, in, out, ncoord, to_internal ? 1 : 0);
+}
+
+// The device copy of an SRS is kept in the kernels' INTERNAL form (Montgomery radix 2^390, see
+// fq30.cuh): one conversion pass at registration, like the reference's own `mature()` step.
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out) {
     if (!out || (n && !h_bases)) return fail(ctx, ZK_ERR_INVALID, "null argument");
     if (stride != 96 && stride < 97) return fail(ctx, ZK_ERR_INVALID, "stride must be 96 or >= 97 (x, y, infinity flag)");
@@ -725,8 +758,48 @@ int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs**
             }
             ZK_HIP(ctx, hipMemcpy(s->d_bases, packed.data(), n * 96, hipMemcpyHostToDevice));
         }
+        srs_convert(ctx, s->d_bases, s->d_bases, n, true);
+        ZK_HIP(ctx, hipGetLastError());
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     *out = s;
+    return ZK_OK;
+}
+
+int srs_from_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out) {
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    zk_srs* s = new zk_srs();
+    s->n = n;
+    s->owned = true;
+    if (n) {
+        ZK_HIP(ctx, hipMalloc(&s->d_bases, n * 96));
+        srs_convert(ctx, d_bases96, s->d_bases, n, true);
+        ZK_HIP(ctx, hipGetLastError());
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *out = s;
+    return ZK_OK;
+}
+
+int srs_download(zk_ctx* ctx, const zk_srs* srs, void* h_out96) {
+    if (!srs || (srs->n && !h_out96)) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    if (!srs->n) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    void* tmp = scratch(ctx, 0, srs->n * 96);
+    if (!tmp) return ZK_ERR_OOM;
+    srs_convert(ctx, srs->d_bases, tmp, srs->n, false);
+    ZK_HIP(ctx, hipGetLastError());
+    ZK_HIP(ctx, hipMemcpyAsync(h_out96, tmp, srs->n * 96, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    size_t blocks = std::min<size_t>((n + kBlk - 1) / kBlk, (size_t)ctx->cu_count * 8);
+    hipLaunchKernelGGL(k_dbg_fq, dim3((unsigned)blocks), dim3(kBlk), 0, ctx->stream, a, b, out, n, op);
+    ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
 

@@ -46,6 +46,7 @@ SYMBOLS = [
     ("zk_srs_free", _i, [_vp, _vp]),
     ("zk_srs_len", _sz, [_vp]),
     ("zk_srs_device_ptr", _vp, [_vp]),
+    ("zk_srs_download", _i, [_vp, _vp, _vp]),
     ("zk_msm_g1", _i, [_vp, _vp, _sz, _vp, _sz, _vp]),
     ("zk_msm_g1_batch", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zk_msm_g1_host", _i, [_vp, _vp, _sz, _sz, _vp, _sz, _vp, ctypes.POINTER(ctypes.c_size_t)]),

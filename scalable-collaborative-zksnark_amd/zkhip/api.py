@@ -99,7 +99,7 @@ class Srs:
         n = len(self)
         out = np.empty((n, 12), dtype=np.uint64)
         if n:
-            self.ctx._check(self.ctx.lib.zk_memcpy_d2h(self.ctx.h, _h(out), self.device_ptr, out.nbytes))
+            self.ctx._check(self.ctx.lib.zk_srs_download(self.ctx.h, self.h, _h(out)))
         return out
 
     def free(self):
