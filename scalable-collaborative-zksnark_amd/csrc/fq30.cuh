@@ -160,7 +160,69 @@ __device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
     t.l[12] = (u32)acc;
     return t;
 }
-__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) { return f30_mul(a, a); }
+// Montgomery square: the 78 off-diagonal products are taken once against the doubled limb (2*a_i < 2^31,
+// product < 2^61 = two "units" of 2^60); a column is folded before it could exceed 15 units.
+__device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
+    u32 m[13], d[13];
+    Fq30 t;
+#pragma unroll
+    for (int i = 0; i < 13; i++) d[i] = a.l[i] << 1;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 25; k++) {
+        int units = 0;
+        u64 nxt = 0;
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int j = k - i;
+            if (j > i && j < 13) {
+                if (units + 2 > 15) {
+                    nxt += acc >> 30;
+                    acc &= Q30::MASK;
+                    units = 0;
+                }
+                acc += (u64)d[i] * a.l[j];
+                units += 2;
+            }
+        }
+        if ((k & 1) == 0) {
+            if (units + 1 > 15) {
+                nxt += acc >> 30;
+                acc &= Q30::MASK;
+                units = 0;
+            }
+            acc += (u64)a.l[k / 2] * a.l[k / 2];
+            units++;
+        }
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int j = k - i;
+            if (i < k && j >= 1 && j < 13) {
+                if (units + 1 > 15) {
+                    nxt += acc >> 30;
+                    acc &= Q30::MASK;
+                    units = 0;
+                }
+                acc += (u64)m[i] * Q30::Q(j);
+                units++;
+            }
+        }
+        if (k < 13) {
+            if (units + 1 > 15) {
+                nxt += acc >> 30;
+                acc &= Q30::MASK;
+            }
+            const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;
+            m[k] = mk;
+            acc += (u64)mk * Q30::Q(0);
+        } else {
+            t.l[k - 13] = (u32)acc & Q30::MASK;
+        }
+        acc = (acc >> 30) + nxt;
+    }
+    t.l[12] = (u32)acc;
+    return t;
+}
 
 // v - c if v >= c else v, for a normalised constant c given by limb accessor
 #define ZK_F30_CSUB(name, C)                                                                         \

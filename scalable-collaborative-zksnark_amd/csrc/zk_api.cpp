@@ -85,6 +85,8 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     for (auto& s2 : c->aux) hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     for (auto& e : c->ev_join) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    for (auto& e : c->ev_part) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    for (auto& e : c->ev_done) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     *out = c;
     return ZK_OK;
 }
@@ -101,6 +103,10 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         if (s2) hipStreamDestroy(s2);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for (auto& e : ctx->ev_join)
+        if (e) hipEventDestroy(e);
+    for (auto& e : ctx->ev_part)
+        if (e) hipEventDestroy(e);
+    for (auto& e : ctx->ev_done)
         if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -33,9 +33,11 @@ struct zk_ctx {
     int msm_window_override = 0;
     float msm_ms[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    static constexpr int kAux = 4;  // extra streams for independent MSM window classes of one batch
-    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kAux = 6;  // extra streams for independent MSM window classes of one batch
+    hipStream_t aux[kAux] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {};
+    static constexpr int kParts = 4;  // staggered parts of one MSM class (zk_msm.hip)
+    hipEvent_t ev_part[kParts] = {}, ev_done[kParts] = {};
     int cu_count = 256;
 };
 

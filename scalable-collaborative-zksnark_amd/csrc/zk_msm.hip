@@ -70,19 +70,21 @@ struct ItemDesc {
                   // else: precomputed table, copy w of point i at bases[w * pstride + i]
 };
 
-__global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ items, size_t ns, WinLayout L,
+__global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ items, size_t ns, WinLayout L, int w0, int wc,
                                                u32* __restrict__ digits_all) {
+    // rows are written for the windows [w0, w0 + wc) only (a class may cover a sub-range of the
+    // windows); the lower windows are still walked for the carry of the signed recoding
     const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (i >= ns) return;
     const ItemDesc it = items[blockIdx.y];
-    u32* digits = digits_all + (size_t)blockIdx.y * L.W * ns;
+    u32* digits = digits_all + (size_t)blockIdx.y * wc * ns;
     if (i >= it.n) {  // padding up to the (class-wide) row stride
-        for (int w = 0; w < L.W; w++) digits[(size_t)w * ns + i] = kSkip;
+        for (int w = 0; w < wc; w++) digits[(size_t)w * ns + i] = kSkip;
         return;
     }
     Fr s = fp_from_mont<FrCfg>(fr_load(it.scalars, i));
     u32 carry = 0;
-    for (int w = 0; w < L.W; w++) {
+    for (int w = 0; w < w0 + wc; w++) {
         const int cw = L.width(w);  // <= 16
         const u32 mask = (1u << cw) - 1u, half = 1u << (cw - 1);
         u32 v = (s.l[0] & mask) + carry;
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ it
             d = 0;
         }
         d = (v == 0) ? kSkip : (d | (v - 1));
-        digits[(size_t)w * ns + i] = d;
+        if (w >= w0) digits[(size_t)(w - w0) * ns + i] = d;
     }
 }
 
@@ -379,6 +381,38 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
     xyzz30_store(out, t, res);
 }
 
+// last step on the device: the c reduced points of every window row (planes T_0..T_{c-2}, then T_all)
+// are rewritten as Jacobian points in the REFERENCE Montgomery form (144 B), so the host chain starts
+// without conversions.  With `pair` the planes are also combined two by two on the way,
+// U_j = T_2j + 2*T_{2j+1} (+ T_all for j = 0), halving the host's additions at the price of a longer
+// device chain (measured: a wash at 2^20).
+// in: [rows][c] XYZZ, out: [rows][nout] Jacobian; nout = c, or max(1, c/2) when pairing.
+__global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void* __restrict__ out, size_t rows, int c, int nout, int pair) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= rows * (size_t)nout) return;
+    const size_t row = t / nout;
+    const int j = (int)(t % nout);
+    Xyzz30 acc;
+    if (!pair) {
+        acc = xyzz30_load(in, row * c + j);
+    } else {
+        const int planes = c - 1;  // T_0 .. T_{c-2}; index c-1 is T_all
+        xyzz30_set_inf(acc);
+        if (2 * j < planes) acc = xyzz30_load(in, row * c + 2 * j);
+        if (j == 0) acc = xyzz30_add(acc, xyzz30_load(in, row * c + (c - 1)));
+        if (2 * j + 1 < planes) acc = xyzz30_add(acc, xyzz30_dbl(xyzz30_load(in, row * c + 2 * j + 1)));
+    }
+    Fq30 X = f30_zero(), Y = f30_zero(), Z = f30_zero();
+    if (!xyzz30_is_inf(acc)) {  // (X*ZZ, Y*ZZZ, ZZ) is a Jacobian representative: x = X*ZZ/ZZ^2, y = Y*ZZZ/ZZ^3
+        X = f30_to_ref(f30_mul(acc.x, acc.zz));
+        Y = f30_to_ref(f30_mul(acc.y, acc.zzz));
+        Z = f30_to_ref(acc.zz);
+    }
+    f30_store(out, t * 144, X);
+    f30_store(out, t * 144 + 48, Y);
+    f30_store(out, t * 144 + 96, Z);
+}
+
 // SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine, packed 96 B), one lane per point.
 // With it every window's digit can use the SAME bucket set (the factor 2^{c w} is in the base).
 __global__ void __launch_bounds__(kBlk) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
@@ -420,7 +454,7 @@ __global__ void __launch_bounds__(kBlk) k_dbg_fq(const void* __restrict__ a, con
                                                int op) {
     for (size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlk) {
         Fq30 x = f30_from_ref(f30_load(a, i * 48)), y = f30_from_ref(f30_load(b, i * 48));
-        Fq30 r = (op == 0) ? f30_add(x, y) : (op == 1) ? f30_sub2(x, y) : f30_mul(x, y);
+        Fq30 r = (op == 0) ? f30_add(x, y) : (op == 1) ? f30_sub2(x, y) : (a == b) ? f30_sqr(x) : f30_mul(x, y);  // same buffer twice: the squaring path
         f30_store(out, i * 48, f30_to_ref(r));
     }
 }
@@ -465,33 +499,43 @@ static zkhost::Jac load_xyzz_host(const uint64_t* p) {
                                zkhost::mul(ZZZ, zkhost::K378()));
 }
 
-// host combine of one item: rows of W x c points (planes T_0..T_{c-2}, T_all per window):
-// result = sum_p 2^p * pos[p] over ~256 bit positions, a doubling chain.  (Splitting the chain over
-// host threads was measured: thread start-up costs what the shorter chain saves.)
-static void combine_item(const uint64_t* h, const WinLayout& L, int c, uint64_t* h_out) {
-    std::vector<zkhost::Jac> pos((size_t)256 + c + 1, zkhost::jac_inf());
-    for (int w = 0; w < L.W; w++) {
-        for (int k = 0; k < c; k++) {
-            zkhost::Jac pt = load_xyzz_host(h + ((size_t)w * c + k) * 24);
+// host combine: per window row `nout` Jacobian points (k_finish) sit at their bit position -- plane k
+// of window w at bit_offset(w) + k, T_all at bit_offset(w); with pairing U_j at bit_offset(w) + 2j --
+// and result = sum_p 2^p * pos[p] is one doubling chain from the top position down.  The chain can be
+// run in pieces: combine_windows() continues `acc` through the positions of windows [w0, w0 + wc),
+// which must be the next lower ones (a class may hold only part of the windows, highest part first).
+// (Splitting the chain over host threads was measured: thread start-up costs what the shorter chain saves.)
+static void combine_windows(zkhost::Jac& acc, const uint64_t* h, const WinLayout& L, int w0, int wc, int c, int nout, bool pair) {
+    const size_t p_lo = (size_t)L.bit_offset(w0);
+    const size_t p_hi = (w0 + wc >= L.W) ? (size_t)256 + c + 2 : (size_t)L.bit_offset(w0 + wc);
+    std::vector<zkhost::Jac> pos(p_hi - p_lo, zkhost::jac_inf());
+    for (int w = 0; w < wc; w++) {
+        for (int j = 0; j < nout; j++) {
+            const uint64_t* src = h + ((size_t)w * nout + j) * 18;
+            zkhost::Jac pt;
+            std::memcpy(pt.x.data(), src, 48);
+            std::memcpy(pt.y.data(), src + 6, 48);
+            std::memcpy(pt.z.data(), src + 12, 48);
             if (zkhost::is_zero(pt.z)) continue;
-            // rows 0..c-2 are planes T_k (weight 2^k); the last row is T_all (weight 1)
-            size_t p = (size_t)L.bit_offset(w) + ((k == c - 1) ? 0 : k);
+            const size_t p = (size_t)L.bit_offset(w0 + w) + (pair ? 2 * (size_t)j : (j == c - 1 ? 0 : (size_t)j)) - p_lo;
             pos[p] = zkhost::jac_add(pos[p], pt);
         }
     }
-    zkhost::Jac acc = zkhost::jac_inf();
     for (size_t p = pos.size(); p-- > 0;) {
-        acc = zkhost::jac_dbl(acc);
-        acc = zkhost::jac_add(acc, pos[p]);
+        acc = zkhost::jac_dbl(acc);  // doubling the identity is free
+        if (!zkhost::is_zero(pos[p].z)) acc = zkhost::jac_add(acc, pos[p]);
     }
-    zkhost::write_normalised(acc, h_out);
 }
 
 struct MsmClass {
     bool shared = false;  // precomputed-table mode: one bucket row per item spanning all windows
-    int rpi = 0;          // bucket rows per item (W, or 1 when shared)
+    int rpi = 0;          // bucket rows per item (the class's windows, or 1 when shared)
     size_t row_len = 0;   // entries per row (ns, or W * ns when shared)
     int c = 0;
+    int w0 = 0, wc = 0;   // the windows [w0, w0 + wc) of the layout this class works on
+    int part = 0, nparts = 1;  // a big class is cut by windows into parts that run staggered (see below)
+    int npair = 0;        // points per window row handed to the host (k_finish)
+    bool pair = false;
     WinLayout L{};
     std::vector<size_t> idx;  // items of the batch in this class
     size_t ns = 0, nb = 0, rows = 0, total = 0, tiles_per_w = 0, total_tiles = 0, chunk_len = 0, cc_elems = 0;
@@ -508,6 +552,8 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
     static const u32 bpb_env = getenv("ZK_MSM_BPB") ? (u32)atoi(getenv("ZK_MSM_BPB")) : 0;
+    static const bool pair_env = getenv("ZK_MSM_PAIR") && atoi(getenv("ZK_MSM_PAIR")) != 0;
+    static const int split_env = getenv("ZK_MSM_SPLIT") ? atoi(getenv("ZK_MSM_SPLIT")) : 1;  // measured on MI355X: no gain (every phase is ALU-bound), off by default
     // ---- validate + classify by window width ----
     std::vector<MsmClass> classes;
     for (size_t k = 0; k < count; k++) {
@@ -534,16 +580,51 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             cl->c = c;
             cl->shared = shared;
             cl->L = msm_layout(c);
+            cl->w0 = 0;
+            cl->wc = cl->L.W;
             cl->nb = (size_t)1 << (c - 1);
+            cl->pair = pair_env;
+            cl->npair = cl->pair ? std::max(1, c / 2) : c;
         }
         cl->idx.push_back(k);
         cl->ns = std::max(cl->ns, (it.n + 3) & ~(size_t)3);
     }
     if (classes.empty()) return ZK_OK;
+    // ---- staggering: a class with enough work is cut by windows into parts (highest windows first).
+    // The accumulation of part k+1 starts when that of part k ends, so the latency-bound tail of part k
+    // (fix-up, bucket reduction, its piece of the host chain) and the sort of part k+1 hide behind the
+    // ALU-bound accumulation; only the last part's tail stays exposed. ----
+    {
+        // (only the class with the most work is cut: one set of part events per ctx)
+        size_t best = 0, best_work = 0;
+        for (size_t i = 0; i < classes.size(); i++) {
+            size_t work = 0;
+            for (size_t k : classes[i].idx) work += items[k].n;
+            if (work > best_work) best_work = work, best = i;
+        }
+        std::vector<MsmClass> cut;
+        for (size_t i = 0; i < classes.size(); i++) {
+            auto& cl = classes[i];
+            const int want_parts = std::min(split_env, (int)zk_ctx::kParts);
+            int parts = (i != best || cl.shared || want_parts < 2 || best_work < ((size_t)1 << 18) || cl.L.W < 2 * want_parts) ? 1 : want_parts;
+            int hi = cl.L.W;
+            for (int part = 0; part < parts; part++) {
+                MsmClass x = cl;
+                const int lo = cl.L.W * (parts - 1 - part) / parts;
+                x.w0 = lo;
+                x.wc = hi - lo;
+                x.part = part;
+                x.nparts = parts;
+                hi = lo;
+                cut.push_back(std::move(x));
+            }
+        }
+        classes.swap(cut);
+    }
     // ---- geometry per class, scratch high-water marks ----
     size_t need[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pinned_bytes = 0;
     for (auto& cl : classes) {
-        const int W = cl.L.W;
+        const int W = cl.wc;
         const size_t nitems = cl.idx.size();
         cl.rpi = cl.shared ? 1 : W;
         cl.row_len = cl.shared ? (size_t)W * cl.ns : cl.ns;
@@ -583,7 +664,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             need[i] += (want_b[i] + 255) & ~(size_t)255;
         }
         cl.pinned_off = pinned_bytes;
-        pinned_bytes += cl.rows * (size_t)cl.c * 192 + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
+        pinned_bytes += ((cl.rows * (size_t)cl.npair * 144 + 255) & ~(size_t)255) + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
     }
     // allocate every arena once, before anything is enqueued (no reallocation between classes)
     static const int slot[9] = {0, 1, 2, 3, 4, 5, 6, 9, 8};
@@ -598,19 +679,20 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 
     // ---- enqueue every class without host synchronisation; independent classes go to separate
-    // streams (the small ones are pure launch/latency chains and overlap with the big one) ----
-    bool first = true;
+    // streams (the small ones are pure launch/latency chains and overlap with the big one).
+    // Phase timers: sort of the first class, accumulation from the first part's launch to the last
+    // part's end, then fix-up / reduction of the last part -- i.e. the exposed time of each phase. ----
     const bool multi = classes.size() > 1;
     if (multi) {
         hipEventRecord(ctx->ev_fork, ctx->stream);
         for (int k = 0; k < zk_ctx::kAux; k++) hipStreamWaitEvent(ctx->aux[k], ctx->ev_fork, 0);
     }
     size_t cls_i = 0;
+    bool any_parts = false;
     for (auto& cl : classes) {
-        const int W = cl.L.W;
         const size_t nitems = cl.idx.size(), ns = cl.ns, nb = cl.nb, total = cl.total;
+        const bool t_first = (cls_i == 0), t_last = (cls_i + 1 == (size_t)classes[0].nparts);  // the first class's parts carry the timers
         hipStream_t st = (!multi || cls_i == 0) ? ctx->stream : ctx->aux[(cls_i - 1) % zk_ctx::kAux];
-        cls_i++;
         u32* digits = (u32*)((char*)buf[0] + cl.off[0]);
         u32* sorted = (u32*)((char*)buf[1] + cl.off[1]);
         u32* counts = (u32*)((char*)buf[2] + cl.off[2]);
@@ -623,7 +705,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         ItemDesc* d_items = (ItemDesc*)((char*)buf[7] + cl.off[7]);
         u32* cc = (u32*)((char*)buf[8] + cl.off[8]);
         uint64_t* h_pts = (uint64_t*)(hpin + cl.pinned_off);
-        ItemDesc* h_items = (ItemDesc*)(hpin + cl.pinned_off + cl.rows * (size_t)cl.c * 192);
+        ItemDesc* h_items = (ItemDesc*)(hpin + cl.pinned_off + ((cl.rows * (size_t)cl.npair * 144 + 255) & ~(size_t)255));
         for (size_t j = 0; j < nitems; j++) {
             const MsmItem& it = items[cl.idx[j]];
             h_items[j].scalars = it.d_scalars;
@@ -631,11 +713,11 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             h_items[j].n = (u32)it.n;
             h_items[j].pstride = cl.shared ? (u32)it.srs->table_stride : 0;
         }
-        if (first) hipEventRecord(ctx->ev[0], st);
+        if (t_first) hipEventRecord(ctx->ev[0], st);
         ZK_HIP(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
         ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
         hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
-                           (const ItemDesc*)d_items, ns, cl.L, digits);
+                           (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, digits);
         hipLaunchKernelGGL((k_sort_pass<false>), dim3((unsigned)(cl.rows * cl.P), cl.nchunks), dim3(kSortThreads), cl.bpb * 4, st,
                            (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, (u32)cl.P, cc, (u32*)nullptr);
         hipLaunchKernelGGL(k_bucket_totals, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)cc, cl.nchunks,
@@ -645,17 +727,19 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
                            total, (const u32*)offsets);
         hipLaunchKernelGGL((k_sort_pass<true>), dim3((unsigned)(cl.rows * cl.P), cl.nchunks), dim3(kSortThreads), cl.bpb * 4, st,
                            (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, (u32)cl.P, cc, sorted);
-        if (first) hipEventRecord(ctx->ev[1], st);
+        if (t_first) hipEventRecord(ctx->ev[1], st);
+        if (cl.part > 0) hipStreamWaitEvent(st, ctx->ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
         hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const u32*)offsets, (const u32*)counts, cl.row_len,
                            (u32)ns, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
-        if (first) hipEventRecord(ctx->ev[4], st);
+        if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(ctx->ev_part[cl.part % zk_ctx::kParts], st);
+        if (t_last) hipEventRecord(ctx->ev[4], st);
         hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
                            (const u32*)counts, nb, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                            longs + 1);
         hipLaunchKernelGGL(k_fixup_long, dim3(512), dim3(kBlk), 0, st, (const u32*)offsets, (const u32*)counts, nb, cl.T,
                            cl.tiles_per_w, bufA, (const void*)heads, (const void*)tails, (const u32*)longs, (const u32*)(longs + 1));
-        if (first) hipEventRecord(ctx->ev[2], st);
+        if (t_last) hipEventRecord(ctx->ev[2], st);
         void* in = bufA;
         void* out = bufB;
         int rows = 1;
@@ -668,11 +752,19 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             rows++;
             len >>= 1;
         }
+        // rows == c reduced points per window row -> Jacobian points in the reference form
+        {
+            const size_t threads = cl.rows * (size_t)cl.npair;
+            hipLaunchKernelGGL(k_finish, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, (const void*)in, out, cl.rows, cl.c, cl.npair, cl.pair ? 1 : 0);
+        }
         ZK_HIP(ctx, hipGetLastError());
-        // rows == c planes per window row
-        ZK_HIP(ctx, hipMemcpyAsync(h_pts, in, cl.rows * (size_t)cl.c * 192, hipMemcpyDeviceToHost, st));
-        if (first) hipEventRecord(ctx->ev[3], st);
-        first = false;
+        ZK_HIP(ctx, hipMemcpyAsync(h_pts, out, cl.rows * (size_t)cl.npair * 144, hipMemcpyDeviceToHost, st));
+        if (t_last) hipEventRecord(ctx->ev[3], st);
+        if (cl.nparts > 1 && cl.part + 1 < cl.nparts) {  // the host starts on this part while the next one runs
+            hipEventRecord(ctx->ev_done[cl.part % zk_ctx::kParts], st);
+            any_parts = true;
+        }
+        cls_i++;
     }
     if (multi) {  // join: later work on the ctx stream is ordered after every class
         for (int k = 0; k < zk_ctx::kAux; k++) {
@@ -680,43 +772,74 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0);
         }
     }
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // ---- host combine: ~255 doublings per item, items in parallel threads ----
-    auto t0 = std::chrono::steady_clock::now();
-    struct Job {
-        const uint64_t* h;
-        const MsmClass* cl;
-        uint64_t* out;
-    };
-    std::vector<Job> jobs;
-    for (auto& cl : classes)
-        for (size_t j = 0; j < cl.idx.size(); j++)
-            jobs.push_back(Job{(const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.rpi * cl.c * 24, &cl, h_out + 18 * cl.idx[j]});
-    auto work = [&](size_t lo, size_t hi) {
+    // ---- host combine: one doubling chain of ~256 steps per item.  Chains of a staggered class are
+    // advanced part by part as the parts arrive (overlapping the device work of the next part); the rest
+    // runs after the join, items in parallel threads. ----
+    std::vector<zkhost::Jac> chain(count, zkhost::jac_inf());
+    float host_ms = 0;
+    auto run_class = [&](const MsmClass& cl, size_t lo, size_t hi) {
+        WinLayout one{1, 0, 0};  // shared buckets: a single row, the window factors live in the table
         for (size_t j = lo; j < hi; j++) {
-            WinLayout one{1, 0, 0};  // shared buckets: a single row, the window factors live in the table
-            combine_item(jobs[j].h, jobs[j].cl->shared ? one : jobs[j].cl->L, jobs[j].cl->c, jobs[j].out);
+            const uint64_t* h = (const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.rpi * cl.npair * 18;
+            if (cl.shared) combine_windows(chain[cl.idx[j]], h, one, 0, 1, cl.c, cl.npair, cl.pair);
+            else combine_windows(chain[cl.idx[j]], h, cl.L, cl.w0, cl.wc, cl.c, cl.npair, cl.pair);
+            if (cl.part + 1 == cl.nparts) zkhost::write_normalised(chain[cl.idx[j]], h_out + 18 * cl.idx[j]);
         }
     };
-    if (jobs.size() == 1) {
-        work(0, 1);
-    } else {
-        size_t nth = std::min<size_t>({jobs.size(), (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)32});
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nth; t++) th.emplace_back(work, jobs.size() * t / nth, jobs.size() * (t + 1) / nth);
-        for (auto& x : th) x.join();
+    struct Job {
+        const MsmClass* cl;
+        size_t j;
+    };
+    auto run_jobs = [&](std::vector<Job>& jobs) {
+        auto t0 = std::chrono::steady_clock::now();
+        auto work = [&](size_t lo, size_t hi) {
+            for (size_t q = lo; q < hi; q++) run_class(*jobs[q].cl, jobs[q].j, jobs[q].j + 1);
+        };
+        if (jobs.size() <= 1) {
+            work(0, jobs.size());
+        } else {
+            size_t nth = std::min<size_t>({jobs.size(), (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)32});
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nth; t++) th.emplace_back(work, jobs.size() * t / nth, jobs.size() * (t + 1) / nth);
+            for (auto& x : th) x.join();
+        }
+        host_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    if (any_parts) {
+        // parts of one class are consecutive in `classes`, highest windows first
+        int max_parts = 1;
+        for (auto& cl : classes) max_parts = std::max(max_parts, cl.nparts);
+        for (int part = 0; part + 1 < max_parts; part++) {
+            std::vector<Job> jobs;
+            for (auto& cl : classes)
+                if (cl.nparts > 1 && cl.part == part && part + 1 < cl.nparts) {
+                    ZK_HIP(ctx, hipEventSynchronize(ctx->ev_done[part % zk_ctx::kParts]));
+                    for (size_t j = 0; j < cl.idx.size(); j++) jobs.push_back(Job{&cl, j});
+                }
+            run_jobs(jobs);
+        }
     }
-    auto t1 = std::chrono::steady_clock::now();
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto t_tail = std::chrono::steady_clock::now();
+    {
+        std::vector<Job> jobs;
+        for (auto& cl : classes)
+            if (cl.part + 1 == cl.nparts)
+                for (size_t j = 0; j < cl.idx.size(); j++) jobs.push_back(Job{&cl, j});
+        host_ms = 0;  // report the exposed part: what runs after the device has finished
+        run_jobs(jobs);
+    }
+    (void)t_tail;
     float ms;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
-    ctx->msm_ms[0] = ms;  // digits + sort
+    ctx->msm_ms[0] = ms;  // digits + sort (first part)
     hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[4]);
-    ctx->msm_ms[1] = ms;  // k_accum_tiles alone (the dominant kernel)
+    ctx->msm_ms[1] = ms;  // k_accum_tiles: first part's launch to last part's end (the dominant kernel)
     hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[2]);
-    ctx->msm_ms[2] = ms;  // fix-up
+    ctx->msm_ms[2] = ms;  // fix-up (last part)
     hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]);
-    ctx->msm_ms[3] = ms;  // bucket reduction + D2H
-    ctx->msm_ms[4] = std::chrono::duration<float, std::milli>(t1 - t0).count();  // host combine
+    ctx->msm_ms[3] = ms;  // bucket reduction + D2H (last part)
+    ctx->msm_ms[4] = host_ms;  // host combine after the device has finished
     ctx->msm_ms[5] = ctx->msm_ms[0] + ctx->msm_ms[1] + ctx->msm_ms[2] + ctx->msm_ms[3] + ctx->msm_ms[4];
     return ZK_OK;
 }

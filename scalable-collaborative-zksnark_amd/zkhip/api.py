@@ -6,12 +6,16 @@ raw integer address.  Host-side results come back as numpy uint64 limb arrays.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
 
 from . import _lib
 from ._lib import ZK_ERR_DIV_ZERO, ZK_ERR_LENGTH
+
+
+_TRACE_MSM = bool(os.environ.get("ZKHIP_TRACE_MSM"))
 
 
 class ZkError(RuntimeError):
@@ -282,6 +286,10 @@ class Ctx:
         if rc == ZK_ERR_LENGTH:
             raise MsmLengthError(rc, (self.lib.zk_last_error(self.h) or b"").decode(), min(n, max(len(srs) - offset, 0)))
         self._check(rc)
+        if _TRACE_MSM:
+            import sys
+
+            print("zkhip-msm", [int(n)], [round(float(x), 3) for x in self.msm_last_timing()], file=sys.stderr)
         return out
 
     def msm_g1_batch(self, srs_list, scalars_list, lens, offsets=None) -> np.ndarray:
@@ -298,6 +306,10 @@ class Ctx:
         if rc == ZK_ERR_LENGTH:
             raise MsmLengthError(rc, (self.lib.zk_last_error(self.h) or b"").decode(), 0)
         self._check(rc)
+        if _TRACE_MSM:  # diagnostics: one line per batch (sizes + the library's phase timers)
+            import sys
+
+            print("zkhip-msm", [int(x) for x in lens], [round(float(x), 3) for x in self.msm_last_timing()], file=sys.stderr)
         return out
 
     def msm_g1_host(self, bases: np.ndarray, scalars: np.ndarray, stride: int = 96) -> np.ndarray:

@@ -14,7 +14,7 @@ from typing import List, Sequence, Tuple
 
 import numpy as np
 
-from .field import R_MOD, fr_from_mont, fr_mont, int_to_limbs
+from .field import R_MOD, fr_from_mont, fr_mont, fr_sum_mont, int_to_limbs
 from .net import Net
 from .pss import PackedSharingParams
 
@@ -148,15 +148,14 @@ def d_sumcheck(be, partial_poly, length: int, challenge: np.ndarray, net: Net) -
     allp = net.all_gather(local)
     if not net.is_leader:
         return np.zeros((0, 2, 4), dtype=np.uint64)
+    head = fr_sum_mont([np.asarray(allp[p])[:n] for p in range(net.n_parties)])  # [n, 2, 4]: per-round sums (:440-447)
     res = []
-    for i in range(n):
-        res.append(tuple(sum(fr_from_mont(allp[p][i][k]) for p in range(net.n_parties)) % R_MOD for k in range(2)))
     v = [fr_from_mont(allp[p][n][1]) for p in range(net.n_parties)]
-    ch = _fr_vec_to_ints(challenge)
-    for i in range(n, n + s):
+    ch = _fr_vec_to_ints(challenge[n : n + s])
+    for i in range(s):
         sm, v = _round_plain(v, ch[i])
         res.append(sm)
-    return _ints_to_fr([x for p in res for x in p]).reshape(-1, 2, 4)
+    return np.concatenate([head.reshape(-1, 2, 4), _ints_to_fr([x for p in res for x in p]).reshape(-1, 2, 4)])
 
 
 def d_sumcheck_product(be, partial_f, partial_g, length: int, challenge: np.ndarray, net: Net) -> np.ndarray:
@@ -168,16 +167,15 @@ def d_sumcheck_product(be, partial_f, partial_g, length: int, challenge: np.ndar
     allp = net.all_gather(local)
     if not net.is_leader:
         return np.zeros((0, 3, 4), dtype=np.uint64)
+    head = fr_sum_mont([np.asarray(allp[p])[:n] for p in range(net.n_parties)])  # [n, 3, 4]
     res = []
-    for i in range(n):
-        res.append(tuple(sum(fr_from_mont(allp[p][i][k]) for p in range(net.n_parties)) % R_MOD for k in range(3)))
     f = [fr_from_mont(allp[p][n][1]) for p in range(net.n_parties)]  # :448
     g = [fr_from_mont(allp[p][n][0]) for p in range(net.n_parties)]  # :449
-    ch = _fr_vec_to_ints(challenge)
-    for i in range(n, n + s):
+    ch = _fr_vec_to_ints(challenge[n : n + s])
+    for i in range(s):
         t, f, g = _round_product(f, g, ch[i])
         res.append(t)
-    return _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)
+    return np.concatenate([head.reshape(-1, 3, 4), _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)])
 
 
 # ---------------------------------------------------------------------------------------

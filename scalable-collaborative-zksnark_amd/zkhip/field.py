@@ -15,12 +15,28 @@ _R_LIMBS = np.array([(R_MOD >> (64 * i)) & _M64 for i in range(4)], dtype=np.uin
 
 
 def int_to_limbs(x: int, n: int) -> np.ndarray:
-    return np.array([(x >> (64 * i)) & _M64 for i in range(n)], dtype=np.uint64)
+    return np.frombuffer(int(x).to_bytes(8 * n, "little"), dtype="<u8").astype(np.uint64)
 
 
 def limbs_to_int(a) -> int:
-    a = np.asarray(a, dtype=np.uint64).reshape(-1)
-    return sum(int(a[i]) << (64 * i) for i in range(a.size))
+    return int.from_bytes(np.ascontiguousarray(a, dtype="<u8").tobytes(), "little")
+
+
+def fr_sum_mont(parts) -> np.ndarray:
+    """
+    sum over axis 0 of Montgomery-form Fr arrays [P, ..., 4] -> [..., 4].  The Montgomery map is
+    linear, so the raw values are added mod r without leaving Montgomery form.
+    """
+    a = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.uint64) for x in parts]), dtype="<u8")
+    shape = a.shape[1:-1]
+    flat = a.reshape(a.shape[0], -1, 4)
+    out = np.empty((flat.shape[1], 4), dtype=np.uint64)
+    for j in range(flat.shape[1]):
+        t = 0
+        for p in range(flat.shape[0]):
+            t += int.from_bytes(flat[p, j].tobytes(), "little")
+        out[j] = int_to_limbs(t % R_MOD, 4)
+    return out.reshape(*shape, 4)
 
 
 def fr_mont(x: int) -> np.ndarray:

@@ -62,10 +62,24 @@ def test_fq_ops(ctx, co):
     b[:, 5] &= np.uint64(0x0FFFFFFFFFFFFFFF)
     a[0] = 0
     b[1] = 0
+    # edge rows: q - 1, 1, and the largest value below q whose 30-bit limbs are all ones where q allows
+    import pyoracle as po
+
+    def limbs6(v):
+        return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]
+
+    for row, v in enumerate((po.Q_MOD - 1, 1, (1 << 380) - 1, po.Q_MOD - (1 << 30), (1 << 360) - 1), start=2):
+        a[row] = limbs6(v)
+        b[row] = limbs6(po.Q_MOD - 1 - row)
     da, db = ctx.to_device(a), ctx.to_device(b)
     for op, ref in (("add", co.fq_add), ("sub", co.fq_sub), ("mul", co.fq_mul)):
         got = ctx.dbg_fq(op, da, db, n).download((n, 6))
         assert (got == ref(a, b)).all(), op
+    # the same buffer as both operands takes the dedicated squaring path
+    got = ctx.dbg_fq("mul", da, da, n).download((n, 6))
+    assert (got == co.fq_mul(a, a)).all()
+    got = ctx.dbg_fq("mul", db, db, n).download((n, 6))
+    assert (got == co.fq_mul(b, b)).all()
 
 
 def test_g1_group_law(ctx, co):
