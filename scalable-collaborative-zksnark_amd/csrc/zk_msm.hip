@@ -32,7 +32,26 @@ namespace zk {
 static constexpr int kBlk = 256;
 static constexpr u32 kSkip = 0xffffffffu;
 
+// The scalar is split with the curve endomorphism (see k_digits): k = k1 + k2*lambda, k1, k2 < 2^128,
+// and the MSM runs over the 2n points P_i, phi(P_i) with 128-bit scalars: half the windows, hence half
+// the buckets to reduce and half the host doubling chain, for the same number of bucket additions.
+static constexpr int kEndoBits = 129;  // 128 bits + room for the carry of the signed recoding
+static constexpr int kFullBits = 256;  // 255-bit scalar + carry (precomputed-table mode)
+
+// window bits for an n-point MSM (2n entries per window after the split).  Up to 2^21 points the
+// measured optimum follows log2(n) - 3, log2(n) - 2 below 2^16 (sweeps in tools/sweep_msm.py); from 2^22 on 19 bits (7 windows
+// instead of 8) saves more bucket additions (10 Fq-mul each, 2n per window) than the ~4x larger bucket
+// reduction (3 x 14 Fq-mul per bucket) costs.
 int msm_pick_window(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    if (lg >= 22) return 19;
+    int c = lg <= 15 ? lg - 2 : lg - 3;  // small MSMs are latency chains: fewer, wider windows
+    if (c < 5) c = 5;
+    if (c > 17) c = 17;
+    return c;
+}
+static int msm_pick_window_full(size_t n) {  // 256-bit layout of the precomputed-table mode
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     int c = lg - 4;
@@ -41,7 +60,7 @@ int msm_pick_window(size_t n) {
     return c;
 }
 
-// Window layout: the 256 bits (255-bit scalar + room for the last carry) are split into W
+// Window layout: the `bits` scalar bits (including room for the last carry) are split into W
 // windows whose widths differ by at most one bit (the first `rem` windows are base+1 wide, the
 // rest base wide, base+1 <= c).  Balanced widths matter: a narrow (or carry-only) top window would
 // funnel ~all points of that window into a handful of buckets.
@@ -50,11 +69,11 @@ struct WinLayout {
     __host__ __device__ int width(int w) const { return base + (w < rem ? 1 : 0); }
     __host__ __device__ int bit_offset(int w) const { return w * base + (w < rem ? w : rem); }
 };
-static WinLayout msm_layout(int c) {
+static WinLayout msm_layout(int c, int bits) {
     WinLayout L;
-    L.W = (256 + c - 1) / c;
-    L.base = 256 / L.W;
-    L.rem = 256 % L.W;
+    L.W = (bits + c - 1) / c;
+    L.base = bits / L.W;
+    L.rem = bits % L.W;
     return L;
 }
 
@@ -66,32 +85,108 @@ struct ItemDesc {
     const void* scalars;
     const void* bases;  // packed 96-B affine points, already offset
     u32 n;
-    u32 pstride;  // 0: one base vector for every window (entry value = point index);
-                  // else: precomputed table, copy w of point i at bases[w * pstride + i]
+    u32 pstride;  // a row holds several copies of the point range: entry v -> bases[(v / ns) * pstride + v % ns]
+                  // (copy 1 = the endomorphism images phi(P_i); precomputed table: copy w = 2^{offset(w)} P_i)
 };
 
-__global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ items, size_t ns, WinLayout L, int w0, int wc,
-                                               u32* __restrict__ digits_all) {
-    // rows are written for the windows [w0, w0 + wc) only (a class may cover a sub-range of the
-    // windows); the lower windows are still walked for the carry of the signed recoding
-    const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
-    if (i >= ns) return;
-    const ItemDesc it = items[blockIdx.y];
-    u32* digits = digits_all + (size_t)blockIdx.y * wc * ns;
-    if (i >= it.n) {  // padding up to the (class-wide) row stride
-        for (int w = 0; w < wc; w++) digits[(size_t)w * ns + i] = kSkip;
-        return;
+// GLV split for BLS12-381 G1: lambda = z^2 - 1 (z the curve parameter) satisfies lambda^2 + lambda + 1 = 0
+// (mod r) and phi(x, y) = (beta*x, y) = lambda*(x, y) on the r-torsion.  k2 = floor(k / lambda) <= lambda + 1,
+// k1 = k - k2*lambda < lambda < 2^128: both halves are non-negative, no lattice rounding needed.
+// The quotient comes from a reciprocal (mu = floor(2^256 / lambda)) on the top 159 bits, short by at
+// most 2, fixed by comparing the remainder with lambda.
+struct Glv {
+    static constexpr u32 LAM(int i) {
+        constexpr u32 t[4] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u};
+        return t[i];
     }
-    Fr s = fp_from_mont<FrCfg>(fr_load(it.scalars, i));
+    static constexpr u32 MU(int i) {
+        constexpr u32 t[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};
+        return t[i];
+    }
+};
+// k (8 limbs, < r) -> k1 (5 limbs, top limb 0), k2 (5 limbs, top limb 0)
+__device__ __forceinline__ void glv_split(const Fr& k, u32 (&k1)[5], u32 (&k2)[5]) {
+    // qh = ((k >> 96) * mu) >> 160
+    u32 prod[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) prod[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            u64 t = (u64)k.l[3 + i] * Glv::MU(j) + prod[i + j] + carry;
+            prod[i + j] = (u32)t;
+            carry = t >> 32;
+        }
+        prod[i + 5] = (u32)carry;
+    }
+    u32 q[5] = {prod[5], prod[6], prod[7], prod[8], 0};
+    // rem = k - q * lambda  (fits 130 bits; computed mod 2^160)
+    u32 ql[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i + j < 5) {
+                u64 t = (u64)q[i] * Glv::LAM(j) + ql[i + j] + carry;
+                ql[i + j] = (u32)t;
+                carry = t >> 32;
+            }
+        }
+        if (i + 4 < 5) ql[i + 4] += (u32)carry;
+    }
+    u32 rem[5];
+    {
+        u32 bw = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            u64 t = (u64)k.l[i] - ql[i] - bw;
+            rem[i] = (u32)t;
+            bw = (u32)(t >> 63);
+        }
+    }
+    for (int it = 0; it < 3; it++) {  // remainder >= lambda: one more lambda goes into the quotient
+        u32 d[5], bw = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            u64 t = (u64)rem[i] - (i < 4 ? Glv::LAM(i) : 0u) - bw;
+            d[i] = (u32)t;
+            bw = (u32)(t >> 63);
+        }
+        if (bw) break;
+#pragma unroll
+        for (int i = 0; i < 5; i++) rem[i] = d[i];
+        u32 c = 1;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            u32 v = q[i] + c;
+            c = (v < c) ? 1u : 0u;
+            q[i] = v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        k1[i] = rem[i];
+        k2[i] = q[i];
+    }
+}
+
+// signed recoding of one (<= 8-limb) value over the windows [0, w0 + wc) of the layout; rows of
+// the windows >= w0 are written at digits[(w - w0) * row_len + pos]
+template <int NL>
+__device__ __forceinline__ void recode_windows(u32 (&s)[NL], const WinLayout& L, int w0, int wc, u32* __restrict__ digits,
+                                               size_t row_len, size_t pos) {
     u32 carry = 0;
     for (int w = 0; w < w0 + wc; w++) {
-        const int cw = L.width(w);  // <= 16
+        const int cw = L.width(w);  // <= 20
         const u32 mask = (1u << cw) - 1u, half = 1u << (cw - 1);
-        u32 v = (s.l[0] & mask) + carry;
+        u32 v = (s[0] & mask) + carry;
         // s >>= cw
 #pragma unroll
-        for (int k = 0; k < 7; k++) s.l[k] = (s.l[k] >> cw) | (s.l[k + 1] << (32 - cw));
-        s.l[7] >>= cw;
+        for (int k = 0; k < NL - 1; k++) s[k] = (s[k] >> cw) | (s[k + 1] << (32 - cw));
+        s[NL - 1] >>= cw;
         u32 d;
         if (v > half) {  // recentre to [-2^(cw-1), 2^(cw-1)]; never triggers in the top window
             v = (1u << cw) - v;
@@ -102,7 +197,35 @@ __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ it
             d = 0;
         }
         d = (v == 0) ? kSkip : (d | (v - 1));
-        if (w >= w0) digits[(size_t)(w - w0) * ns + i] = d;
+        if (w >= w0) digits[(size_t)(w - w0) * row_len + pos] = d;
+    }
+}
+
+// rows are written for the windows [w0, w0 + wc) only (a class may cover a sub-range of the windows);
+// the lower windows are still walked for the carry of the signed recoding.
+// endo: row = [k1 digits of the ns points | k2 digits of the ns points] (entry ns + i refers to phi(P_i)).
+__global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ items, size_t ns, WinLayout L, int w0, int wc, int endo,
+                                               u32* __restrict__ digits_all) {
+    const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (i >= ns) return;
+    const ItemDesc it = items[blockIdx.y];
+    const size_t row_len = endo ? 2 * ns : ns;
+    u32* digits = digits_all + (size_t)blockIdx.y * wc * row_len;
+    if (i >= it.n) {  // padding up to the (class-wide) row stride
+        for (int w = 0; w < wc; w++) {
+            digits[(size_t)w * row_len + i] = kSkip;
+            if (endo) digits[(size_t)w * row_len + ns + i] = kSkip;
+        }
+        return;
+    }
+    Fr s = fp_from_mont<FrCfg>(fr_load(it.scalars, i));
+    if (endo) {
+        u32 k1[5], k2[5];
+        glv_split(s, k1, k2);
+        recode_windows<5>(k1, L, w0, wc, digits, row_len, i);
+        recode_windows<5>(k2, L, w0, wc, digits, row_len, ns + i);
+    } else {
+        recode_windows<8>(s.l, L, w0, wc, digits, row_len, i);
     }
 }
 
@@ -182,46 +305,52 @@ __global__ void __launch_bounds__(kBlk) k_chunk_offsets(u32* __restrict__ cc, u3
     }
 }
 
-// exclusive scan of counts[row][0..nb) -> offsets.  One block per row; the row is staged in LDS in
-// tiles of kScanTile counters (coalesced global loads/stores, the serial part runs out of LDS).
+// exclusive scan of the bucket counts of every row.  One workgroup per (row, segment of kScanTile
+// counters): it first adds up the counters of the earlier segments of its row (redundant coalesced reads
+// out of L2, at most nb of them) and then scans its own segment in LDS -- a single launch with
+// rows * nb / kScanTile workgroups instead of a chain of dependent ones.
 static constexpr int kScanThreads = 1024;
-static constexpr int kScanTile = 16384;
+static constexpr int kScanTile = 4096;
 __global__ void __launch_bounds__(kScanThreads) k_scan(const u32* __restrict__ counts, size_t nb, u32* __restrict__ offsets) {
     __shared__ u32 tile[kScanTile];
     __shared__ u32 part[kScanThreads];
-    __shared__ u32 carry_s;
     const int tid = threadIdx.x;
-    const u32* src = counts + (size_t)blockIdx.x * nb;
-    u32* dst = offsets + (size_t)blockIdx.x * nb;
-    if (tid == 0) carry_s = 0;
+    const size_t row = blockIdx.x, t0 = (size_t)blockIdx.y * kScanTile;
+    const u32* src = counts + row * nb;
+    u32* dst = offsets + row * nb;
+    const size_t len = (nb - t0 < (size_t)kScanTile) ? nb - t0 : (size_t)kScanTile;
+    // sum of the earlier segments
+    u32 pre = 0;
+    for (size_t i = tid; i < t0; i += kScanThreads) pre += src[i];
+    part[tid] = pre;
+    for (size_t i = tid; i < len; i += kScanThreads) tile[i] = src[t0 + i];
     __syncthreads();
-    for (size_t t0 = 0; t0 < nb; t0 += kScanTile) {
-        const size_t len = (nb - t0 < (size_t)kScanTile) ? nb - t0 : (size_t)kScanTile;
-        for (size_t i = tid; i < len; i += kScanThreads) tile[i] = src[t0 + i];
-        __syncthreads();
-        const size_t per = (len + kScanThreads - 1) / kScanThreads;
-        const size_t lo = (size_t)tid * per, hi = (lo + per < len) ? lo + per : len;
-        u32 s = 0;
-        for (size_t i = lo; i < hi; i++) s += tile[i];
-        part[tid] = s;
-        __syncthreads();
-        for (int off = 1; off < kScanThreads; off <<= 1) {  // Hillis-Steele over the per-thread sums
-            u32 v = (tid >= off) ? part[tid - off] : 0u;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        u32 run = carry_s + part[tid] - s;  // exclusive prefix of this thread's slice
-        for (size_t i = lo; i < hi; i++) {
-            u32 v = tile[i];
-            tile[i] = run;
-            run += v;
-        }
-        __syncthreads();
-        for (size_t i = tid; i < len; i += kScanThreads) dst[t0 + i] = tile[i];
-        if (tid == kScanThreads - 1) carry_s += part[tid];
+    for (int off = kScanThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
         __syncthreads();
     }
+    const u32 carry = part[0];
+    __syncthreads();
+    const size_t per = (len + kScanThreads - 1) / kScanThreads;
+    const size_t lo = (size_t)tid * per < len ? (size_t)tid * per : len, hi = (lo + per < len) ? lo + per : len;
+    u32 sum = 0;
+    for (size_t i = lo; i < hi; i++) sum += tile[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < kScanThreads; off <<= 1) {  // Hillis-Steele over the per-thread sums
+        u32 v = (tid >= off) ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = carry + part[tid] - sum;  // exclusive prefix of this thread's slice
+    for (size_t i = lo; i < hi; i++) {
+        u32 v = tile[i];
+        tile[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    for (size_t i = tid; i < len; i += kScanThreads) dst[t0 + i] = tile[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -241,8 +370,8 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
     const size_t w = g / tiles_per_w, t = g % tiles_per_w;  // w = row
     const ItemDesc it = items[w / rows_per_item];
     const void* __restrict__ bases = it.bases;
-    // entry value v = index inside the row; with a precomputed table the row spans all windows:
-    // window = v / nsi, point = v % nsi  ->  table index window * pstride + point
+    // entry value v = index inside the row; a row spans `copies` images of the point range:
+    // copy = v / nsi, point = v % nsi  ->  base index copy * pstride + point
     auto pidx = [&](u32 v) -> size_t {
         v &= 0x7fffffffu;
         if (it.pstride == 0) return v;
@@ -449,6 +578,22 @@ __global__ void __launch_bounds__(kBlk) k_srs_convert(const void* __restrict__ i
     }
 }
 
+// second half of the device SRS: phi(P_i) = (beta * x_i, y_i) (infinity stays infinity: beta * 0 = 0)
+__global__ void __launch_bounds__(kBlk) k_srs_endo(void* __restrict__ bases, size_t n) {
+    Fq30 beta;
+    {
+        constexpr u32 t[13] = {0x1c907181u, 0x3cbde486u, 0x26574c3eu, 0x332475ecu, 0x1c3ebc1bu, 0x39ee6864u, 0x16ffa856u,
+                               0x2c3499ffu, 0x0550bd16u, 0x14cbac30u, 0x17d18c86u, 0x215959f7u, 0x0009c6d4u};
+#pragma unroll
+        for (int i = 0; i < 13; i++) beta.l[i] = t[i];
+    }
+    for (size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlk) {
+        Aff30 p = aff30_load(bases, i);
+        f30_store(bases, (n + i) * 96, f30_canon8(f30_mul(p.x, beta)));
+        f30_store(bases, (n + i) * 96 + 48, p.y);
+    }
+}
+
 // test hooks: field ops on reference-form Fq vectors through the production (unsaturated) arithmetic
 __global__ void __launch_bounds__(kBlk) k_dbg_fq(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ out, size_t n,
                                                int op) {
@@ -507,7 +652,7 @@ static zkhost::Jac load_xyzz_host(const uint64_t* p) {
 // (Splitting the chain over host threads was measured: thread start-up costs what the shorter chain saves.)
 static void combine_windows(zkhost::Jac& acc, const uint64_t* h, const WinLayout& L, int w0, int wc, int c, int nout, bool pair) {
     const size_t p_lo = (size_t)L.bit_offset(w0);
-    const size_t p_hi = (w0 + wc >= L.W) ? (size_t)256 + c + 2 : (size_t)L.bit_offset(w0 + wc);
+    const size_t p_hi = (w0 + wc >= L.W) ? (size_t)L.bit_offset(L.W - 1) + L.width(L.W - 1) + c + 2 : (size_t)L.bit_offset(w0 + wc);
     std::vector<zkhost::Jac> pos(p_hi - p_lo, zkhost::jac_inf());
     for (int w = 0; w < wc; w++) {
         for (int j = 0; j < nout; j++) {
@@ -530,7 +675,8 @@ static void combine_windows(zkhost::Jac& acc, const uint64_t* h, const WinLayout
 struct MsmClass {
     bool shared = false;  // precomputed-table mode: one bucket row per item spanning all windows
     int rpi = 0;          // bucket rows per item (the class's windows, or 1 when shared)
-    size_t row_len = 0;   // entries per row (ns, or W * ns when shared)
+    size_t row_len = 0;   // entries per row: 2 * ns (points and their endomorphism images), or W * ns when shared
+    int copies = 2;
     int c = 0;
     int w0 = 0, wc = 0;   // the windows [w0, w0 + wc) of the layout this class works on
     int part = 0, nparts = 1;  // a big class is cut by windows into parts that run staggered (see below)
@@ -545,7 +691,8 @@ struct MsmClass {
     size_t off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets of this class inside the scratch arenas
 };
 
-static int quantised_window(int c) { return c <= 4 ? 4 : 4 + 3 * ((c - 4 + 2) / 3); }
+// batches group their items into a few window classes: 5, 8, 11, 14, 17 bits (rounded up), then 19
+static int quantised_window(int c) { return c <= 5 ? 5 : (c > 17 ? 19 : 5 + 3 * ((c - 5 + 2) / 3)); }
 
 int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) {
     if (!h_out && count) return fail(ctx, ZK_ERR_INVALID, "null argument");
@@ -562,14 +709,14 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         if (it.offset + it.n > it.srs->n)
             return fail(ctx, ZK_ERR_LENGTH, "msm: %zu scalars but only %zu bases from offset %zu", it.n,
                         it.srs->n - std::min(it.offset, it.srs->n), it.offset);
-        if (it.n >= ((size_t)1 << 31)) return fail(ctx, ZK_ERR_INVALID, "msm: n too large");
+        if (it.n >= ((size_t)1 << 30)) return fail(ctx, ZK_ERR_INVALID, "msm: n too large");  // 2n row entries, 31-bit indices
         if (it.n == 0) {
             zkhost::write_normalised(zkhost::jac_inf(), h_out + 18 * k);
             continue;
         }
+        const bool shared = it.srs->d_table != nullptr && ctx->msm_window_override <= 0;
         int c = ctx->msm_window_override > 0 ? ctx->msm_window_override : msm_pick_window(it.n);
         if (count > 1 && ctx->msm_window_override <= 0) c = quantised_window(c);
-        const bool shared = it.srs->d_table != nullptr && ctx->msm_window_override <= 0;
         if (shared) c = it.srs->table_c;
         MsmClass* cl = nullptr;
         for (auto& x : classes)
@@ -579,7 +726,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             cl = &classes.back();
             cl->c = c;
             cl->shared = shared;
-            cl->L = msm_layout(c);
+            cl->L = msm_layout(c, shared ? kFullBits : kEndoBits);
             cl->w0 = 0;
             cl->wc = cl->L.W;
             cl->nb = (size_t)1 << (c - 1);
@@ -627,7 +774,8 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         const int W = cl.wc;
         const size_t nitems = cl.idx.size();
         cl.rpi = cl.shared ? 1 : W;
-        cl.row_len = cl.shared ? (size_t)W * cl.ns : cl.ns;
+        cl.copies = cl.shared ? W : 2;
+        cl.row_len = (size_t)cl.copies * cl.ns;
         cl.rows = nitems * cl.rpi;
         cl.total = cl.rows * cl.nb;
         size_t nmax = 0;
@@ -636,19 +784,22 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         // for small MSMs balance the serial chain of a lane (T mixed adds, ~10 Fq-mul each) against
         // the fix-up chain of a bucket (entries_per_bucket / T full adds, ~14 Fq-mul each)
         cl.T = 32;
-        const double per_bucket = (double)nmax * (cl.shared ? W : 1) / (double)cl.nb;
-        if ((size_t)nitems * W * nmax / 32 < (size_t)ctx->cu_count * 4 * 64 * 2) {
+        const double per_bucket = (double)nmax * cl.copies / (double)cl.nb;
+        if ((size_t)nitems * cl.rpi * cl.copies * nmax / 32 < (size_t)ctx->cu_count * 4 * 64 * 2) {
             cl.T = 4;
             while (cl.T < 32 && (double)cl.T * cl.T < 1.4 * per_bucket) cl.T <<= 1;
-        } else if (cl.shared) {
-            // long buckets (every window lands in the same row): longer tiles keep the fix-up chain short
-            while (cl.T < 128 && (double)cl.T * 4 < per_bucket && (size_t)nitems * W * nmax / (2 * cl.T) >= (size_t)ctx->cu_count * 4 * 64 * 2) cl.T <<= 1;
+        } else {
+            // long buckets: longer tiles keep the fix-up chain (tiles per bucket) at 2-3 while there are
+            // still several waves of lanes per SIMD
+            while (cl.T < 1024 && (double)cl.T * 2 <= per_bucket &&
+                   (size_t)nitems * cl.rpi * cl.copies * nmax / (2 * cl.T) >= (size_t)ctx->cu_count * 4 * 64 * 2 * 4)
+                cl.T <<= 1;
         }
         if (T_env) cl.T = T_env;
         cl.tiles_per_w = (cl.row_len + cl.T - 1) / cl.T;
         cl.total_tiles = cl.tiles_per_w * cl.rows;
-        // sort geometry: rows x chunks x bucket ranges; LDS counters <= 64 KiB per block
-        cl.bpb = (u32)std::min<size_t>(cl.nb, bpb_env ? bpb_env : 16384);
+        // sort geometry: rows x chunks x bucket ranges; LDS counters <= 128 KiB per block
+        cl.bpb = (u32)std::min<size_t>(cl.nb, bpb_env ? bpb_env : 32768);
         cl.P = (unsigned)(cl.nb / cl.bpb);
         size_t want = 512 / (cl.rows * cl.P);
         cl.nchunks = (u32)std::max<size_t>(1, std::min<size_t>(want ? want : 1, (cl.row_len + 8191) / 8192));
@@ -711,18 +862,18 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             h_items[j].scalars = it.d_scalars;
             h_items[j].bases = (const char*)(cl.shared ? it.srs->d_table : it.srs->d_bases) + it.offset * 96;
             h_items[j].n = (u32)it.n;
-            h_items[j].pstride = cl.shared ? (u32)it.srs->table_stride : 0;
+            h_items[j].pstride = cl.shared ? (u32)it.srs->table_stride : (u32)it.srs->n;  // phi(P_i) sits n points after P_i
         }
         if (t_first) hipEventRecord(ctx->ev[0], st);
         ZK_HIP(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
         ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
         hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
-                           (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, digits);
+                           (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, cl.shared ? 0 : 1, digits);
         hipLaunchKernelGGL((k_sort_pass<false>), dim3((unsigned)(cl.rows * cl.P), cl.nchunks), dim3(kSortThreads), cl.bpb * 4, st,
                            (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, (u32)cl.P, cc, (u32*)nullptr);
         hipLaunchKernelGGL(k_bucket_totals, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)cc, cl.nchunks,
                            nb, cl.bpb, total, counts);
-        hipLaunchKernelGGL(k_scan, dim3((unsigned)cl.rows), dim3(kScanThreads), 0, st, (const u32*)counts, nb, offsets);
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)cl.rows, (unsigned)((nb + kScanTile - 1) / kScanTile)), dim3(kScanThreads), 0, st, (const u32*)counts, nb, offsets);
         hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, cc, cl.nchunks, nb, cl.bpb,
                            total, (const u32*)offsets);
         hipLaunchKernelGGL((k_sort_pass<true>), dim3((unsigned)(cl.rows * cl.P), cl.nchunks), dim3(kSortThreads), cl.bpb * 4, st,
@@ -858,6 +1009,11 @@ static void srs_convert(zk_ctx* ctx, const void* in, void* out, size_t npoints, 
     hipLaunchKernelGGL(k_srs_convert, dim3((unsigned)blocks), dim3(kBlk), 0, ctx->stream, in, out, ncoord, to_internal ? 1 : 0);
 }
 
+static void srs_endo(zk_ctx* ctx, zk_srs* s) {
+    size_t blocks = std::min<size_t>((s->n + kBlk - 1) / kBlk, (size_t)ctx->cu_count * 8);
+    if (blocks) hipLaunchKernelGGL(k_srs_endo, dim3((unsigned)blocks), dim3(kBlk), 0, ctx->stream, s->d_bases, s->n);
+}
+
 // The device copy of an SRS is kept in the kernels' INTERNAL form (Montgomery radix 2^390, see
 // fq30.cuh): one conversion pass at registration, like the reference's own `mature()` step.
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out) {
@@ -868,7 +1024,7 @@ int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs**
     s->n = n;
     s->owned = true;
     if (n) {
-        ZK_HIP(ctx, hipMalloc(&s->d_bases, n * 96));
+        ZK_HIP(ctx, hipMalloc(&s->d_bases, 2 * n * 96));  // P_i, then phi(P_i)
         if (stride == 96) {
             ZK_HIP(ctx, hipMemcpyAsync(s->d_bases, h_bases, n * 96, hipMemcpyHostToDevice, ctx->stream));
             ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -882,6 +1038,7 @@ int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs**
             ZK_HIP(ctx, hipMemcpy(s->d_bases, packed.data(), n * 96, hipMemcpyHostToDevice));
         }
         srs_convert(ctx, s->d_bases, s->d_bases, n, true);
+        srs_endo(ctx, s);
         ZK_HIP(ctx, hipGetLastError());
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -895,8 +1052,9 @@ int srs_from_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out) 
     s->n = n;
     s->owned = true;
     if (n) {
-        ZK_HIP(ctx, hipMalloc(&s->d_bases, n * 96));
+        ZK_HIP(ctx, hipMalloc(&s->d_bases, 2 * n * 96));  // P_i, then phi(P_i)
         srs_convert(ctx, d_bases96, s->d_bases, n, true);
+        srs_endo(ctx, s);
         ZK_HIP(ctx, hipGetLastError());
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -928,7 +1086,7 @@ int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t 
 
 int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     if (!srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
-    if (c == 0) c = msm_pick_window(srs->n ? srs->n : 1);
+    if (c == 0) c = msm_pick_window_full(srs->n ? srs->n : 1);
     if (c < 2 || c > 20) return fail(ctx, ZK_ERR_INVALID, "window bits out of range");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     if (srs->d_table) {
@@ -937,7 +1095,7 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
         srs->d_table = nullptr;
     }
     if (srs->n == 0) return ZK_OK;
-    const WinLayout L = msm_layout(c);
+    const WinLayout L = msm_layout(c, kFullBits);
     const size_t nsr = (srs->n + 3) & ~(size_t)3;
     ZK_HIP(ctx, hipMalloc(&srs->d_table, (size_t)L.W * nsr * 96));
     ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * 96, ctx->stream));

@@ -58,6 +58,40 @@ def test_msm_edge_cases(ctx, co):
     assert (jac_norm_to_affine(ctx.msm_g1(srs, ctx.to_device(same), n)) == co.msm_g1(bases, same)).all()
 
 
+def test_msm_endomorphism_split_boundaries(ctx, co):
+    """
+    The library splits every scalar as k = k1 + k2*lambda (lambda = z^2 - 1) and runs on P_i, phi(P_i):
+    scalars sitting on the boundaries of that split (multiples of lambda, quotient / remainder extremes,
+    carries of the signed recoding at 2^127 / 2^128) must still give the oracle's point.
+    """
+    import pyoracle as po
+
+    lam = 0xAC45A4010001A40200000000FFFFFFFF
+    r = po.R_MOD
+    assert (lam * lam + lam + 1) % r == 0
+    special = [0, 1, 2, lam - 1, lam, lam + 1, 2 * lam - 1, 2 * lam, lam * lam % r, (lam * lam - 1) % r, r - 1, r - 2, r - lam,
+               r - lam - 1, (r // lam) * lam, (r // lam) * lam - 1, (1 << 127) - 1, 1 << 127, (1 << 127) + 1, (1 << 128) - 1, 1 << 128,
+               (1 << 128) + 1, (lam << 127) % r, (1 << 254), r >> 1, (r >> 1) + 1, lam * ((1 << 127) - 1) % r,
+               ((1 << 128) - 1) * lam % r, (lam - 1) + (lam) * lam if (lam - 1) + lam * lam < r else lam - 1]
+    n = len(special)
+    bases, _ = synthetic_bases(n, 191)
+    scalars = np.array([po.fr_to_mont_limbs(v % r) for v in special], dtype=np.uint64)
+    srs = ctx.srs_register(bases)
+    d = ctx.to_device(scalars)
+    exp = co.msm_g1(bases, scalars)
+    for c in (0, 5, 9, 13, 16, 17):
+        ctx.msm_set_window(c)
+        try:
+            got = ctx.msm_g1(srs, d, n)
+        finally:
+            ctx.msm_set_window(0)
+        assert (jac_norm_to_affine(got) == exp).all(), c
+    # one scalar at a time: the point itself is checked, not just the sum
+    for i in range(n):
+        got = ctx.msm_g1(srs, ctx.to_device(scalars[i : i + 1]), 1, offset=i)
+        assert (jac_norm_to_affine(got) == co.msm_g1(bases[i : i + 1], scalars[i : i + 1])).all(), hex(special[i])
+
+
 def test_msm_host_dropin_and_length_error(ctx, co):
     import zkhip
 
