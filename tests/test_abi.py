@@ -54,6 +54,6 @@ def test_status_codes_and_version():
 
     lib = zkhip.lib()
     assert lib.zk_version().startswith(b"zkhip")
-    assert lib.zk_msm_window(1 << 20) == 16
+    assert lib.zk_msm_window(1 << 20) == 17  # 129-bit scalar halves: 8 windows of 16-17 bits
     h = ctypes.c_void_p()
     assert lib.zk_ctx_create(0, None) == zkhip._lib.ZK_ERR_INVALID
