@@ -28,7 +28,7 @@ import numpy as np  # noqa: E402
 
 LOG2_N = 20
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-FQ_MUL_PEAK = 60.0e9  # measured Fq Montgomery mul/s, whole chip (profiles/r01_ubench_int_alu.txt)
+FQ_MUL_PEAK = 80.0e9  # measured Fq multiplier rate (13x30-bit limbs, csrc/fq30.cuh) at the kernel's 2 waves/SIMD, whole chip (profiles/r01_ubench_mul30.txt)
 FR_MUL_PEAK = 133.0e9  # measured Fr Montgomery mul/s
 
 
@@ -161,8 +161,8 @@ def main():
     alg_bytes = 128.0 * n  # 96-B affine point + 32-B scalar per scalar-mul, read once
     achieved = alg_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
     c = ctx.lib.zk_msm_window(n)
-    windows = (255 + c - 1) // c
-    fq_mul_equiv = n * windows * 10.0  # one XYZZ mixed add (8M + 2S) per point per window
+    windows = (129 + c - 1) // c  # scalars are split into two 128-bit halves (k = k1 + k2*lambda): 2n entries per window
+    fq_mul_equiv = 2.0 * n * windows * 10.0  # one XYZZ mixed add (8M + 2S) per entry per window
     out = {
         "metric": "G1 scalar-muls/sec (d_msm) + Fr field-ops/sec (d_sumcheck), 2^20 shares, 1/2/4/8 GPU",
         "value": value,
@@ -182,6 +182,8 @@ def main():
             "parties": world,
             "exchange": "none" if world == 1 else ("d_msm all-gather + PSS unpack2/pack map" if world == 8 else "all-gather only (partial party set)"),
             "pippenger_window_bits": c,
+            "windows": windows,
+            "entries_per_window": 2 * n,
         },
         "msm_phase_ms": {"digits_sort": float(phase[0]), "k_accum_tiles": accum_ms, "fixup": float(phase[2]), "bucket_reduce": float(phase[3]), "host_combine": float(phase[4])},
         "roofline": {

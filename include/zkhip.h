@@ -113,7 +113,10 @@ int zk_product_tree(zk_ctx *ctx, const void *d_x, size_t N, void *d_tree);
 
 /* ---- G1 MSM -------------------------------------------------------------------------- */
 /* Upload a base vector once (the reference clones powers_of_g[level] per call, dpoly_comm.rs:258).
- * h_bases: n affine points at `stride` bytes (96 or 104); stored on device packed at 96 B. */
+ * h_bases: n affine points at `stride` bytes (96 or 104).  The device copy is the library's own:
+ * packed at 96 B in its internal Montgomery form, followed by the endomorphism images (beta*x, y) of
+ * every point (2 * n * 96 bytes).  Bases must lie in the prime-order subgroup, as arkworks' G1Affine
+ * guarantees: the MSM splits scalars as k1 + k2*lambda and phi = [lambda] holds only there. */
 int zk_srs_register(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n, zk_srs **out);
 /* Same from a device buffer in the packed 96-B reference layout.  The library keeps its own copy in
  * its internal Montgomery form (one conversion pass); the caller's buffer is not referenced afterwards. */
@@ -159,12 +162,13 @@ int zk_g1_lincomb(zk_ctx *ctx, const uint64_t *h_points, const uint64_t *h_scala
  * (the per-proof-element sums of d_open, dpoly_comm.rs:372-376); inversions are batched. */
 int zk_g1_lincomb_batch(zk_ctx *ctx, const uint64_t *h_points, const uint64_t *h_scalars, size_t n,
                         size_t count, uint64_t *h_out);
-/* window size (bits) the device Pippenger picks for n points; 0 < override <= 20 forces it */
+/* window size (bits) the device Pippenger picks for n points (2n entries of 128-bit half scalars per
+ * window, ceil(129 / bits) windows); 0 < override <= 20 forces it */
 int zk_msm_window(size_t n);
 int zk_msm_set_window(zk_ctx *ctx, int c_override);
 /* per-phase time of the last zk_msm_g1 (first window class of a batch) on this ctx, in ms, HIP
  * events on the ctx stream: [0] digits+sort, [1] k_accum_tiles (bucket accumulation kernel alone),
- * [2] fix-up, [3] bucket reduction + D2H, [4] host combine (wall), [5] total */
+ * [2] fix-up, [3] bucket reduction + conversion + D2H, [4] host combine (wall), [5] total */
 int zk_msm_last_timing(zk_ctx *ctx, float h_ms[6]);
 
 /* ---- test hooks (used by tests/ only; stable but not part of the drop-in surface) --- */

@@ -3,6 +3,7 @@
 // Value bounds (multiples of q) are invariants of the representation, documented per formula:
 //   affine SRS points:  x, y < q (canonical, internal Montgomery form 2^390)
 //   XYZZ points:        X < 8q, Y < 4q, ZZ < 2q, ZZZ < 2q   (in registers and in HBM; 8q < 2^384)
+//   (HBM layout of XYZZ arrays: blocks of 64 points, see xyzz30_load)
 // Every product below has input bounds multiplying to <= 256, hence result < 2q (fq30.cuh).
 // Infinity = all limbs of ZZ exactly zero (only ever produced by explicit assignment).
 #pragma once
@@ -31,15 +32,49 @@ __device__ __forceinline__ Aff30 aff30_load(const void* base, size_t idx) {
     p.y = f30_load(base, idx * 96 + 48);
     return p;
 }
+// XYZZ arrays (buckets, tile heads/tails, reduction rows) are stored in blocks of 64 points, 16-byte
+// chunk k (0..11, three per coordinate) of the 64 points side by side: chunk k of point i lives at byte
+// (i / 64) * 12288 + k * 1024 + (i % 64) * 16.  Lanes that walk consecutive points -- the fix-up, every
+// reduction pass, the head / tail stores of the accumulation -- then move 1 KiB contiguous per load or
+// store instruction instead of 64 pieces 192 B apart.  Arrays are allocated in multiples of 64 points.
+__device__ __forceinline__ size_t xyzz30_chunk_off(size_t idx, int k) { return (idx >> 6) * 12288 + (size_t)k * 1024 + (idx & 63) * 16; }
+__device__ __forceinline__ Fq30 f30_load_chunks(const void* base, size_t idx, int k0) {
+    const char* b = reinterpret_cast<const char*>(base);
+    u32 w[12];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uint4 v = *reinterpret_cast<const uint4*>(b + xyzz30_chunk_off(idx, k0 + i));
+        w[4 * i] = v.x;
+        w[4 * i + 1] = v.y;
+        w[4 * i + 2] = v.z;
+        w[4 * i + 3] = v.w;
+    }
+    return f30_from_words(w);
+}
+__device__ __forceinline__ void f30_store_chunks(void* base, size_t idx, int k0, const Fq30& a) {
+    char* b = reinterpret_cast<char*>(base);
+    u32 w[12];
+    f30_to_words(a, w);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        *reinterpret_cast<uint4*>(b + xyzz30_chunk_off(idx, k0 + i)) = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
 __device__ __forceinline__ Xyzz30 xyzz30_load(const void* base, size_t idx) {
     Xyzz30 p;
-    p.x = f30_load(base, idx * 192);
-    p.y = f30_load(base, idx * 192 + 48);
-    p.zz = f30_load(base, idx * 192 + 96);
-    p.zzz = f30_load(base, idx * 192 + 144);
+    p.x = f30_load_chunks(base, idx, 0);
+    p.y = f30_load_chunks(base, idx, 3);
+    p.zz = f30_load_chunks(base, idx, 6);
+    p.zzz = f30_load_chunks(base, idx, 9);
     return p;
 }
 __device__ __forceinline__ void xyzz30_store(void* base, size_t idx, const Xyzz30& p) {
+    f30_store_chunks(base, idx, 0, p.x);
+    f30_store_chunks(base, idx, 3, p.y);
+    f30_store_chunks(base, idx, 6, p.zz);
+    f30_store_chunks(base, idx, 9, p.zzz);
+}
+// plain 192-byte records (test hook output read by the host)
+__device__ __forceinline__ void xyzz30_store_flat(void* base, size_t idx, const Xyzz30& p) {
     f30_store(base, idx * 192, p.x);
     f30_store(base, idx * 192 + 48, p.y);
     f30_store(base, idx * 192 + 96, p.zz);

@@ -1,19 +1,23 @@
 // zk_msm.hip -- G1 multi-scalar multiplication on gfx950: the `G::msm(bases, scalars)` call of
 // d_msm (dist-primitive/src/dmsm.rs:23) and of commit/open (dpoly_comm.rs:242,274,457).
 //
-// Pipeline (signed-digit Pippenger, window c, W windows, nb = 2^(c-1) buckets per window):
-//   1 k_digits   scalars out of Montgomery form (as ark `into_bigint`), signed c-bit digits,
-//                per-(window,bucket) histogram                           [coalesced 32-B reads]
-//   2 k_scan     exclusive scan of the histogram per window
-//   3 k_scatter  counting sort: point indices grouped by bucket          [atomics-free adds later]
-//   4 k_accum    one lane per bucket walks its run, gathers 96-B affine bases from HBM and
-//                accumulates with XYZZ mixed adds (8M+2S)                [the dominant kernel]
-//   5 k_halve    bucket reduction WITHOUT the serial running sum: sum_b b*B_b is split into
-//                bit planes.  Each pass pairs neighbours (L[2j]+L[2j+1]) and peels the odd
-//                elements off as a new row whose plain sum is the plane T_k; rows keep halving.
-//                After c-1 passes every window is down to c points (T_0..T_{c-2}, T_all).
-//   6 host       sum_w 2^{cw} (T_all + sum_k 2^k T_k): ~255 doublings, a pure dependency chain
-//                (host_curve.hpp), then normalisation to affine.
+// Pipeline (signed-digit Pippenger over the 2n points P_i, phi(P_i) with 128-bit scalar halves;
+// window c, W = ceil(129 / c) windows, nb = 2^(c-1) buckets per window):
+//   1 k_digits        scalars out of Montgomery form (as ark `into_bigint`), GLV split k = k1 + k2*lambda,
+//                     signed digits of both halves                            [coalesced 32-B reads]
+//   2 k_sort_pass<0>, k_bucket_totals, k_scan, k_chunk_offsets, k_sort_pass<1>
+//                     chunked counting sort, counters in LDS: entries grouped by bucket
+//   3 k_accum_tiles   every lane walks T consecutive sorted entries, gathers 96-B affine bases from
+//                     HBM and accumulates with XYZZ mixed adds (8M+2S)        [the dominant kernel]
+//   4 k_fixup(_long)  stitches the buckets cut by tile boundaries
+//   5 k_halve         bucket reduction WITHOUT the serial running sum: sum_b b*B_b is split into
+//                     bit planes.  Each pass pairs neighbours (L[2j]+L[2j+1]) and peels the odd
+//                     elements off as a new row whose plain sum is the plane T_k; rows keep halving.
+//                     After c-1 passes every window is down to c points (T_0..T_{c-2}, T_all).
+//   6 k_finish        those points as Jacobian coordinates in the reference Montgomery form
+//   7 host            sum_w 2^{o_w} (T_all + sum_k 2^k T_k): ~129 doublings, a pure dependency chain
+//                     (host_curve.hpp), then normalisation to affine.
+// Field arithmetic: csrc/fq30.cuh (13 x 30-bit limbs, Montgomery radix 2^390, lazy reduction).
 // All additions are exact group operations, so the affine result is independent of the
 // (non-deterministic) order in which the sort places points inside a bucket.
 #include "curve30.cuh"
@@ -627,7 +631,7 @@ __global__ void __launch_bounds__(kBlk) k_dbg_g1(const void* __restrict__ p, con
     } else if (mode == 2) {  // (p+q) + (p+q): doubling path of the full addition
         r = xyzz30_add(s, s);
     }
-    xyzz30_store(out, i, r);
+    xyzz30_store_flat(out, i, r);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -807,8 +811,9 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         cl.nchunks = (u32)((cl.row_len + cl.chunk_len - 1) / cl.chunk_len);
         cl.cc_elems = cl.rows * cl.P * (size_t)cl.nchunks * cl.bpb;
         // classes run concurrently on separate streams: each gets its own region of every arena
-        const size_t want_b[9] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4, cl.total * 192, cl.total * 192,
-                                  2 * cl.total_tiles * 192, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
+        const size_t total64 = (cl.total + 63) & ~(size_t)63, tiles64 = (cl.total_tiles + 63) & ~(size_t)63;  // XYZZ arrays: blocks of 64
+        const size_t want_b[9] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4, total64 * 192, total64 * 192,
+                                  2 * tiles64 * 192, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
                                   cl.cc_elems * 4};
         for (int i = 0; i < 9; i++) {
             cl.off[i] = need[i];
@@ -851,7 +856,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         void* bufA = (char*)buf[3] + cl.off[3];
         void* bufB = (char*)buf[4] + cl.off[4];
         void* heads = (char*)buf[5] + cl.off[5];
-        void* tails = (char*)heads + cl.total_tiles * 192;
+        void* tails = (char*)heads + ((cl.total_tiles + 63) & ~(size_t)63) * 192;
         u32* longs = (u32*)((char*)buf[6] + cl.off[6]);
         ItemDesc* d_items = (ItemDesc*)((char*)buf[7] + cl.off[7]);
         u32* cc = (u32*)((char*)buf[8] + cl.off[8]);

@@ -5,12 +5,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-#include "../scalable-collaborative-zksnark_amd/csrc/fp.cuh"
+#include "../scalable-collaborative-zksnark_amd/csrc/fq30.cuh"  // production multiplier / squaring (includes fp.cuh)
 using namespace zk;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 struct F30 { u32 l[13]; };
-__host__ __device__ constexpr u32 Q30(int i) {
+__host__ __device__ constexpr u32 QL30(int i) {
     constexpr u32 t[13] = {0x3fffaaab, 0x27fbffff, 0x153ffffb, 0x2affffac, 0x30f6241e, 0x034a83da, 0x112bf673, 0x12e13ce1,
                            0x2cd76477, 0x1ed90d2e, 0x29a4b1ba, 0x3a8e5ff9, 0x001a0111};
     return t[i];
@@ -37,7 +37,7 @@ __device__ __forceinline__ F30 mul30(const F30& a, const F30& b) {
             int j = k - i;
             if (i < k && i < 13 && j >= 1 && j < 13) {
                 if (cnt == 15) { nxt += acc >> 30; acc &= MASK30; cnt = 0; }
-                acc += (u64)m[i] * Q30(j);
+                acc += (u64)m[i] * QL30(j);
                 cnt++;
             }
         }
@@ -45,7 +45,7 @@ __device__ __forceinline__ F30 mul30(const F30& a, const F30& b) {
             if (cnt >= 15) { nxt += acc >> 30; acc &= MASK30; }
             u32 mk = ((u32)acc * QP30) & MASK30;
             m[k] = mk;
-            acc += (u64)mk * Q30(0);
+            acc += (u64)mk * QL30(0);
         } else {
             t.l[k - 13] = (u32)acc & MASK30;
         }
@@ -55,7 +55,7 @@ __device__ __forceinline__ F30 mul30(const F30& a, const F30& b) {
     // conditional subtraction of q
     F30 d; u32 bw = 0;
 #pragma unroll
-    for (int i = 0; i < 13; i++) { u32 x = t.l[i] - Q30(i) - bw; bw = x >> 31; d.l[i] = x & MASK30; }
+    for (int i = 0; i < 13; i++) { u32 x = t.l[i] - QL30(i) - bw; bw = x >> 31; d.l[i] = x & MASK30; }
     // (top limb: 21 bits, the subtraction borrow shows in bit 31 too)
     F30 r;
 #pragma unroll
@@ -77,6 +77,19 @@ template <int ITER> __global__ void __launch_bounds__(256) k32(u32* out, const u
     x.l[11] &= 0x0fffffff; y.l[11] &= 0x0fffffff;
     for (int it = 0; it < ITER; it++) { x = fq_mul(x, y); y = fq_mul(y, x); }
     u32 s = 0; for (int i = 0; i < 12; i++) s ^= x.l[i] ^ y.l[i];
+    out[tid] = s;
+}
+// the production routines of csrc/fq30.cuh (lazy reduction: no final conditional subtraction)
+template <int ITER, bool SQR> __global__ void __launch_bounds__(256) kprod(u32* out, const u32* in) {
+    Fq30 x, y; size_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = 0; i < 13; i++) { x.l[i] = (in[i] + (u32)tid) & MASK30; y.l[i] = (in[13 + i] ^ (u32)tid) & MASK30; }  // both lane-dependent
+    x.l[12] &= 0xfffff; y.l[12] &= 0xfffff;
+#pragma unroll 1
+    for (int it = 0; it < ITER; it++) {
+        if (SQR) { x = f30_sqr(x); y = f30_sqr(y); }
+        else { x = f30_mul(x, y); y = f30_mul(y, x); }
+    }
+    u32 s = 0; for (int i = 0; i < 13; i++) s ^= x.l[i] ^ y.l[i];
     out[tid] = s;
 }
 // correctness: c32 = fq_mul(a,b) (R=2^384); c30 = mul30(a,b) on the same integers: c30 * 2^390 == c32 * 2^384 (mod q)
@@ -117,6 +130,10 @@ int main() {
         timeit(nm, [&] { k32<IT><<<nb, 256>>>(d_out, d_in); }, (double)nb * 256 * IT * 2);
         snprintf(nm, 64, "Fq mul 13x30 unsaturated (%d waves/SIMD)", bpc);
         timeit(nm, [&] { k30<IT><<<nb, 256>>>(d_out, d_in); }, (double)nb * 256 * IT * 2);
+        snprintf(nm, 64, "fq30.cuh f30_mul (%d waves/SIMD)", bpc);
+        timeit(nm, [&] { kprod<IT, false><<<nb, 256>>>(d_out, d_in); }, (double)nb * 256 * IT * 2);
+        snprintf(nm, 64, "fq30.cuh f30_sqr (%d waves/SIMD)", bpc);
+        timeit(nm, [&] { kprod<IT, true><<<nb, 256>>>(d_out, d_in); }, (double)nb * 256 * IT * 2);
     }
     return 0;
 }
