@@ -5,8 +5,8 @@
 // window c, W = ceil(129 / c) windows, nb = 2^(c-1) buckets per window):
 //   1 k_digits        scalars out of Montgomery form (as ark `into_bigint`), GLV split k = k1 + k2*lambda,
 //                     signed digits of both halves                            [coalesced 32-B reads]
-//   2 k_sort_pass<0>, k_bucket_totals, k_scan, k_chunk_offsets, k_sort_pass<1>
-//                     chunked counting sort, counters in LDS: entries grouped by bucket
+//   2 k_part_hist, k_part_scan, k_part_bases, k_part_scatter, k_part_sort
+//                     two-level counting sort, counters in LDS: entries grouped by bucket
 //   3 k_accum_tiles   every lane walks T consecutive sorted entries, gathers 96-B affine bases from
 //                     HBM and accumulates with XYZZ mixed adds (8M+2S)        [the dominant kernel]
 //   4 k_fixup(_long)  stitches the buckets cut by tile boundaries
@@ -234,127 +234,166 @@ __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ it
 }
 
 // ---------------------------------------------------------------------------------------
-// 2./3. counting sort, every digit read exactly once per pass.  A "row" is one bucket set (a
-// window, or -- with a precomputed SRS -- all windows at once).  The row is cut into chunks;
-// block (chunk, p, row) keeps the counters of bucket range p in LDS (no global atomics):
-//   k_sort_pass<false>  per-chunk histogram  -> cc[row][p][chunk][bpb]
-//   k_bucket_totals     counts[row][b] = sum over chunks
-//   k_scan              offsets[row][b] = exclusive scan of counts
-//   k_chunk_offsets     cc <- offsets[row][b] + sum of earlier chunks (start cursor of each chunk)
-//   k_sort_pass<true>   cursors from cc; writes the entry (index in row | sign bit) in place
+// 2./3. two-level counting sort of the entries of every row (a "row" is one bucket set: a window,
+// or -- with a precomputed SRS -- all windows at once) by bucket.  No global atomics; every store
+// stream is either coalesced or confined to a region one workgroup owns (so partial lines merge in
+// that workgroup's L2 instead of bouncing between XCDs):
+//   level 1  the row is cut into chunks; the top bits of the bucket pick one of np <= 256 partitions
+//     k_part_hist     block (chunk, row): partition histogram in LDS      -> hist[row][p][chunk]
+//     k_part_scan     block (p, row): exclusive scan over the chunks      -> hist in place, total[row][p]
+//     k_part_bases    block (row): exclusive scan over the partitions     -> base[row][p], rowtot[row]
+//     k_part_scatter  block (chunk, row): cursors in LDS; entry (index in row | sign bit) and its
+//                     bucket-in-partition go to part_idx / part_low: np streams of ~chunk/np entries
+//   level 2  block (p, row) owns its partition: counts the <= 2048 buckets in LDS, scans, writes
+//     k_part_sort     counts[row][b], offsets[row][b] and the entries grouped by bucket into sorted[]
 // ---------------------------------------------------------------------------------------
 static constexpr int kSortThreads = 1024;
-template <bool SCATTER>
-__global__ void __launch_bounds__(kSortThreads) k_sort_pass(const u32* __restrict__ digits, size_t row_len, size_t chunk_len,
-                                                          u32 nchunks, size_t nb, u32 bpb, u32 P, u32* __restrict__ cc,
-                                                          u32* __restrict__ sorted) {
-    extern __shared__ u32 cnt[];
-    // grid.x = (row, bucket range), grid.y = chunk: blocks that scatter into the same output region get
-    // consecutive-by-8 linear ids, i.e. the same XCD (block b -> XCD b % 8), so their 4-byte stores
-    // merge into full lines in ONE L2 instead of partial lines in eight
-    const u32 chunk = blockIdx.y, p = blockIdx.x % P, row = blockIdx.x / P;
-    const u32 lo = p * bpb;
-    u32* glob = cc + (((size_t)row * P + p) * nchunks + chunk) * bpb;
-    for (u32 i = threadIdx.x; i < bpb; i += kSortThreads) cnt[i] = SCATTER ? glob[i] : 0u;
+static constexpr u32 kMaxParts = 256;
+static constexpr u32 kMaxLow = 2048;  // buckets per partition (nb / np), nb <= 2^19
+
+__global__ void __launch_bounds__(kSortThreads) k_part_hist(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
+                                                          u32 np, int low_bits, u32* __restrict__ hist) {
+    __shared__ u32 cnt[kMaxParts];
+    const u32 chunk = blockIdx.x % nchunks, row = blockIdx.x / nchunks;
+    for (u32 i = threadIdx.x; i < np; i += kSortThreads) cnt[i] = 0u;
     __syncthreads();
-    const size_t c0 = (size_t)chunk * chunk_len;                        // multiple of 4
+    const size_t c0 = (size_t)chunk * chunk_len;                              // multiple of 4
     const size_t c1 = (c0 + chunk_len < row_len) ? c0 + chunk_len : row_len;  // row_len multiple of 4
     const uint4* row4 = reinterpret_cast<const uint4*>(digits + (size_t)row * row_len);
-    u32* out = sorted + (size_t)row * row_len;
+    for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
+        uint4 d4 = row4[i4];
+        u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (dd[k] != kSkip) atomicAdd(&cnt[(dd[k] & 0x7fffffffu) >> low_bits], 1u);
+    }
+    __syncthreads();
+    for (u32 p = threadIdx.x; p < np; p += kSortThreads) hist[((size_t)row * np + p) * nchunks + chunk] = cnt[p];
+}
+
+// exclusive scan of n <= blockDim values held one per thread (blockDim a power of two <= 1024)
+__device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* sh, u32* total) {
+    const int tid = threadIdx.x, n = blockDim.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < n; off <<= 1) {
+        u32 t = (tid >= off) ? sh[tid - off] : 0u;
+        __syncthreads();
+        sh[tid] += t;
+        __syncthreads();
+    }
+    const u32 incl = sh[tid];
+    if (total) *total = sh[n - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+static constexpr int kScanThreads = 256;
+__global__ void __launch_bounds__(kScanThreads) k_part_scan(u32* __restrict__ hist, u32 nchunks, u32* __restrict__ total) {
+    __shared__ u32 sh[kScanThreads];
+    u32* h = hist + (size_t)blockIdx.x * nchunks;  // blockIdx.x = row * np + p
+    u32 carry = 0;
+    for (u32 t0 = 0; t0 < nchunks; t0 += kScanThreads) {
+        const u32 i = t0 + threadIdx.x;
+        const u32 v = (i < nchunks) ? h[i] : 0u;
+        u32 tile_total;
+        const u32 ex = block_exclusive_scan(v, sh, &tile_total);
+        if (i < nchunks) h[i] = carry + ex;
+        carry += tile_total;
+    }
+    if (threadIdx.x == 0) total[blockIdx.x] = carry;
+}
+__global__ void __launch_bounds__(kScanThreads) k_part_bases(const u32* __restrict__ total, u32 np, u32* __restrict__ base,
+                                                           u32* __restrict__ rowtot) {
+    __shared__ u32 sh[kScanThreads];
+    const u32 row = blockIdx.x;
+    const u32 v = (threadIdx.x < np) ? total[(size_t)row * np + threadIdx.x] : 0u;
+    u32 all;
+    const u32 ex = block_exclusive_scan(v, sh, &all);
+    if (threadIdx.x < np) base[(size_t)row * np + threadIdx.x] = ex;
+    if (threadIdx.x == 0) rowtot[row] = all;
+}
+
+__global__ void __launch_bounds__(kSortThreads) k_part_scatter(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
+                                                             u32 np, int low_bits, const u32* __restrict__ hist,
+                                                             const u32* __restrict__ base, int idx_bits, u32* __restrict__ part_idx,
+                                                             unsigned short* __restrict__ part_low) {
+    __shared__ u32 cur[kMaxParts];
+    const u32 chunk = blockIdx.x % nchunks, row = blockIdx.x / nchunks;
+    for (u32 p = threadIdx.x; p < np; p += kSortThreads)
+        cur[p] = base[(size_t)row * np + p] + hist[((size_t)row * np + p) * nchunks + chunk];
+    __syncthreads();
+    const size_t c0 = (size_t)chunk * chunk_len;
+    const size_t c1 = (c0 + chunk_len < row_len) ? c0 + chunk_len : row_len;
+    const uint4* row4 = reinterpret_cast<const uint4*>(digits + (size_t)row * row_len);
+    u32* oi = part_idx + (size_t)row * row_len;
+    unsigned short* ol = part_low + (size_t)row * row_len;
+    const u32 low_mask = (1u << low_bits) - 1u;
     for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
         uint4 d4 = row4[i4];
         u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            u32 d = dd[k];
-            u32 b = (d & 0x7fffffffu) - lo;  // kSkip maps far outside any range
-            if (d != kSkip && b < bpb) {
-                if (SCATTER) {
-                    u32 pos = atomicAdd(&cnt[b], 1u);
-                    out[pos] = (u32)(4 * i4 + k) | (d & 0x80000000u);
+            const u32 d = dd[k];
+            if (d != kSkip) {
+                const u32 b = d & 0x7fffffffu;
+                const u32 pos = atomicAdd(&cur[b >> low_bits], 1u);
+                if (idx_bits) {  // index, bucket-in-partition and sign fit one word: a single store stream
+                    oi[pos] = (u32)(4 * i4 + k) | ((b & low_mask) << idx_bits) | (d & 0x80000000u);
                 } else {
-                    atomicAdd(&cnt[b], 1u);
+                    oi[pos] = (u32)(4 * i4 + k) | (d & 0x80000000u);
+                    ol[pos] = (unsigned short)(b & low_mask);
                 }
             }
         }
     }
-    if (!SCATTER) {
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < bpb; i += kSortThreads) glob[i] = cnt[i];
-    }
 }
 
-// counts[row][b] = sum over chunks of cc[row][p][chunk][b - p*bpb]
-__global__ void __launch_bounds__(kBlk) k_bucket_totals(const u32* __restrict__ cc, u32 nchunks, size_t nb, u32 bpb, size_t total,
-                                                      u32* __restrict__ counts) {
-    const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
-    if (g >= total) return;
-    const size_t row = g / nb, b = g % nb, p = b / bpb, bl = b % bpb, P = nb / bpb;
-    const u32* src = cc + ((row * P + p) * nchunks) * bpb + bl;
-    u32 s = 0;
-    for (u32 ch = 0; ch < nchunks; ch++) s += src[(size_t)ch * bpb];
-    counts[g] = s;
-}
-__global__ void __launch_bounds__(kBlk) k_chunk_offsets(u32* __restrict__ cc, u32 nchunks, size_t nb, u32 bpb, size_t total,
-                                                      const u32* __restrict__ offsets) {
-    const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
-    if (g >= total) return;
-    const size_t row = g / nb, b = g % nb, p = b / bpb, bl = b % bpb, P = nb / bpb;
-    u32* src = cc + ((row * P + p) * nchunks) * bpb + bl;
-    u32 run = offsets[g];
-    for (u32 ch = 0; ch < nchunks; ch++) {
-        u32 v = src[(size_t)ch * bpb];
-        src[(size_t)ch * bpb] = run;
-        run += v;
-    }
-}
-
-// exclusive scan of the bucket counts of every row.  One workgroup per (row, segment of kScanTile
-// counters): it first adds up the counters of the earlier segments of its row (redundant coalesced reads
-// out of L2, at most nb of them) and then scans its own segment in LDS -- a single launch with
-// rows * nb / kScanTile workgroups instead of a chain of dependent ones.
-static constexpr int kScanThreads = 1024;
-static constexpr int kScanTile = 4096;
-__global__ void __launch_bounds__(kScanThreads) k_scan(const u32* __restrict__ counts, size_t nb, u32* __restrict__ offsets) {
-    __shared__ u32 tile[kScanTile];
-    __shared__ u32 part[kScanThreads];
-    const int tid = threadIdx.x;
-    const size_t row = blockIdx.x, t0 = (size_t)blockIdx.y * kScanTile;
-    const u32* src = counts + row * nb;
-    u32* dst = offsets + row * nb;
-    const size_t len = (nb - t0 < (size_t)kScanTile) ? nb - t0 : (size_t)kScanTile;
-    // sum of the earlier segments
-    u32 pre = 0;
-    for (size_t i = tid; i < t0; i += kScanThreads) pre += src[i];
-    part[tid] = pre;
-    for (size_t i = tid; i < len; i += kScanThreads) tile[i] = src[t0 + i];
+// launched with 1024 threads for long partitions, 256 for short ones (fewer barrier steps in the scan)
+__global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restrict__ part_idx, const unsigned short* __restrict__ part_low,
+                                                              size_t row_len, u32 np, int low_bits, int idx_bits, size_t nb,
+                                                              const u32* __restrict__ base, const u32* __restrict__ rowtot,
+                                                              u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ sorted) {
+    __shared__ u32 cnt[kMaxLow];
+    __shared__ u32 sh[kSortThreads];
+    const u32 nthr = blockDim.x;
+    const u32 p = blockIdx.x % np, row = blockIdx.x / np;
+    const u32 nlow = 1u << low_bits, low_mask = nlow - 1u;
+    const u32 keep = idx_bits ? (((1u << idx_bits) - 1u) | 0x80000000u) : 0xffffffffu;  // entry bits that survive (index | sign)
+    const u32 s = base[(size_t)row * np + p];
+    const u32 e = (p + 1 < np) ? base[(size_t)row * np + p + 1] : rowtot[row];
+    const u32* pi = part_idx + (size_t)row * row_len;
+    const unsigned short* pl = part_low + (size_t)row * row_len;
+    for (u32 i = threadIdx.x; i < nlow; i += nthr) cnt[i] = 0u;
     __syncthreads();
-    for (int off = kScanThreads / 2; off > 0; off >>= 1) {
-        if (tid < off) part[tid] += part[tid + off];
-        __syncthreads();
+    for (u32 i = s + threadIdx.x; i < e; i += nthr) {
+        const u32 low = idx_bits ? ((pi[i] >> idx_bits) & low_mask) : (u32)pl[i];
+        atomicAdd(&cnt[low], 1u);
     }
-    const u32 carry = part[0];
     __syncthreads();
-    const size_t per = (len + kScanThreads - 1) / kScanThreads;
-    const size_t lo = (size_t)tid * per < len ? (size_t)tid * per : len, hi = (lo + per < len) ? lo + per : len;
+    // exclusive scan of cnt[0..nlow): each thread owns `per` consecutive counters
+    const u32 per = (nlow + nthr - 1) / nthr;
+    const u32 lo = threadIdx.x * per < nlow ? threadIdx.x * per : nlow, hi = (lo + per < nlow) ? lo + per : nlow;
     u32 sum = 0;
-    for (size_t i = lo; i < hi; i++) sum += tile[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < kScanThreads; off <<= 1) {  // Hillis-Steele over the per-thread sums
-        u32 v = (tid >= off) ? part[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    u32 run = carry + part[tid] - sum;  // exclusive prefix of this thread's slice
-    for (size_t i = lo; i < hi; i++) {
-        u32 v = tile[i];
-        tile[i] = run;
+    for (u32 i = lo; i < hi; i++) sum += cnt[i];
+    u32 run = s + block_exclusive_scan(sum, sh, nullptr);
+    u32* cnt_out = counts + (size_t)row * nb + (size_t)p * nlow;
+    u32* off_out = offsets + (size_t)row * nb + (size_t)p * nlow;
+    for (u32 i = lo; i < hi; i++) {
+        const u32 v = cnt[i];
+        cnt_out[i] = v;
+        off_out[i] = run;
+        cnt[i] = run;  // becomes the cursor of bucket i
         run += v;
     }
     __syncthreads();
-    for (size_t i = tid; i < len; i += kScanThreads) dst[t0 + i] = tile[i];
+    u32* out = sorted + (size_t)row * row_len;
+    for (u32 i = s + threadIdx.x; i < e; i += nthr) {
+        const u32 v = pi[i];
+        const u32 low = idx_bits ? ((v >> idx_bits) & low_mask) : (u32)pl[i];
+        const u32 pos = atomicAdd(&cnt[low], 1u);
+        out[pos] = v & keep;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -689,10 +728,11 @@ struct MsmClass {
     WinLayout L{};
     std::vector<size_t> idx;  // items of the batch in this class
     size_t ns = 0, nb = 0, rows = 0, total = 0, tiles_per_w = 0, total_tiles = 0, chunk_len = 0, cc_elems = 0;
-    u32 T = 32, bpb = 0, nchunks = 0;
-    unsigned P = 1;
+    u32 T = 32, nchunks = 0, np = 1;  // sort: chunks per row, partitions per row
+    int low_bits = 0;                 // log2(buckets per partition)
+    int idx_bits = 0;                 // > 0: level-1 entries carry the bucket-in-partition above the index bits
     size_t pinned_off = 0;  // byte offset of this class's results in the pinned staging area
-    size_t off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets of this class inside the scratch arenas
+    size_t off[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets of this class inside the scratch arenas
 };
 
 // batches group their items into a few window classes: 5, 8, 11, 14, 17 bits (rounded up), then 19
@@ -702,7 +742,6 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     if (!h_out && count) return fail(ctx, ZK_ERR_INVALID, "null argument");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
-    static const u32 bpb_env = getenv("ZK_MSM_BPB") ? (u32)atoi(getenv("ZK_MSM_BPB")) : 0;
     static const bool pair_env = getenv("ZK_MSM_PAIR") && atoi(getenv("ZK_MSM_PAIR")) != 0;
     static const int split_env = getenv("ZK_MSM_SPLIT") ? atoi(getenv("ZK_MSM_SPLIT")) : 1;  // measured on MI355X: no gain (every phase is ALU-bound), off by default
     // ---- validate + classify by window width ----
@@ -773,7 +812,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         classes.swap(cut);
     }
     // ---- geometry per class, scratch high-water marks ----
-    size_t need[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pinned_bytes = 0;
+    size_t need[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pinned_bytes = 0;
     for (auto& cl : classes) {
         const int W = cl.wc;
         const size_t nitems = cl.idx.size();
@@ -802,20 +841,25 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         if (T_env) cl.T = T_env;
         cl.tiles_per_w = (cl.row_len + cl.T - 1) / cl.T;
         cl.total_tiles = cl.tiles_per_w * cl.rows;
-        // sort geometry: rows x chunks x bucket ranges; LDS counters <= 128 KiB per block
-        cl.bpb = (u32)std::min<size_t>(cl.nb, bpb_env ? bpb_env : 32768);
-        cl.P = (unsigned)(cl.nb / cl.bpb);
-        size_t want = 512 / (cl.rows * cl.P);
-        cl.nchunks = (u32)std::max<size_t>(1, std::min<size_t>(want ? want : 1, (cl.row_len + 8191) / 8192));
-        cl.chunk_len = ((cl.row_len + cl.nchunks - 1) / cl.nchunks + 3) & ~(size_t)3;
+        // sort geometry: <= 256 partitions per row (top bits of the bucket), chunks of >= 16 Ki entries,
+        // at most 128 chunks per row
+        cl.np = (u32)std::min<size_t>(cl.nb, kMaxParts);
+        cl.low_bits = 0;
+        while (((size_t)cl.np << cl.low_bits) < cl.nb) cl.low_bits++;
+        {
+            int ib = 1;
+            while (((size_t)1 << ib) < cl.row_len) ib++;
+            cl.idx_bits = (ib + cl.low_bits <= 31) ? ib : 0;
+        }
+        cl.chunk_len = (std::max<size_t>(16384, (cl.row_len + 127) / 128) + 3) & ~(size_t)3;
         cl.nchunks = (u32)((cl.row_len + cl.chunk_len - 1) / cl.chunk_len);
-        cl.cc_elems = cl.rows * cl.P * (size_t)cl.nchunks * cl.bpb;
+        cl.cc_elems = cl.rows * (size_t)cl.np * cl.nchunks + 2 * cl.rows * (size_t)cl.np + cl.rows;  // hist, total, base, rowtot
         // classes run concurrently on separate streams: each gets its own region of every arena
         const size_t total64 = (cl.total + 63) & ~(size_t)63, tiles64 = (cl.total_tiles + 63) & ~(size_t)63;  // XYZZ arrays: blocks of 64
-        const size_t want_b[9] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4, total64 * 192, total64 * 192,
-                                  2 * tiles64 * 192, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
-                                  cl.cc_elems * 4};
-        for (int i = 0; i < 9; i++) {
+        const size_t want_b[10] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4, total64 * 192, total64 * 192,
+                                   2 * tiles64 * 192, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
+                                   cl.cc_elems * 4, cl.rows * cl.row_len * 2};
+        for (int i = 0; i < 10; i++) {
             cl.off[i] = need[i];
             need[i] += (want_b[i] + 255) & ~(size_t)255;
         }
@@ -823,17 +867,14 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         pinned_bytes += ((cl.rows * (size_t)cl.npair * 144 + 255) & ~(size_t)255) + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
     }
     // allocate every arena once, before anything is enqueued (no reallocation between classes)
-    static const int slot[9] = {0, 1, 2, 3, 4, 5, 6, 9, 8};
-    void* buf[9];
-    for (int i = 0; i < 9; i++) {
+    static const int slot[10] = {0, 1, 2, 3, 4, 5, 6, 9, 8, 11};
+    void* buf[10];
+    for (int i = 0; i < 10; i++) {
         buf[i] = scratch(ctx, slot[i], need[i]);
         if (!buf[i]) return ZK_ERR_OOM;
     }
     char* hpin = (char*)pinned(ctx, pinned_bytes);
     if (!hpin) return ZK_ERR_OOM;
-    hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-
     // ---- enqueue every class without host synchronisation; independent classes go to separate
     // streams (the small ones are pure launch/latency chains and overlap with the big one).
     // Phase timers: sort of the first class, accumulation from the first part's launch to the last
@@ -850,7 +891,9 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         const bool t_first = (cls_i == 0), t_last = (cls_i + 1 == (size_t)classes[0].nparts);  // the first class's parts carry the timers
         hipStream_t st = (!multi || cls_i == 0) ? ctx->stream : ctx->aux[(cls_i - 1) % zk_ctx::kAux];
         u32* digits = (u32*)((char*)buf[0] + cl.off[0]);
-        u32* sorted = (u32*)((char*)buf[1] + cl.off[1]);
+        u32* sorted = digits;  // the digits are dead once partitioned: the sorted entries take their place
+        u32* part_idx = (u32*)((char*)buf[1] + cl.off[1]);
+        unsigned short* part_low = (unsigned short*)((char*)buf[9] + cl.off[9]);
         u32* counts = (u32*)((char*)buf[2] + cl.off[2]);
         u32* offsets = counts + total;
         void* bufA = (char*)buf[3] + cl.off[3];
@@ -874,15 +917,21 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
         hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, cl.shared ? 0 : 1, digits);
-        hipLaunchKernelGGL((k_sort_pass<false>), dim3((unsigned)(cl.rows * cl.P), cl.nchunks), dim3(kSortThreads), cl.bpb * 4, st,
-                           (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, (u32)cl.P, cc, (u32*)nullptr);
-        hipLaunchKernelGGL(k_bucket_totals, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)cc, cl.nchunks,
-                           nb, cl.bpb, total, counts);
-        hipLaunchKernelGGL(k_scan, dim3((unsigned)cl.rows, (unsigned)((nb + kScanTile - 1) / kScanTile)), dim3(kScanThreads), 0, st, (const u32*)counts, nb, offsets);
-        hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, cc, cl.nchunks, nb, cl.bpb,
-                           total, (const u32*)offsets);
-        hipLaunchKernelGGL((k_sort_pass<true>), dim3((unsigned)(cl.rows * cl.P), cl.nchunks), dim3(kSortThreads), cl.bpb * 4, st,
-                           (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, nb, cl.bpb, (u32)cl.P, cc, sorted);
+        {
+            u32* hist = cc;
+            u32* ptotal = hist + cl.rows * (size_t)cl.np * cl.nchunks;
+            u32* pbase = ptotal + cl.rows * (size_t)cl.np;
+            u32* rowtot = pbase + cl.rows * (size_t)cl.np;
+            const dim3 g_chunks((unsigned)(cl.nchunks * cl.rows)), g_parts((unsigned)(cl.np * cl.rows));
+            hipLaunchKernelGGL(k_part_hist, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, cl.np,
+                               cl.low_bits, hist);
+            hipLaunchKernelGGL(k_part_scan, dim3((unsigned)(cl.rows * cl.np)), dim3(kScanThreads), 0, st, hist, cl.nchunks, ptotal);
+            hipLaunchKernelGGL(k_part_bases, dim3((unsigned)cl.rows), dim3(kScanThreads), 0, st, (const u32*)ptotal, cl.np, pbase, rowtot);
+            hipLaunchKernelGGL(k_part_scatter, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks,
+                               cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low);
+            hipLaunchKernelGGL(k_part_sort, g_parts, dim3(cl.row_len / cl.np >= 4096 ? kSortThreads : 256), 0, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len,
+                               cl.np, cl.low_bits, cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, counts, offsets, sorted);
+        }
         if (t_first) hipEventRecord(ctx->ev[1], st);
         if (cl.part > 0) hipStreamWaitEvent(st, ctx->ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
         hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
