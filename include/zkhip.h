@@ -175,6 +175,8 @@ int zk_msm_last_timing(zk_ctx *ctx, float h_ms[6]);
 int zk_dbg_fq_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
 int zk_dbg_fq_add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
 int zk_dbg_fq_sub(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
+/* a*b + b*b through the fused two-product multiplication (one Montgomery reduction) */
+int zk_dbg_fq_mul2add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
 /* device XYZZ formulas on pairs of packed affine points; h_out[i] = 18 u64 normalised Jacobian.
  * mode 0: p+q (mixed add)  1: (p+q)+p (full add)  2: (p+q)+(p+q) (doubling path)  3: p-q */
 int zk_dbg_g1_op(zk_ctx *ctx, int mode, const void *d_p96, const void *d_q96, void *h_out, size_t n);

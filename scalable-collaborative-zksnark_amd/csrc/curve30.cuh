@@ -155,7 +155,12 @@ __device__ __forceinline__ void xyzz30_madd(Xyzz30& acc, const Aff30& p, bool ne
     }
     const Fq30 Q2 = f30_add(Q, Q);                              // < 4q
     const Fq30 X3 = f30_sub4(f30_sub2(f30_sqr(R), PPP), Q2);    // (R^2 + 2q - PPP) + 4q - 2Q < 8q
-    const Fq30 Y3 = f30_sub2(f30_mul(R, f30_sub8(Q, X3)), f30_mul(acc.y, PPP));  // R(Q + 8q - X3) + 2q - Y1*PPP < 4q
+#ifdef ZK_AB_BASE  // A/B build only (tools/ab): two multiplications and a subtraction
+    const Fq30 Y3 = f30_sub2(f30_mul(R, f30_sub8(Q, X3)), f30_mul(acc.y, PPP));
+#else
+    // R(Q + 8q - X3) + (4q - Y1)*PPP under one reduction: 6q*10q + 4q*2q <= 256 q^2 -> < 2q
+    const Fq30 Y3 = f30_mul2add(R, f30_sub8(Q, X3), f30_sub4(f30_zero(), acc.y), PPP);
+#endif
     acc.zzz = f30_mul(acc.zzz, PPP);
     acc.zz = ZZ3;
     acc.x = X3;
@@ -184,10 +189,60 @@ __device__ __forceinline__ Xyzz30 xyzz30_add(const Xyzz30& a, const Xyzz30& b) {
     }
     const Fq30 Q2 = f30_add(Q, Q);
     r.x = f30_sub4(f30_sub2(f30_sqr(R), PPP), Q2);                          // < 8q
-    r.y = f30_sub2(f30_mul(R, f30_sub8(Q, r.x)), f30_mul(S1, PPP));        // < 4q
+    r.y = f30_mul2add(R, f30_sub8(Q, r.x), f30_sub2(f30_zero(), S1), PPP);  // 4q*10q + 2q*2q -> < 2q
     r.zz = ZZ3;
     r.zzz = f30_mul(f30_mul(a.zzz, b.zzz), PPP);
     return r;
+}
+
+// ---- one XYZZ addition spread over the four lanes of a quad (latency-bound reduction passes) ----
+// The 13 field multiplications of add-2008-s have depth 4; a quad runs them as 4 rounds of one
+// multiplication per lane, exchanging operands with DPP quad broadcasts (no LDS, no memory).
+template <int R>
+__device__ __forceinline__ Fq30 f30_quad_bcast(const Fq30& v) {  // lane R's value to the 4 lanes of its quad
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)v.l[i], R * 0x55, 0xf, 0xf, true);
+    return r;
+}
+__device__ __forceinline__ Fq30 f30_sel4(int role, const Fq30& a0, const Fq30& a1, const Fq30& a2, const Fq30& a3) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = (role == 0) ? a0.l[i] : (role == 1) ? a1.l[i] : (role == 2) ? a2.l[i] : a3.l[i];
+    return r;
+}
+// out[io] = in[ia] + in[ib]; called by all four lanes of a quad (role = lane & 3) with identical indices.
+// Round 1: U1 = X1*ZZ2 | U2 = X2*ZZ1 | S1 = Y1*ZZZ2 | S2 = Y2*ZZZ1      (lane 0 | 1 | 2 | 3)
+// Round 2: A = ZZ1*ZZ2 | B = ZZZ1*ZZZ2 | PP = P^2 | RR = R^2
+// Round 3: Q = U1*PP   | ZZ3 = A*PP    | PPP = P*PP | -
+// Round 4: -           | ZZZ3 = B*PPP  | T1 = S1*PPP | T2 = R*(Q + 8q - X3);  Y3 = T2 - T1
+__device__ __forceinline__ void xyzz30_add_quad(const void* __restrict__ in, size_t ia, size_t ib, void* __restrict__ out, size_t io,
+                                               int role) {
+    const Fq30 opA = f30_load_chunks(in, (role & 1) ? ib : ia, (role & 2) ? 3 : 0);  // a.x | b.x | a.y | b.y
+    const Fq30 opB = f30_load_chunks(in, (role & 1) ? ia : ib, (role & 2) ? 9 : 6);  // b.zz | a.zz | b.zzz | a.zzz
+    const Fq30 zz2 = f30_quad_bcast<0>(opB), zz1 = f30_quad_bcast<1>(opB), zzz2 = f30_quad_bcast<2>(opB), zzz1 = f30_quad_bcast<3>(opB);
+    const bool a_inf = f30_all_zero(zz1), b_inf = f30_all_zero(zz2);  // identical in the four lanes
+    if (a_inf || b_inf) {  // the other operand (or infinity) is the result: lane r copies coordinate r
+        f30_store_chunks(out, io, 3 * role, f30_load_chunks(in, a_inf ? ib : ia, 3 * role));
+        return;
+    }
+    const Fq30 m1 = f30_mul(opA, opB);
+    const Fq30 u1 = f30_quad_bcast<0>(m1), u2 = f30_quad_bcast<1>(m1), s1 = f30_quad_bcast<2>(m1), s2 = f30_quad_bcast<3>(m1);
+    const Fq30 P = f30_sub2(u2, u1);  // < 4q
+    const Fq30 R = f30_sub2(s2, s1);  // < 4q
+    const Fq30 m2 = f30_mul(f30_sel4(role, zz1, zzz1, P, R), f30_sel4(role, zz2, zzz2, P, R));
+    const Fq30 A = f30_quad_bcast<0>(m2), B = f30_quad_bcast<1>(m2), PP = f30_quad_bcast<2>(m2), RR = f30_quad_bcast<3>(m2);
+    const Fq30 m3 = f30_mul(f30_sel4(role, u1, A, P, P), PP);
+    const Fq30 Q = f30_quad_bcast<0>(m3), ZZ3 = f30_quad_bcast<1>(m3), PPP = f30_quad_bcast<2>(m3);
+    if (f30_is_zero_2q(ZZ3)) {  // same x: doubling or cancellation (adversarial inputs only) -- lane 0 redoes it alone
+        if (role == 0) xyzz30_store(out, io, xyzz30_add(xyzz30_load(in, ia), xyzz30_load(in, ib)));
+        return;
+    }
+    const Fq30 X3 = f30_sub4(f30_sub2(RR, PPP), f30_add(Q, Q));  // < 8q
+    const Fq30 m4 = f30_mul(f30_sel4(role, B, B, s1, R), f30_sel4(role, PPP, PPP, PPP, f30_sub8(Q, X3)));
+    const Fq30 ZZZ3 = f30_quad_bcast<1>(m4), T1 = f30_quad_bcast<2>(m4), T2 = f30_quad_bcast<3>(m4);
+    const Fq30 Y3 = f30_sub2(T2, T1);  // < 4q
+    f30_store_chunks(out, io, 3 * role, f30_sel4(role, X3, Y3, ZZ3, ZZZ3));
 }
 
 }  // namespace zk

@@ -224,6 +224,74 @@ __device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
     return t;
 }
 
+// (a*b + c*d) * 2^-390 (mod q) with ONE Montgomery reduction: both products are accumulated column by
+// column before the reduction terms (507 mad instead of 676 for two multiplications and an addition).
+// Inputs normalised; needs bound(a)*bound(b) + bound(c)*bound(d) <= 256 q^2; result normalised, < 2q.
+// A difference of products a*b - c*d is taken as a*b + (kq - c)*d.
+__device__ __forceinline__ Fq30 f30_mul2add(const Fq30& a, const Fq30& b, const Fq30& c, const Fq30& d) {
+    u32 m[13];
+    Fq30 t;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 25; k++) {
+        int units = 0;
+        u64 nxt = 0;
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 13) {
+                if (units + 1 > 15) {
+                    nxt += acc >> 30;
+                    acc &= Q30::MASK;
+                    units = 0;
+                }
+                acc += (u64)a.l[i] * b.l[j];
+                units++;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 13) {
+                if (units + 1 > 15) {
+                    nxt += acc >> 30;
+                    acc &= Q30::MASK;
+                    units = 0;
+                }
+                acc += (u64)c.l[i] * d.l[j];
+                units++;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const int j = k - i;
+            if (i < k && j >= 1 && j < 13) {
+                if (units + 1 > 15) {
+                    nxt += acc >> 30;
+                    acc &= Q30::MASK;
+                    units = 0;
+                }
+                acc += (u64)m[i] * Q30::Q(j);
+                units++;
+            }
+        }
+        if (k < 13) {
+            if (units + 1 > 15) {
+                nxt += acc >> 30;
+                acc &= Q30::MASK;
+            }
+            const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;
+            m[k] = mk;
+            acc += (u64)mk * Q30::Q(0);
+        } else {
+            t.l[k - 13] = (u32)acc & Q30::MASK;
+        }
+        acc = (acc >> 30) + nxt;
+    }
+    t.l[12] = (u32)acc;
+    return t;
+}
+
 // v - c if v >= c else v, for a normalised constant c given by limb accessor
 #define ZK_F30_CSUB(name, C)                                                                         \
     __device__ __forceinline__ Fq30 name(const Fq30& v) {                                           \

@@ -317,6 +317,7 @@ int zk_msm_last_timing(zk_ctx* ctx, float h_ms[6]) {
     return ZK_OK;
 }
 
+int zk_dbg_fq_mul2add(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 3, a, b, out, n); }
 int zk_dbg_fq_add(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 0, a, b, out, n); }
 int zk_dbg_fq_sub(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 1, a, b, out, n); }
 int zk_dbg_fq_mul(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 2, a, b, out, n); }

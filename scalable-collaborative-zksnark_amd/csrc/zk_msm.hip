@@ -553,6 +553,28 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
     xyzz30_store(out, t, res);
 }
 
+// the same pass with one addition per QUAD of lanes (curve30.cuh: xyzz30_add_quad): for the late passes,
+// which are a single dependent addition of pure latency, this cuts the chain from 13 multiplications to 4
+__global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len) {
+    const size_t half = len >> 1;
+    const size_t per_w = (size_t)(rows + 1) * half;
+    const size_t tq = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    const size_t t = tq >> 2;
+    const int role = (int)(tq & 3);
+    if (t >= per_w * W) return;  // whole quads leave together (kBlk is a multiple of 4)
+    const size_t w = t / per_w, rem = t % per_w;
+    const int r = (int)(rem / half);
+    const size_t j = rem % half;
+    const size_t in_w = w * (size_t)rows * len;
+    const size_t src_row = (r < rows - 1) ? (size_t)r : (size_t)(rows - 1);
+    const size_t ib = in_w + src_row * len + 2 * j + 1;
+    if (r == rows - 1) {  // odd elements of L become the new plane row: lane r copies coordinate r
+        f30_store_chunks(out, t, 3 * role, f30_load_chunks(in, ib, 3 * role));
+        return;
+    }
+    xyzz30_add_quad(in, ib - 1, ib, out, t, role);
+}
+
 // last step on the device: the c reduced points of every window row (planes T_0..T_{c-2}, then T_all)
 // are rewritten as Jacobian points in the REFERENCE Montgomery form (144 B), so the host chain starts
 // without conversions.  With `pair` the planes are also combined two by two on the way,
@@ -642,7 +664,7 @@ __global__ void __launch_bounds__(kBlk) k_dbg_fq(const void* __restrict__ a, con
                                                int op) {
     for (size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlk) {
         Fq30 x = f30_from_ref(f30_load(a, i * 48)), y = f30_from_ref(f30_load(b, i * 48));
-        Fq30 r = (op == 0) ? f30_add(x, y) : (op == 1) ? f30_sub2(x, y) : (a == b) ? f30_sqr(x) : f30_mul(x, y);  // same buffer twice: the squaring path
+        Fq30 r = (op == 0) ? f30_add(x, y) : (op == 1) ? f30_sub2(x, y) : (op == 3) ? f30_mul2add(x, y, y, y) : (a == b) ? f30_sqr(x) : f30_mul(x, y);  // same buffer twice: the squaring path; op 3: x*y + y*y under one reduction
         f30_store(out, i * 48, f30_to_ref(r));
     }
 }
@@ -743,6 +765,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
     static const bool pair_env = getenv("ZK_MSM_PAIR") && atoi(getenv("ZK_MSM_PAIR")) != 0;
+    static const size_t quad_max = getenv("ZK_MSM_QUAD") ? (size_t)atol(getenv("ZK_MSM_QUAD")) : 32768;  // additions per pass (above it the plain pass is faster: measured)
     static const int split_env = getenv("ZK_MSM_SPLIT") ? atoi(getenv("ZK_MSM_SPLIT")) : 1;  // measured on MI355X: no gain (every phase is ALU-bound), off by default
     // ---- validate + classify by window width ----
     std::vector<MsmClass> classes;
@@ -827,15 +850,16 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         // for small MSMs balance the serial chain of a lane (T mixed adds, ~10 Fq-mul each) against
         // the fix-up chain of a bucket (entries_per_bucket / T full adds, ~14 Fq-mul each)
         cl.T = 32;
-        const double per_bucket = (double)nmax * cl.copies / (double)cl.nb;
+        // entries per bucket in a typical row: most rows are L.base bits wide, i.e. 2^(base-1) buckets in use
+        const double per_bucket = (double)nmax * cl.copies / (double)(cl.shared ? cl.nb : std::min(cl.nb, (size_t)1 << (cl.L.base > 0 ? cl.L.base - 1 : 0)));
         if ((size_t)nitems * cl.rpi * cl.copies * nmax / 32 < (size_t)ctx->cu_count * 4 * 64 * 2) {
             cl.T = 4;
             while (cl.T < 32 && (double)cl.T * cl.T < 1.4 * per_bucket) cl.T <<= 1;
         } else {
-            // long buckets: longer tiles keep the fix-up chain (tiles per bucket) at 2-3 while there are
-            // still several waves of lanes per SIMD
+            // long buckets: longer tiles keep the fix-up chain (tiles per bucket) at 2-3 while the lanes
+            // still fill the chip (2 waves per SIMD)
             while (cl.T < 1024 && (double)cl.T * 2 <= per_bucket &&
-                   (size_t)nitems * cl.rpi * cl.copies * nmax / (2 * cl.T) >= (size_t)ctx->cu_count * 4 * 64 * 2 * 4)
+                   (size_t)nitems * cl.rpi * cl.copies * nmax / (2 * cl.T) >= (size_t)ctx->cu_count * 4 * 64 * 2)
                 cl.T <<= 1;
         }
         if (T_env) cl.T = T_env;
@@ -951,8 +975,12 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         size_t len = nb;
         while (len > 1) {
             size_t threads = cl.rows * (size_t)(rows + 1) * (len >> 1);
-            hipLaunchKernelGGL(k_halve, dim3((unsigned)((threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
-                               (int)cl.rows, rows, len);
+            if (threads <= quad_max)  // too few additions to fill the chip: spend four lanes on each
+                hipLaunchKernelGGL(k_halve_quad, dim3((unsigned)((4 * threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
+                                   (int)cl.rows, rows, len);
+            else
+                hipLaunchKernelGGL(k_halve, dim3((unsigned)((threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
+                                   (int)cl.rows, rows, len);
             std::swap(in, out);
             rows++;
             len >>= 1;

@@ -10,7 +10,7 @@ import subprocess
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)
-LIB_PATH = os.path.join(_ROOT, "libzkhip.so")
+LIB_PATH = os.environ.get("ZKHIP_LIB") or os.path.join(_ROOT, "libzkhip.so")  # ZKHIP_LIB: an explicitly chosen build (A/B runs)
 CSRC = os.path.join(_ROOT, "csrc")
 
 # every symbol include/zkhip.h declares: (name, restype, argtypes)
@@ -58,6 +58,7 @@ SYMBOLS = [
     ("zk_dbg_fq_mul", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_fq_add", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_fq_sub", _i, [_vp, _vp, _vp, _vp, _sz]),
+    ("zk_dbg_fq_mul2add", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_g1_op", _i, [_vp, _i, _vp, _vp, _vp, _sz]),
 ]
 

@@ -355,7 +355,7 @@ class Ctx:
 
     # ---- test hooks ----
     def dbg_fq(self, op: str, a, b, n, out=None):
-        fn = {"add": self.lib.zk_dbg_fq_add, "sub": self.lib.zk_dbg_fq_sub, "mul": self.lib.zk_dbg_fq_mul}[op]
+        fn = {"add": self.lib.zk_dbg_fq_add, "sub": self.lib.zk_dbg_fq_sub, "mul": self.lib.zk_dbg_fq_mul, "mul2add": self.lib.zk_dbg_fq_mul2add}[op]
         out = out or self.alloc(max(48 * n, 1))
         self._check(fn(self.h, _ptr(a), _ptr(b), _ptr(out), n))
         return out

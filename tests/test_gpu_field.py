@@ -75,6 +75,8 @@ def test_fq_ops(ctx, co):
     for op, ref in (("add", co.fq_add), ("sub", co.fq_sub), ("mul", co.fq_mul)):
         got = ctx.dbg_fq(op, da, db, n).download((n, 6))
         assert (got == ref(a, b)).all(), op
+    got = ctx.dbg_fq("mul2add", da, db, n).download((n, 6))  # a*b + b*b under one reduction
+    assert (got == co.fq_add(co.fq_mul(a, b), co.fq_mul(b, b))).all()
     # the same buffer as both operands takes the dedicated squaring path
     got = ctx.dbg_fq("mul", da, da, n).download((n, 6))
     assert (got == co.fq_mul(a, a)).all()
