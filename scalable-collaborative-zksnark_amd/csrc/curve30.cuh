@@ -155,12 +155,8 @@ __device__ __forceinline__ void xyzz30_madd(Xyzz30& acc, const Aff30& p, bool ne
     }
     const Fq30 Q2 = f30_add(Q, Q);                              // < 4q
     const Fq30 X3 = f30_sub4(f30_sub2(f30_sqr(R), PPP), Q2);    // (R^2 + 2q - PPP) + 4q - 2Q < 8q
-#ifdef ZK_AB_BASE  // A/B build only (tools/ab): two multiplications and a subtraction
-    const Fq30 Y3 = f30_sub2(f30_mul(R, f30_sub8(Q, X3)), f30_mul(acc.y, PPP));
-#else
     // R(Q + 8q - X3) + (4q - Y1)*PPP under one reduction: 6q*10q + 4q*2q <= 256 q^2 -> < 2q
     const Fq30 Y3 = f30_mul2add(R, f30_sub8(Q, X3), f30_sub4(f30_zero(), acc.y), PPP);
-#endif
     acc.zzz = f30_mul(acc.zzz, PPP);
     acc.zz = ZZ3;
     acc.x = X3;
