@@ -1266,11 +1266,70 @@ int g1_lincomb_batch_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint6
                 break;
             }
     std::vector<H::Jac> acc(count, H::jac_inf());
-    for (size_t r = 0; r < count; r++) {
-        for (int b = top; b >= 0; b--) {
-            acc[r] = H::jac_dbl(acc[r]);
-            for (size_t i = 0; i < n; i++)
-                if ((h_scalars_canon[4 * i + b / 64] >> (b % 64)) & 1) acc[r] = H::jac_add_mixed(acc[r], pts[r * n + i]);
+    // rows are independent ~255-step chains: host threads over rows.  A row whose points are all the same
+    // (the no-comm echo net hands the leader N copies of its own message) collapses to ONE scalar
+    // multiplication by the sum of the coefficients.
+    uint64_t ksum[4] = {0, 0, 0, 0};
+    {
+        H::u128 cy = 0;
+        uint64_t t[5] = {0, 0, 0, 0, 0};
+        for (size_t i = 0; i < n; i++) {
+            cy = 0;
+            for (int k = 0; k < 4; k++) {
+                cy += (H::u128)t[k] + h_scalars_canon[4 * i + k];
+                t[k] = (uint64_t)cy;
+                cy >>= 64;
+            }
+            t[4] += (uint64_t)cy;
+            // reduce mod r (r > 2^254: at most a few subtractions)
+            static const uint64_t R[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+            for (;;) {
+                bool ge = t[4] != 0;
+                if (!ge) {
+                    ge = true;
+                    for (int k = 3; k >= 0; k--) {
+                        if (t[k] > R[k]) break;
+                        if (t[k] < R[k]) {
+                            ge = false;
+                            break;
+                        }
+                    }
+                }
+                if (!ge) break;
+                uint64_t bw = 0;
+                for (int k = 0; k < 4; k++) {
+                    H::u128 d = (H::u128)t[k] - R[k] - bw;
+                    t[k] = (uint64_t)d;
+                    bw = (uint64_t)(d >> 64) & 1;
+                }
+                t[4] -= bw;
+            }
+        }
+        for (int k = 0; k < 4; k++) ksum[k] = t[k];
+    }
+    auto row_work = [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; r++) {
+            bool same = n > 1;
+            for (size_t i = 1; i < n && same; i++) same = (pts[r * n + i].x == pts[r * n].x) && (pts[r * n + i].y == pts[r * n].y);
+            if (same) {
+                acc[r] = H::scalar_mul(pts[r * n], ksum);
+                continue;
+            }
+            for (int b = top; b >= 0; b--) {
+                acc[r] = H::jac_dbl(acc[r]);
+                for (size_t i = 0; i < n; i++)
+                    if ((h_scalars_canon[4 * i + b / 64] >> (b % 64)) & 1) acc[r] = H::jac_add_mixed(acc[r], pts[r * n + i]);
+            }
+        }
+    };
+    {
+        const size_t nth = (top < 8 || count < 2) ? 1 : std::min<size_t>({count, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)32});
+        if (nth <= 1) {
+            row_work(0, count);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nth; t++) th.emplace_back(row_work, count * t / nth, count * (t + 1) / nth);
+            for (auto& x : th) x.join();
         }
     }
     std::vector<H::Aff> outa(count);
