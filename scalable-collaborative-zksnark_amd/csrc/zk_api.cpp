@@ -86,7 +86,6 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     for (auto& e : c->ev_join) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& e : c->ev_part) hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    for (auto& e : c->ev_done) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     *out = c;
     return ZK_OK;
 }
@@ -106,8 +105,9 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         if (e) hipEventDestroy(e);
     for (auto& e : ctx->ev_part)
         if (e) hipEventDestroy(e);
-    for (auto& e : ctx->ev_done)
+    for (auto& e : ctx->ev_cls)
         if (e) hipEventDestroy(e);
+    zk::msm_host_pool_destroy(ctx);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -37,7 +37,9 @@ struct zk_ctx {
     hipStream_t aux[kAux] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {};
     static constexpr int kParts = 4;  // staggered parts of one MSM class (zk_msm.hip)
-    hipEvent_t ev_part[kParts] = {}, ev_done[kParts] = {};
+    hipEvent_t ev_part[kParts] = {};
+    std::vector<hipEvent_t> ev_cls;  // completion event per MSM window class of a batch
+    void* host_pool = nullptr;       // worker threads for the per-item host chains (zk_msm.hip)
     int cu_count = 256;
 };
 
@@ -79,6 +81,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out);
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
 int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c);
+void msm_host_pool_destroy(zk_ctx* ctx);
 int srs_from_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out);
 int srs_download(zk_ctx* ctx, const zk_srs* srs, void* h_out96);
 int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, zk_srs** out);

@@ -27,7 +27,11 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -737,6 +741,65 @@ static void combine_windows(zkhost::Jac& acc, const uint64_t* h, const WinLayout
     }
 }
 
+// Host worker pool of a ctx (created on first use, joined by zk_ctx_destroy): the per-item doubling
+// chains run here while the calling thread is still waiting for the device work of later classes.
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    std::deque<std::function<void()>> q;
+    size_t pending = 0;
+    bool stop = false;
+    explicit HostPool(unsigned n) {
+        for (unsigned i = 0; i < n; i++)
+            th.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this] { return stop || !q.empty(); });
+                        if (q.empty()) return;
+                        job = std::move(q.front());
+                        q.pop_front();
+                    }
+                    job();
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    void submit(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(std::move(f));
+            pending++;
+        }
+        cv.notify_one();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [this] { return pending == 0; });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+static HostPool* host_pool(zk_ctx* ctx) {
+    if (!ctx->host_pool) ctx->host_pool = new HostPool(std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
+    return (HostPool*)ctx->host_pool;
+}
+void msm_host_pool_destroy(zk_ctx* ctx) {
+    delete (HostPool*)ctx->host_pool;
+    ctx->host_pool = nullptr;
+}
+
 struct MsmClass {
     bool shared = false;  // precomputed-table mode: one bucket row per item spanning all windows
     int rpi = 0;          // bucket rows per item (the class's windows, or 1 when shared)
@@ -909,7 +972,6 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         for (int k = 0; k < zk_ctx::kAux; k++) hipStreamWaitEvent(ctx->aux[k], ctx->ev_fork, 0);
     }
     size_t cls_i = 0;
-    bool any_parts = false;
     for (auto& cl : classes) {
         const size_t nitems = cl.idx.size(), ns = cl.ns, nb = cl.nb, total = cl.total;
         const bool t_first = (cls_i == 0), t_last = (cls_i + 1 == (size_t)classes[0].nparts);  // the first class's parts carry the timers
@@ -993,10 +1055,12 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         ZK_HIP(ctx, hipGetLastError());
         ZK_HIP(ctx, hipMemcpyAsync(h_pts, out, cl.rows * (size_t)cl.npair * 144, hipMemcpyDeviceToHost, st));
         if (t_last) hipEventRecord(ctx->ev[3], st);
-        if (cl.nparts > 1 && cl.part + 1 < cl.nparts) {  // the host starts on this part while the next one runs
-            hipEventRecord(ctx->ev_done[cl.part % zk_ctx::kParts], st);
-            any_parts = true;
+        while (ctx->ev_cls.size() <= cls_i) {  // one completion event per class: the host starts on a class as soon as it lands
+            hipEvent_t e;
+            ZK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_cls.push_back(e);
         }
+        hipEventRecord(ctx->ev_cls[cls_i], st);
         cls_i++;
     }
     if (multi) {  // join: later work on the ctx stream is ordered after every class
@@ -1005,64 +1069,48 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0);
         }
     }
-    // ---- host combine: one doubling chain of ~256 steps per item.  Chains of a staggered class are
-    // advanced part by part as the parts arrive (overlapping the device work of the next part); the rest
-    // runs after the join, items in parallel threads. ----
+    // ---- host combine: one doubling chain of ~129 steps per item, run by the ctx's worker pool.  Classes
+    // are taken in the order they finish on the device (least work first; the parts of a staggered class
+    // in window order): while the big class is still running, the items of the small ones are already
+    // being combined.  Only the last class's chains are exposed. ----
     std::vector<zkhost::Jac> chain(count, zkhost::jac_inf());
-    float host_ms = 0;
-    auto run_class = [&](const MsmClass& cl, size_t lo, size_t hi) {
+    auto run_item = [&chain, hpin, h_out](const MsmClass& cl, size_t j) {
         WinLayout one{1, 0, 0};  // shared buckets: a single row, the window factors live in the table
-        for (size_t j = lo; j < hi; j++) {
-            const uint64_t* h = (const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.rpi * cl.npair * 18;
-            if (cl.shared) combine_windows(chain[cl.idx[j]], h, one, 0, 1, cl.c, cl.npair, cl.pair);
-            else combine_windows(chain[cl.idx[j]], h, cl.L, cl.w0, cl.wc, cl.c, cl.npair, cl.pair);
-            if (cl.part + 1 == cl.nparts) zkhost::write_normalised(chain[cl.idx[j]], h_out + 18 * cl.idx[j]);
+        const uint64_t* h = (const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.rpi * cl.npair * 18;
+        if (cl.shared) combine_windows(chain[cl.idx[j]], h, one, 0, 1, cl.c, cl.npair, cl.pair);
+        else combine_windows(chain[cl.idx[j]], h, cl.L, cl.w0, cl.wc, cl.c, cl.npair, cl.pair);
+        if (cl.part + 1 == cl.nparts) zkhost::write_normalised(chain[cl.idx[j]], h_out + 18 * cl.idx[j]);
+    };
+    std::vector<size_t> order(classes.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+        const MsmClass &x = classes[a], &y = classes[b];
+        if (x.nparts > 1 || y.nparts > 1) return a < b;  // staggered parts stay in enqueue (= window) order, last
+        return x.rows * x.row_len < y.rows * y.row_len;
+    });
+    HostPool* pool = classes.size() > 1 || count > 1 ? host_pool(ctx) : nullptr;
+    float host_ms = 0;
+    for (size_t oi = 0; oi < order.size(); oi++) {
+        const MsmClass& cl = classes[order[oi]];
+        {
+            const hipError_t e = hipEventSynchronize(ctx->ev_cls[order[oi]]);
+            if (e != hipSuccess) {
+                if (pool) pool->wait();  // jobs in flight reference this frame
+                return hip_fail(ctx, e, "hipEventSynchronize(class done)");
+            }
         }
-    };
-    struct Job {
-        const MsmClass* cl;
-        size_t j;
-    };
-    auto run_jobs = [&](std::vector<Job>& jobs) {
         auto t0 = std::chrono::steady_clock::now();
-        auto work = [&](size_t lo, size_t hi) {
-            for (size_t q = lo; q < hi; q++) run_class(*jobs[q].cl, jobs[q].j, jobs[q].j + 1);
-        };
-        if (jobs.size() <= 1) {
-            work(0, jobs.size());
-        } else {
-            size_t nth = std::min<size_t>({jobs.size(), (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)32});
-            std::vector<std::thread> th;
-            for (size_t t = 0; t < nth; t++) th.emplace_back(work, jobs.size() * t / nth, jobs.size() * (t + 1) / nth);
-            for (auto& x : th) x.join();
+        if (cl.nparts > 1 && cl.part > 0 && pool) pool->wait();  // the previous part's chains must have advanced first
+        for (size_t j = 0; j < cl.idx.size(); j++) {
+            if (pool && (cl.idx.size() > 1 || oi + 1 < order.size())) pool->submit([&run_item, &cl, j] { run_item(cl, j); });
+            else run_item(cl, j);
         }
-        host_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    };
-    if (any_parts) {
-        // parts of one class are consecutive in `classes`, highest windows first
-        int max_parts = 1;
-        for (auto& cl : classes) max_parts = std::max(max_parts, cl.nparts);
-        for (int part = 0; part + 1 < max_parts; part++) {
-            std::vector<Job> jobs;
-            for (auto& cl : classes)
-                if (cl.nparts > 1 && cl.part == part && part + 1 < cl.nparts) {
-                    ZK_HIP(ctx, hipEventSynchronize(ctx->ev_done[part % zk_ctx::kParts]));
-                    for (size_t j = 0; j < cl.idx.size(); j++) jobs.push_back(Job{&cl, j});
-                }
-            run_jobs(jobs);
+        if (oi + 1 == order.size()) {
+            if (pool) pool->wait();
+            host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();  // exposed part
         }
     }
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    auto t_tail = std::chrono::steady_clock::now();
-    {
-        std::vector<Job> jobs;
-        for (auto& cl : classes)
-            if (cl.part + 1 == cl.nparts)
-                for (size_t j = 0; j < cl.idx.size(); j++) jobs.push_back(Job{&cl, j});
-        host_ms = 0;  // report the exposed part: what runs after the device has finished
-        run_jobs(jobs);
-    }
-    (void)t_tail;
     float ms;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
     ctx->msm_ms[0] = ms;  // digits + sort (first part)
