@@ -59,7 +59,8 @@ int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
 int zk_ctx_sync(zk_ctx *ctx);
 const char *zk_version(void);
 
-/* ---- device memory helpers (thin hipMalloc/hipMemcpy wrappers for non-HIP callers) -- */
+/* ---- device memory helpers for non-HIP callers.  zk_free parks the block in the ctx (no device
+ * synchronisation) and zk_malloc of the same size reuses it; everything is released with the ctx. -- */
 int zk_malloc(zk_ctx *ctx, size_t bytes, void **d_out);
 int zk_free(zk_ctx *ctx, void *d_ptr);
 int zk_memcpy_h2d(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

@@ -95,6 +95,8 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto& a : ctx->scratch)
         if (a.p) hipFree(a.p);
+    for (auto& kv : ctx->pool_free)
+        for (void* p : kv.second) hipFree(p);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     for (auto& e : ctx->ev)
         if (e) hipEventDestroy(e);
@@ -131,14 +133,50 @@ int zk_ctx_sync(zk_ctx* ctx) {
     return ZK_OK;
 }
 
+// Device buffers are recycled per ctx: zk_free parks the block (exact size) instead of hipFree -- which
+// would synchronise the device -- and zk_malloc hands it out again.  Safe because every use of a ctx's
+// memory is ordered on the ctx stream.  The park is capped (kPoolCapBytes); beyond it blocks are really freed.
+static constexpr size_t kPoolCapBytes = (size_t)64 << 30;
 int zk_malloc(zk_ctx* ctx, size_t bytes, void** d_out) {
     if (!ctx || !d_out) return ZK_ERR_INVALID;
+    if (!bytes) bytes = 1;
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    auto it = ctx->pool_free.find(bytes);
+    if (it != ctx->pool_free.end() && !it->second.empty()) {
+        *d_out = it->second.back();
+        it->second.pop_back();
+        ctx->pool_bytes -= bytes;
+        ctx->pool_size[*d_out] = bytes;
+        return ZK_OK;
+    }
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    ZK_HIP(ctx, hipMalloc(d_out, bytes ? bytes : 1));
+    hipError_t e = hipMalloc(d_out, bytes);
+    if (e != hipSuccess) {  // out of memory: drop the parked blocks and retry once
+        (void)hipGetLastError();
+        hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->pool_free)
+            for (void* p : kv.second) hipFree(p);
+        ctx->pool_free.clear();
+        ctx->pool_bytes = 0;
+        ZK_HIP(ctx, hipMalloc(d_out, bytes));
+    }
+    ctx->pool_size[*d_out] = bytes;
     return ZK_OK;
 }
 int zk_free(zk_ctx* ctx, void* d_ptr) {
     if (!ctx) return ZK_ERR_INVALID;
+    if (!d_ptr) return ZK_OK;
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    auto it = ctx->pool_size.find(d_ptr);
+    if (it != ctx->pool_size.end()) {
+        const size_t bytes = it->second;
+        ctx->pool_size.erase(it);
+        if (ctx->pool_bytes + bytes <= kPoolCapBytes) {
+            ctx->pool_free[bytes].push_back(d_ptr);
+            ctx->pool_bytes += bytes;
+            return ZK_OK;
+        }
+    }
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP(ctx, hipFree(d_ptr));
     return ZK_OK;

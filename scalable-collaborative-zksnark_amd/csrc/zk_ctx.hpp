@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/zkhip.h"
@@ -40,6 +42,11 @@ struct zk_ctx {
     hipEvent_t ev_part[kParts] = {};
     std::vector<hipEvent_t> ev_cls;  // completion event per MSM window class of a batch
     void* host_pool = nullptr;       // worker threads for the per-item host chains (zk_msm.hip)
+    // zk_malloc / zk_free block recycling (zk_api.cpp)
+    std::unordered_map<size_t, std::vector<void*>> pool_free;
+    std::unordered_map<void*, size_t> pool_size;
+    size_t pool_bytes = 0;
+    std::mutex pool_mu;  // a garbage collector may release buffers from another thread
     int cu_count = 256;
 };
 
