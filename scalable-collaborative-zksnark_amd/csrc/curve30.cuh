@@ -198,7 +198,12 @@ template <int R>
 __device__ __forceinline__ Fq30 f30_quad_bcast(const Fq30& v) {  // lane R's value to the 4 lanes of its quad
     Fq30 r;
 #pragma unroll
-    for (int i = 0; i < 13; i++) r.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)v.l[i], R * 0x55, 0xf, 0xf, true);
+    for (int i = 0; i < 13; i++) {
+        r.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)v.l[i], R * 0x55, 0xf, 0xf, true);
+        // keep the broadcast a plain v_mov_b32_dpp: folded into a following subtraction (DPP combine) the
+        // lane permutation landed on the wrong operand (observed: r.y of xyzz30_acc_quad wrong in 3 of 4 lanes)
+        asm volatile("" : "+v"(r.l[i]));
+    }
     return r;
 }
 __device__ __forceinline__ Fq30 f30_sel4(int role, const Fq30& a0, const Fq30& a1, const Fq30& a2, const Fq30& a3) {
@@ -239,6 +244,33 @@ __device__ __forceinline__ void xyzz30_add_quad(const void* __restrict__ in, siz
     const Fq30 ZZZ3 = f30_quad_bcast<1>(m4), T1 = f30_quad_bcast<2>(m4), T2 = f30_quad_bcast<3>(m4);
     const Fq30 Y3 = f30_sub2(T2, T1);  // < 4q
     f30_store_chunks(out, io, 3 * role, f30_sel4(role, X3, Y3, ZZ3, ZZZ3));
+}
+
+// acc += in[ib] with acc held (replicated) in the registers of all four lanes of the quad: the chained
+// form for the fix-up, same rounds as xyzz30_add_quad.  Each lane fetches the one coordinate of b its
+// round-1 product needs (b.zz | b.x | b.zzz | b.y).
+__device__ __forceinline__ Xyzz30 xyzz30_acc_quad(const Xyzz30& acc, const void* __restrict__ in, size_t ib, int role) {
+    const Fq30 bpart = f30_load_chunks(in, ib, role == 0 ? 6 : role == 1 ? 0 : role == 2 ? 9 : 3);
+    const Fq30 zz2 = f30_quad_bcast<0>(bpart);
+    if (f30_all_zero(zz2)) return acc;                       // b is infinity
+    if (xyzz30_is_inf(acc)) return xyzz30_load(in, ib);      // (all lanes load all of b)
+    const Fq30 zzz2 = f30_quad_bcast<2>(bpart);
+    const Fq30 m1 = f30_mul(f30_sel4(role, acc.x, bpart, acc.y, bpart), f30_sel4(role, bpart, acc.zz, bpart, acc.zzz));
+    const Fq30 u1 = f30_quad_bcast<0>(m1), u2 = f30_quad_bcast<1>(m1), s1 = f30_quad_bcast<2>(m1), s2 = f30_quad_bcast<3>(m1);
+    const Fq30 P = f30_sub2(u2, u1);  // < 4q
+    const Fq30 R = f30_sub2(s2, s1);  // < 4q
+    const Fq30 m2 = f30_mul(f30_sel4(role, acc.zz, acc.zzz, P, R), f30_sel4(role, zz2, zzz2, P, R));
+    const Fq30 A = f30_quad_bcast<0>(m2), B = f30_quad_bcast<1>(m2), PP = f30_quad_bcast<2>(m2), RR = f30_quad_bcast<3>(m2);
+    const Fq30 m3 = f30_mul(f30_sel4(role, u1, A, P, P), PP);
+    const Fq30 Q = f30_quad_bcast<0>(m3), ZZ3 = f30_quad_bcast<1>(m3), PPP = f30_quad_bcast<2>(m3);
+    if (f30_is_zero_2q(ZZ3)) return xyzz30_add(acc, xyzz30_load(in, ib));  // doubling / cancellation: every lane alone, same result
+    Xyzz30 r;
+    r.x = f30_sub4(f30_sub2(RR, PPP), f30_add(Q, Q));  // < 8q
+    const Fq30 m4 = f30_mul(f30_sel4(role, B, B, s1, R), f30_sel4(role, PPP, PPP, PPP, f30_sub8(Q, r.x)));
+    r.zzz = f30_quad_bcast<1>(m4);
+    r.y = f30_sub2(f30_quad_bcast<3>(m4), f30_quad_bcast<2>(m4));  // < 4q
+    r.zz = ZZ3;
+    return r;
 }
 
 }  // namespace zk

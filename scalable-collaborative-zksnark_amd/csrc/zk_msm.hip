@@ -502,6 +502,35 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets,
     xyzz30_store(buckets, g, acc);
 }
 
+// the same with one bucket per QUAD of lanes (small and mid-size MSMs: the chain of dependent additions
+// is pure latency, a quad runs each in 4 multiplication rounds instead of 13)
+__global__ void __launch_bounds__(kBlk) k_fixup_quad(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, u32 T,
+                                                   size_t tiles_per_w, size_t total, void* __restrict__ buckets,
+                                                   const void* __restrict__ heads, const void* __restrict__ tails,
+                                                   u32* __restrict__ long_count, u32* __restrict__ long_list) {
+    const size_t tq = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    const size_t g = tq >> 2;
+    const int role = (int)(tq & 3);
+    if (g >= total) return;
+    const size_t w = g / nb;
+    const u32 s = offsets[g], c = counts[g];
+    if (c == 0) {
+        f30_store_chunks(buckets, g, 3 * role, f30_zero());
+        return;
+    }
+    const u32 e = s + c;
+    const u32 t0 = s / T, t1 = (e - 1) / T;
+    if (t0 == t1) return;  // the whole bucket sat inside one tile and was stored by k_accum_tiles
+    if (t1 - t0 > kLongSpan) {
+        if (role == 0) long_list[atomicAdd(long_count, 1u)] = (u32)g;
+        return;
+    }
+    const size_t base = w * tiles_per_w;
+    Xyzz30 acc = (s == t0 * T) ? xyzz30_load(heads, base + t0) : xyzz30_load(tails, base + t0);
+    for (u32 t = t0 + 1; t <= t1; t++) acc = xyzz30_acc_quad(acc, heads, base + t, role);
+    f30_store_chunks(buckets, g, 3 * role, role == 0 ? acc.x : role == 1 ? acc.y : role == 2 ? acc.zz : acc.zzz);
+}
+
 // one workgroup per long bucket: strided partial sums per lane, then an LDS tree
 __global__ void __launch_bounds__(kBlk) k_fixup_long(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, u32 T,
                                                    size_t tiles_per_w, void* __restrict__ buckets, const void* __restrict__ heads,
@@ -828,6 +857,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
     static const bool pair_env = getenv("ZK_MSM_PAIR") && atoi(getenv("ZK_MSM_PAIR")) != 0;
+    static const size_t fixq_max = getenv("ZK_MSM_FIXQ") ? (size_t)atol(getenv("ZK_MSM_FIXQ")) : 65536;  // buckets per class
     static const size_t quad_max = getenv("ZK_MSM_QUAD") ? (size_t)atol(getenv("ZK_MSM_QUAD")) : 32768;  // additions per pass (above it the plain pass is faster: measured)
     static const int split_env = getenv("ZK_MSM_SPLIT") ? atoi(getenv("ZK_MSM_SPLIT")) : 1;  // measured on MI355X: no gain (every phase is ALU-bound), off by default
     // ---- validate + classify by window width ----
@@ -1025,9 +1055,14 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
                            (u32)ns, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
         if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(ctx->ev_part[cl.part % zk_ctx::kParts], st);
         if (t_last) hipEventRecord(ctx->ev[4], st);
-        hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
-                           (const u32*)counts, nb, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
-                           longs + 1);
+        if (total <= fixq_max)
+            hipLaunchKernelGGL(k_fixup_quad, dim3((unsigned)((4 * total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
+                               (const u32*)counts, nb, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
+                               longs + 1);
+        else
+            hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
+                               (const u32*)counts, nb, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
+                               longs + 1);
         hipLaunchKernelGGL(k_fixup_long, dim3(512), dim3(kBlk), 0, st, (const u32*)offsets, (const u32*)counts, nb, cl.T,
                            cl.tiles_per_w, bufA, (const void*)heads, (const void*)tails, (const u32*)longs, (const u32*)(longs + 1));
         if (t_last) hipEventRecord(ctx->ev[2], st);

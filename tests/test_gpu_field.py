@@ -144,3 +144,16 @@ def test_fr_deinterleave(ctx):
     t = rand_fr(2 * n, 77)
     ev, od = ctx.fr_deinterleave(ctx.to_device(t), n)
     assert (ev.download((n, 4)) == t[0::2]).all() and (od.download((n, 4)) == t[1::2]).all()
+
+
+def test_quad_lane_additions(tmp_path):
+    """the four-lane XYZZ additions of the reduction / fix-up passes == the single-lane formulas"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "quad_selftest")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-pragma-unroll-threshold=1000000",
+                           "-o", exe, os.path.join(root, "tools", "quad_selftest.hip")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "add_quad mismatches 0, acc_quad mismatches 0" in out.stdout, out.stdout + out.stderr
