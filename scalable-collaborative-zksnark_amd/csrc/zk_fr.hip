@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 namespace zk {
 
@@ -136,15 +137,30 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
     if (W != 0) block_reduce_store<NS>(acc, lds, partials, blockIdx.x, gridDim.x);
 }
 
-// sums partials[s][0..nb) -> out[s]; one block per s
-__global__ void __launch_bounds__(kBlock) k_reduce_partials(const void* __restrict__ partials, size_t nb, void* __restrict__ out) {
+// the per-block partial sums of ALL passes of one call, reduced in a single launch after the last
+// pass (the sums of round i are not an input of round i+1): block b -> output b of pass p
+struct ReducePlan {
+    static constexpr int kMax = 24;
+    const void* partials[kMax];  // [nsums][nb] Fr
+    unsigned nb[kMax];
+    unsigned first[kMax + 1];    // first output index of pass p (prefix sums of nsums); outputs are consecutive in `out`
+    int n;
+};
+__global__ void __launch_bounds__(kBlock) k_reduce_all(ReducePlan plan, void* __restrict__ out) {
     extern __shared__ uint4 lds[];
-    const int s = blockIdx.x;
+    int p = 0;
+    while (p + 1 < plan.n && blockIdx.x >= plan.first[p + 1]) p++;
+    const size_t s = blockIdx.x - plan.first[p], nb = plan.nb[p];
     Fr acc[1];
     acc[0] = fp_zero<FrCfg>();
-    for (size_t i = threadIdx.x; i < nb; i += kBlock) acc[0] = fr_add(acc[0], fr_load(partials, (size_t)s * nb + i));
-    block_reduce_store<1>(acc, lds, out, s, 0);
+    for (size_t i = threadIdx.x; i < nb; i += kBlock) acc[0] = fr_add(acc[0], fr_load(plan.partials[p], s * nb + i));
+    block_reduce_store<1>(acc, lds, out, blockIdx.x, 0);
 }
+
+// the tail's challenges travel as kernel arguments (at most log2(kTailMax) = 11 rounds)
+struct TailChal {
+    uint64_t c[11 * 4];
+};
 
 // ---------------------------------------------------------------------------------------
 // Tail: all remaining rounds on a table of m <= kTailMax elements inside ONE workgroup, the
@@ -153,7 +169,7 @@ __global__ void __launch_bounds__(kBlock) k_reduce_partials(const void* __restri
 // ---------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) k_tail(const void* __restrict__ f, const void* __restrict__ g, size_t m, int rounds,
-                                               const void* __restrict__ chal, void* __restrict__ sums_out,
+                                               TailChal chal, void* __restrict__ sums_out,
                                                void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go) {
     // One barrier per round: the per-lane partial sums of every round are parked in LDS and ALL
     // rounds are reduced together at the end (the sums of round i are not an input of round i+1).
@@ -175,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(const void* __restrict__ f, con
     for (int rd = 0; rd < rounds; rd++) {
         const size_t h = mm >> 1;
         const size_t cnt = h < (size_t)kBlock ? h : (size_t)kBlock;
-        const Fr r = fr_load(chal, rd);
+        const Fr r = fr_load(chal.c, rd);  // kernel-argument segment: no H2D copy, no extra buffer
         Fr acc[NS];
 #pragma unroll
         for (int s = 0; s < NS; s++) acc[s] = fp_zero<FrCfg>();
@@ -267,30 +283,24 @@ static int ilog2(size_t x) {
     return l;
 }
 
-template <int K, int MODE>
-static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void* go, size_t m, const uint64_t* chal,
-                       void* d_sums_at, void* qbase) {
-    constexpr int W = ModeTraits<MODE>::W;
-    const size_t q = m >> K;
+static size_t pass_blocks(zk_ctx* ctx, size_t m, int k) {
+    const size_t q = m >> k;
     size_t blocks = (q + kBlock - 1) / kBlock;
     const size_t maxb = (size_t)ctx->cu_count * 4;
-    if (blocks > maxb) blocks = maxb;
+    return blocks > maxb ? maxb : blocks;
+}
+template <int K, int MODE>
+static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void* go, size_t m, const uint64_t* chal, void* partials,
+                       void* qbase) {
+    constexpr int W = ModeTraits<MODE>::W;
+    const size_t blocks = pass_blocks(ctx, m, K);
     ChalArgs ch;
     std::memset(&ch, 0, sizeof(ch));
     std::memcpy(&ch, chal, (size_t)K * 32);
-    void* partials = nullptr;
-    size_t lds = 0;
-    if (W != 0) {
-        partials = scratch(ctx, 4, (size_t)K * W * blocks * 32);
-        if (!partials) return ZK_ERR_OOM;
-        lds = (size_t)K * W * kBlock * 32;
-    }
+    const size_t lds = (W != 0) ? (size_t)K * W * kBlock * 32 : 0;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_pass<K, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
                        qbase);
-    if (W != 0)
-        hipLaunchKernelGGL(k_reduce_partials, dim3(K * W), dim3(kBlock), (size_t)kBlock * 32, ctx->stream, partials, blocks,
-                           d_sums_at);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -310,10 +320,6 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     if (!d_res) return ZK_ERR_OOM;
     void* d_last_f = d_res + rounds * W * fr;
     void* d_last_g = d_res + (rounds * W + 1) * fr;
-    // challenges on device for the tail kernel
-    char* d_chal = (char*)scratch(ctx, 6, std::max<size_t>(rounds, 1) * fr);
-    if (!d_chal) return ZK_ERR_OOM;
-    if (rounds) ZK_HIP(ctx, hipMemcpyAsync(d_chal, h_chal, rounds * fr, hipMemcpyHostToDevice, ctx->stream));
 
     const void* cf = d_f;
     const void* cg = d_g;
@@ -330,24 +336,61 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
             if (!bufs[2] || !bufs[3]) return ZK_ERR_OOM;
         }
     }
-    while (done < rounds && m > tail_max) {
-        const size_t kcap = (MODE == 1) ? 2 : KMAX;  // measured: K = 3 product passes (35 dependent muls per lane) are no faster than K = 2
-        int k = (int)std::min<size_t>({kcap, rounds - done, (size_t)(ilog2(m) - ilog2(tail_max))});
+    // plan the passes first: every pass parks its per-block partial sums in its own slice of one arena
+    struct Pass {
+        int k;
+        size_t m, blocks, part_off;
+    };
+    std::vector<Pass> plan;
+    size_t part_bytes = 0;
+    {
+        size_t mm = m, dd = 0;
+        while (dd < rounds && mm > tail_max) {
+            const size_t kcap = (MODE == 1) ? 2 : KMAX;  // measured: K = 3 product passes (35 dependent muls per lane) are no faster than K = 2
+            const int k = (int)std::min<size_t>({kcap, rounds - dd, (size_t)(ilog2(mm) - ilog2(tail_max))});
+            const size_t blocks = pass_blocks(ctx, mm, k);
+            plan.push_back(Pass{k, mm, blocks, part_bytes});
+            part_bytes += (size_t)k * W * blocks * fr;
+            mm >>= k;
+            dd += k;
+        }
+    }
+    if ((int)plan.size() > ReducePlan::kMax) return fail(ctx, ZK_ERR_INVALID, "internal: too many passes");
+    char* d_part = nullptr;
+    if (W != 0 && part_bytes) {
+        d_part = (char*)scratch(ctx, 4, part_bytes);
+        if (!d_part) return ZK_ERR_OOM;
+    }
+    ReducePlan rp;
+    std::memset(&rp, 0, sizeof(rp));
+    for (const Pass& ps : plan) {
+        const int k = ps.k;
         const bool final_out = (MODE == 2) && (done + k == rounds);
         void* fo = final_out ? d_out : bufs[flip];
         void* go = TWO ? bufs[2 + flip] : nullptr;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
-        void* sums_at = d_res + done * W * fr;
+        void* part = d_part ? d_part + ps.part_off : nullptr;
         int rc;
-        if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
-        else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
-        else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, sums_at, qb);
+        if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
+        else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
+        else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
         if (rc) return rc;
+        if (W != 0) {  // outputs of this pass: sums of rounds done .. done+k-1, consecutive in d_res
+            rp.partials[rp.n] = part;
+            rp.nb[rp.n] = (unsigned)ps.blocks;
+            rp.first[rp.n] = (unsigned)(done * W);
+            rp.n++;
+            rp.first[rp.n] = (unsigned)((done + k) * W);
+        }
         cf = fo;
         cg = go;
         m >>= k;
         done += k;
         flip ^= 1;
+    }
+    if (W != 0 && rp.n) {
+        hipLaunchKernelGGL(k_reduce_all, dim3(rp.first[rp.n]), dim3(kBlock), (size_t)kBlock * 32, ctx->stream, rp, (void*)d_res);
+        ZK_HIP(ctx, hipGetLastError());
     }
     if (done < rounds || MODE != 2) {
         // tail: the remaining rounds (possibly zero) in one workgroup; also emits the final table
@@ -363,7 +406,11 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
             hipFuncSetAttribute((const void*)k_tail<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_tail<MODE>), dim3(1), dim3(kBlock), lds, ctx->stream, cf, cg, m, rl, (const void*)(d_chal + done * fr),
+        TailChal tc;
+        std::memset(&tc, 0, sizeof(tc));
+        if (rl > 11) return fail(ctx, ZK_ERR_INVALID, "internal: tail rounds");
+        if (rl) std::memcpy(tc.c, h_chal + 4 * done, (size_t)rl * fr);
+        hipLaunchKernelGGL((k_tail<MODE>), dim3(1), dim3(kBlock), lds, ctx->stream, cf, cg, m, rl, tc,
                            (void*)(d_res + done * W * fr), qb, fo, d_last_g);
         ZK_HIP(ctx, hipGetLastError());
     } else if (rounds == 0) {
