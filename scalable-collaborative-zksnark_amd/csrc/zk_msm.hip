@@ -472,16 +472,25 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
     else xyzz30_store(tails, g, acc);
 }
 
+// which bucket rows belong to a window one bit narrower than the widest: row r of the launch is window
+// w0 + r % rpi of its item; such a row only ever uses the lower half of its buckets (and of every row the
+// reduction derives from it), so the upper halves are neither written nor read.
+struct NarrowRows {
+    int rpi, w0, from;
+    __host__ __device__ bool narrow(size_t row) const { return w0 + (int)(row % (size_t)rpi) >= from; }
+};
+
 // stitch the runs cut by tile boundaries; also writes infinity for empty buckets.  Buckets that
 // span more than kLongSpan tiles (skewed scalars: many equal digits) are queued for k_fixup_long.
 static constexpr u32 kLongSpan = 24;
-__global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, u32 T,
+__global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, NarrowRows nr, u32 T,
                                               size_t tiles_per_w, size_t total, void* __restrict__ buckets,
                                               const void* __restrict__ heads, const void* __restrict__ tails,
                                               u32* __restrict__ long_count, u32* __restrict__ long_list) {
     const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (g >= total) return;
     const size_t w = g / nb;
+    if (nr.narrow(w) && (g % nb) >= nb / 2) return;  // never populated, never read by the reduction
     const u32 s = offsets[g], c = counts[g];
     if (c == 0) {
         Xyzz30 z;
@@ -504,7 +513,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets,
 
 // the same with one bucket per QUAD of lanes (small and mid-size MSMs: the chain of dependent additions
 // is pure latency, a quad runs each in 4 multiplication rounds instead of 13)
-__global__ void __launch_bounds__(kBlk) k_fixup_quad(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, u32 T,
+__global__ void __launch_bounds__(kBlk) k_fixup_quad(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, NarrowRows nr, u32 T,
                                                    size_t tiles_per_w, size_t total, void* __restrict__ buckets,
                                                    const void* __restrict__ heads, const void* __restrict__ tails,
                                                    u32* __restrict__ long_count, u32* __restrict__ long_list) {
@@ -513,6 +522,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup_quad(const u32* __restrict__ off
     const int role = (int)(tq & 3);
     if (g >= total) return;
     const size_t w = g / nb;
+    if (nr.narrow(w) && (g % nb) >= nb / 2) return;  // never populated, never read by the reduction
     const u32 s = offsets[g], c = counts[g];
     if (c == 0) {
         f30_store_chunks(buckets, g, 3 * role, f30_zero());
@@ -565,7 +575,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup_long(const u32* __restrict__ off
 }
 
 // one bit-plane pass of the bucket reduction.  in: [W][rows][len], out: [W][rows+1][len/2]
-__global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len) {
+__global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len, NarrowRows nr) {
     const size_t half = len >> 1;
     const size_t per_w = (size_t)(rows + 1) * half;
     const size_t t = (size_t)blockIdx.x * kBlk + threadIdx.x;
@@ -573,9 +583,13 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
     const size_t w = t / per_w, rem = t % per_w;
     const int r = (int)(rem / half);
     const size_t j = rem % half;
+    const size_t eff = nr.narrow(w) ? half : len;  // elements of every row of this window that can be non-trivial
+    if (2 * j >= eff) return;
     const size_t in_w = w * (size_t)rows * len;
     const size_t src_row = (r < rows - 1) ? (size_t)r : (size_t)(rows - 1);  // rows-1 = the L row
-    Xyzz30 b = xyzz30_load(in, in_w + src_row * len + 2 * j + 1);
+    Xyzz30 b;
+    if (2 * j + 1 < eff) b = xyzz30_load(in, in_w + src_row * len + 2 * j + 1);
+    else xyzz30_set_inf(b);
     Xyzz30 res;
     if (r == rows - 1) {
         res = b;  // odd elements of L become the new plane row
@@ -588,7 +602,8 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
 
 // the same pass with one addition per QUAD of lanes (curve30.cuh: xyzz30_add_quad): for the late passes,
 // which are a single dependent addition of pure latency, this cuts the chain from 13 multiplications to 4
-__global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len) {
+__global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len,
+                                                   NarrowRows nr) {
     const size_t half = len >> 1;
     const size_t per_w = (size_t)(rows + 1) * half;
     const size_t tq = (size_t)blockIdx.x * kBlk + threadIdx.x;
@@ -598,11 +613,18 @@ __global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in
     const size_t w = t / per_w, rem = t % per_w;
     const int r = (int)(rem / half);
     const size_t j = rem % half;
+    const size_t eff = nr.narrow(w) ? half : len;
+    if (2 * j >= eff) return;
     const size_t in_w = w * (size_t)rows * len;
     const size_t src_row = (r < rows - 1) ? (size_t)r : (size_t)(rows - 1);
     const size_t ib = in_w + src_row * len + 2 * j + 1;
+    const bool b_real = 2 * j + 1 < eff;
     if (r == rows - 1) {  // odd elements of L become the new plane row: lane r copies coordinate r
-        f30_store_chunks(out, t, 3 * role, f30_load_chunks(in, ib, 3 * role));
+        f30_store_chunks(out, t, 3 * role, b_real ? f30_load_chunks(in, ib, 3 * role) : f30_zero());
+        return;
+    }
+    if (!b_real) {  // a + infinity
+        f30_store_chunks(out, t, 3 * role, f30_load_chunks(in, ib - 1, 3 * role));
         return;
     }
     xyzz30_add_quad(in, ib - 1, ib, out, t, role);
@@ -834,7 +856,9 @@ struct MsmClass {
     int rpi = 0;          // bucket rows per item (the class's windows, or 1 when shared)
     size_t row_len = 0;   // entries per row: 2 * ns (points and their endomorphism images), or W * ns when shared
     int copies = 2;
-    int c = 0;
+    int c = 0;            // bits of the widest window: 2^(c-1) buckets per row, c reduced points per row
+    int key_c = 0;        // the window bits asked for (class key)
+    int narrow_from = 0x7fffffff;  // windows with index >= this are one bit narrower
     int w0 = 0, wc = 0;   // the windows [w0, w0 + wc) of the layout this class works on
     int part = 0, nparts = 1;  // a big class is cut by windows into parts that run staggered (see below)
     int npair = 0;        // points per window row handed to the host (k_finish)
@@ -879,18 +903,22 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         if (shared) c = it.srs->table_c;
         MsmClass* cl = nullptr;
         for (auto& x : classes)
-            if (x.c == c && x.shared == shared) cl = &x;
+            if (x.key_c == c && x.shared == shared) cl = &x;
         if (!cl) {
             classes.emplace_back();
             cl = &classes.back();
-            cl->c = c;
+            cl->key_c = c;
             cl->shared = shared;
             cl->L = msm_layout(c, shared ? kFullBits : kEndoBits);
+            // the balanced layout may end up narrower than asked: buckets and planes follow the WIDEST window;
+            // windows one bit narrower (index >= L.rem) use only the lower half of their bucket row
+            cl->c = cl->L.base + (cl->L.rem ? 1 : 0);
+            cl->narrow_from = (shared || cl->L.rem == 0) ? 0x7fffffff : cl->L.rem;
             cl->w0 = 0;
             cl->wc = cl->L.W;
-            cl->nb = (size_t)1 << (c - 1);
+            cl->nb = (size_t)1 << (cl->c - 1);
             cl->pair = pair_env;
-            cl->npair = cl->pair ? std::max(1, c / 2) : c;
+            cl->npair = cl->pair ? std::max(1, cl->c / 2) : cl->c;
         }
         cl->idx.push_back(k);
         cl->ns = std::max(cl->ns, (it.n + 3) & ~(size_t)3);
@@ -1055,13 +1083,14 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
                            (u32)ns, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
         if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(ctx->ev_part[cl.part % zk_ctx::kParts], st);
         if (t_last) hipEventRecord(ctx->ev[4], st);
+        const NarrowRows nrw{cl.rpi, cl.w0, cl.narrow_from};
         if (total <= fixq_max)
             hipLaunchKernelGGL(k_fixup_quad, dim3((unsigned)((4 * total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
-                               (const u32*)counts, nb, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
+                               (const u32*)counts, nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                                longs + 1);
         else
             hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
-                               (const u32*)counts, nb, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
+                               (const u32*)counts, nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                                longs + 1);
         hipLaunchKernelGGL(k_fixup_long, dim3(512), dim3(kBlk), 0, st, (const u32*)offsets, (const u32*)counts, nb, cl.T,
                            cl.tiles_per_w, bufA, (const void*)heads, (const void*)tails, (const u32*)longs, (const u32*)(longs + 1));
@@ -1074,10 +1103,10 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             size_t threads = cl.rows * (size_t)(rows + 1) * (len >> 1);
             if (threads <= quad_max)  // too few additions to fill the chip: spend four lanes on each
                 hipLaunchKernelGGL(k_halve_quad, dim3((unsigned)((4 * threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
-                                   (int)cl.rows, rows, len);
+                                   (int)cl.rows, rows, len, nrw);
             else
                 hipLaunchKernelGGL(k_halve, dim3((unsigned)((threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
-                                   (int)cl.rows, rows, len);
+                                   (int)cl.rows, rows, len, nrw);
             std::swap(in, out);
             rows++;
             len >>= 1;
