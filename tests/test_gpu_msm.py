@@ -16,7 +16,7 @@ def test_msm_matches_oracle(ctx, co, n):
     assert (jac_norm_to_affine(got) == co.msm_g1(bases, scalars)).all()
 
 
-@pytest.mark.parametrize("c", [4, 7, 8, 11, 13, 15, 16])
+@pytest.mark.parametrize("c", [2, 3, 4, 5, 7, 8, 11, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_msm_all_window_sizes(ctx, co, c):
     n = 3000
     bases, _ = synthetic_bases(n, 77)
@@ -199,3 +199,36 @@ def test_msm_precomputed_srs_matches_oracle(ctx, co, n, c):
         exp = co.msm_g1(bases, scalars)
         assert (jac_norm_to_affine(got[0]) == exp).all() and (jac_norm_to_affine(got[1]) == exp).all()
         assert (jac_norm_to_affine(got[2]) == co.msm_g1(bases[off : off + m], scalars[off : off + m])).all()
+
+
+def test_msm_2pow22_window19_linearity(ctx, co):
+    """
+    above 2^22 the 19-bit layout (7 windows) takes over; too large for the CPU oracle in seconds, so:
+    MSM(b, s1 + s2) == MSM(b, s1) + MSM(b, s2), and the prefix 2^14 of the same vectors against the oracle
+    """
+    import pyoracle as po
+    from helpers import pt_ints
+
+    n = 1 << 22
+    srs = ctx.srs_generate(0x1111, 0x2222, n)
+    s1, s2 = rand_fr(n, 301), rand_fr(n, 302)
+    d1, d2 = ctx.to_device(s1), ctx.to_device(s2)
+    assert ctx.lib.zk_msm_window(n) == 19
+    a = pt_ints(jac_norm_to_affine(ctx.msm_g1(srs, d1, n)))
+    b = pt_ints(jac_norm_to_affine(ctx.msm_g1(srs, d2, n)))
+    both = pt_ints(jac_norm_to_affine(ctx.msm_g1(srs, ctx.fr_add(d1, d2, n), n)))
+    assert both == po.g1_add(a, b)
+    m = 1 << 14
+    bases = srs.download()[:m].copy()
+    assert (jac_norm_to_affine(ctx.msm_g1(srs, d1, m)) == co.msm_g1(bases, s1[:m].copy())).all()
+
+
+def test_device_buffers_are_recycled(ctx):
+    """zk_free parks a block, zk_malloc of the same size hands it out again (no hipFree / device sync)"""
+    a = ctx.alloc(12345 * 32)
+    p = a.ptr
+    a.free()
+    b = ctx.alloc(12345 * 32)
+    assert b.ptr == p
+    c = ctx.alloc(12345 * 32)
+    assert c.ptr != p
