@@ -218,8 +218,8 @@ def commit(be, powers_of_g, peval, length: int) -> np.ndarray:
     return be.msm_g1(powers_of_g[level], peval, length)
 
 
-def open_(be, powers_of_g, peval, length: int, point: np.ndarray):
-    """dpoly_comm.rs:299-325 (= d_local_open :327-353) -> (value [4], proofs [n,18])"""
+def _open_items(be, powers_of_g, peval, length: int, point: np.ndarray):
+    """the fold rounds of one open (:309-323): returns (value [4], q buffer, srs list, scalar views, lens)"""
     n = length.bit_length() - 1
     q, value = be.open_rounds(peval, length, point[:n])
     srs, bufs, lens, off, m = [], [], [], 0, length
@@ -230,16 +230,52 @@ def open_(be, powers_of_g, peval, length: int, point: np.ndarray):
         lens.append(h)
         off += h
         m = h
+    return value, q, srs, bufs, lens
+
+
+def open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray]):
+    """
+    several independent opens (dpoly_comm.rs:299-325 each) with ALL their commitments in one batched MSM
+    pass: -> list of (value [4], proofs [n_k, 18]).  Same outputs as calling open_ once per polynomial.
+    """
+    vals, keep, srs, bufs, ms, cuts = [], [], [], [], [], [0]
+    for pe, length, pt in zip(pevals, lens, points):
+        v, q, s_, b_, l_ = _open_items(be, powers_of_g, pe, length, np.asarray(pt, dtype=np.uint64).reshape(-1, 4))
+        vals.append(v)
+        keep.append(q)  # the q buffers must outlive the batched MSM
+        srs += s_
+        bufs += b_
+        ms += l_
+        cuts.append(len(ms))
+    proofs = be.msm_g1_batch(srs, bufs, ms) if ms else np.zeros((0, 18), dtype=np.uint64)
+    return [(vals[k], proofs[cuts[k] : cuts[k + 1]]) for k in range(len(vals))]
+
+
+def open_(be, powers_of_g, peval, length: int, point: np.ndarray):
+    """dpoly_comm.rs:299-325 (= d_local_open :327-353) -> (value [4], proofs [n,18])"""
     # the n commitments of one open are independent: one batched pass (the reference commits them one by one)
-    return value, be.msm_g1_batch(srs, bufs, lens)
+    return open_many(be, powers_of_g, [peval], [length], [point])[0]
+
+
+def d_commit_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], net: Net) -> np.ndarray:
+    """several d_commit (dpoly_comm.rs:276-297) in one MSM pass and one exchange -> [k, 18]"""
+    k = len(lens)
+    if not k:
+        return np.zeros((0, 18), dtype=np.uint64)
+    srs = []
+    for length in lens:
+        level = length.bit_length() - 1
+        assert level < len(powers_of_g) and length == 1 << level
+        srs.append(powers_of_g[level])
+    local = be.msm_g1_batch(srs, list(pevals), list(lens))  # [k, 18]
+    got = net.all_gather(local)  # [party][k, 18]
+    ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
+    return be.g1_lincomb_batch(np.stack([np.stack([got[p][i] for p in range(net.n_parties)]) for i in range(k)]), ones)
 
 
 def d_commit(be, powers_of_g, peval, length: int, net: Net) -> np.ndarray:
     """dpoly_comm.rs:276-297: every party ends with the sum of the local commitments"""
-    local = commit(be, powers_of_g, peval, length)
-    pts = np.stack(net.all_gather(local))
-    ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
-    return be.g1_lincomb(pts, ones)
+    return d_commit_many(be, powers_of_g, [peval], [length], net)[0]
 
 
 def c_commit(be, powers_of_g, pevals: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net) -> np.ndarray:
@@ -252,23 +288,78 @@ def c_commit(be, powers_of_g, pevals: Sequence, lens: Sequence[int], pp: PackedS
     return d_msm(be, bases, pevals, lens, pp, net)
 
 
+def d_open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], net: Net):
+    """
+    several d_open (dpoly_comm.rs:355-398) at once: the local opens share one batched MSM pass, the
+    values and proofs travel in one exchange each, the leader's root opens share another MSM pass.
+    -> list of (root value [4], root proofs ++ summed local proofs) for the leader, (0, []) for workers.
+    """
+    k = len(lens)
+    if not k:
+        return []
+    plog = net.n_parties.bit_length() - 1
+    pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
+    local = open_many(be, powers_of_g, pevals, lens, [p[plog:] for p in pts])
+    cuts = [0]
+    for _, prf in local:
+        cuts.append(cuts[-1] + len(prf))
+    vals = net.all_gather(np.stack([np.asarray(v, dtype=np.uint64).reshape(4) for v, _ in local]))  # [party][k, 4]
+    prfs = net.all_gather(np.concatenate([prf for _, prf in local]) if cuts[-1] else np.zeros((0, 18), dtype=np.uint64))
+    if not net.is_leader:
+        return [(ZERO.copy(), np.zeros((0, 18), dtype=np.uint64)) for _ in range(k)]
+    ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
+    total = cuts[-1]
+    pi = be.g1_lincomb_batch(np.stack([np.stack([prfs[p][i] for p in range(net.n_parties)]) for i in range(total)]), ones) if total else np.zeros((0, 18), dtype=np.uint64)
+    roots = open_many(be, powers_of_g, [be.to_device(np.stack([vals[p][i] for p in range(net.n_parties)])) for i in range(k)],
+                      [net.n_parties] * k, [p[:plog] for p in pts])
+    out = []
+    for i in range(k):
+        root_val, root_proofs = roots[i]
+        allp = list(root_proofs) + list(pi[cuts[i] : cuts[i + 1]])  # root proofs FIRST (:379-384)
+        out.append((root_val, np.stack(allp) if allp else np.zeros((0, 18), dtype=np.uint64)))
+    return out
+
+
 def d_open(be, powers_of_g, peval, length: int, point: np.ndarray, net: Net):
     """
     dpoly_comm.rs:355-398.  Leader: (root value [4], root proofs (s entries) ++ summed local proofs
     (n' entries)) -- root proofs FIRST (:379-384); workers: (0, []).
     """
-    plog = net.n_parties.bit_length() - 1
-    point = np.asarray(point, dtype=np.uint64).reshape(-1, 4)
-    value, proofs = open_(be, powers_of_g, peval, length, point[plog:])
-    vals = net.all_gather(np.asarray(value, dtype=np.uint64).reshape(4))
-    prfs = net.all_gather(proofs)
-    if not net.is_leader:
-        return ZERO.copy(), np.zeros((0, 18), dtype=np.uint64)
-    ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
-    pi = list(be.g1_lincomb_batch(np.stack([np.stack([prfs[p][i] for p in range(net.n_parties)]) for i in range(len(proofs))]), ones)) if len(proofs) else []
-    root_val, root_proofs = open_(be, powers_of_g, be.to_device(np.stack(vals)), net.n_parties, point[:plog])
-    allp = list(root_proofs) + pi
-    return root_val, (np.stack(allp) if allp else np.zeros((0, 18), dtype=np.uint64))
+    return d_open_many(be, powers_of_g, [peval], [length], [point], net)[0]
+
+
+def c_open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], pp: PackedSharingParams, net: Net):
+    """several c_open (dpoly_comm.rs:401-464) whose q_i commitments share ONE d_msm -> list of (value, proofs)"""
+    k = len(lens)
+    pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
+    vals, keep, bufs, ms, cuts = [], [], [], [], [0]
+    for pe, length, pt in zip(pevals, lens, pts):
+        n = length.bit_length() - 1
+        q, value = be.open_rounds(pe, length, pt[:n])
+        keep.append(q)
+        vals.append(value)
+        off, m = 0, length
+        for _ in range(n):
+            h = m // 2
+            bufs.append(q.at(32 * off))
+            ms.append(h)
+            off += h
+            m = h
+        cuts.append(len(ms))
+    com = c_commit(be, powers_of_g, bufs, ms, pp, net) if ms else np.zeros((0, 18), dtype=np.uint64)
+    out = []
+    for i in range(k):
+        res = list(com[cuts[i] : cuts[i + 1]])
+        cur = _fr_vec_to_ints(pss2ss(vals[i], pp, net))
+        pt = _fr_vec_to_ints(pts[i])
+        for r in range(pp.l.bit_length() - 1):
+            h = len(cur) // 2
+            qi = [(cur[j + h] - cur[j]) % R_MOD for j in range(h)]
+            level = (len(qi) * pp.l).bit_length() - 1
+            res.append(be.msm_g1(powers_of_g[level], be.to_device(_ints_to_fr(qi)), len(qi)))
+            cur = [(cur[j] * (1 - pt[r]) + cur[j + h] * pt[r]) % R_MOD for j in range(h)]
+        out.append((fr_mont(cur[0]), np.stack(res) if res else np.zeros((0, 18), dtype=np.uint64)))
+    return out
 
 
 def c_open(be, powers_of_g, peval, length: int, point: np.ndarray, pp: PackedSharingParams, net: Net):
@@ -277,26 +368,7 @@ def c_open(be, powers_of_g, peval, length: int, point: np.ndarray, pp: PackedSha
     pss2ss of the last value, then log2(l) more rounds on the l-vector re-using point[0..] (:452).
     Returns (value [4], proofs [n + log2 l, 18]).
     """
-    n = length.bit_length() - 1
-    point = np.asarray(point, dtype=np.uint64).reshape(-1, 4)
-    q, value = be.open_rounds(peval, length, point[:n])
-    bufs, lens, off, m = [], [], 0, length
-    for _ in range(n):
-        h = m // 2
-        bufs.append(q.at(32 * off))
-        lens.append(h)
-        off += h
-        m = h
-    res = list(c_commit(be, powers_of_g, bufs, lens, pp, net)) if n else []
-    cur = _fr_vec_to_ints(pss2ss(value, pp, net))
-    pt = _fr_vec_to_ints(point)
-    for i in range(pp.l.bit_length() - 1):
-        h = len(cur) // 2
-        qi = [(cur[j + h] - cur[j]) % R_MOD for j in range(h)]
-        level = (len(qi) * pp.l).bit_length() - 1
-        res.append(be.msm_g1(powers_of_g[level], be.to_device(_ints_to_fr(qi)), len(qi)))
-        cur = [(cur[j] * (1 - pt[i]) + cur[j + h] * pt[i]) % R_MOD for j in range(h)]
-    return fr_mont(cur[0]), (np.stack(res) if res else np.zeros((0, 18), dtype=np.uint64))
+    return c_open_many(be, powers_of_g, [peval], [length], [point], pp, net)[0]
 
 
 def fix_variable(be, evaluations, length: int, points: np.ndarray):

@@ -108,8 +108,8 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     s_dev = be.to_device(s_np)
     wiring_commits.append(dp.d_commit(be, dc, local_s_p, 4 * M // npar, net))  # 2.b
     wiring_proofs.append(dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net))  # 2.c
-    wiring_opens.append(dp.c_open(be, cc, T["V"], 4 * M // l, pk.challenge_r1, pp, net))  # 2.d
-    wiring_opens.append(dp.c_open(be, cc, T["V"], 4 * M // l, pk.challenge_r2, pp, net))
+    # 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
+    wiring_opens += dp.c_open_many(be, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net)
     wiring_opens.append(dp.d_open(be, dc, local_s_p, 4 * M // npar, pk.challenge_r2, net))
     # 2.e (:322-340)
     hlen = 4 * M // npar
@@ -119,10 +119,10 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     subtree, top = dp.d_acc_product(be, h_p, hlen, net)  # :342
     v1x = _at(subtree, 32 * hlen)  # tree[N..]
     vx0, vx1 = be.fr_deinterleave(subtree, hlen)  # tree[0::2], tree[1::2]  :344-359
-    for tab in (T["ssigma_p"], T["sid_p"], h_p, num, den, v1x, vx0, vx1):  # :363-380
-        wiring_commits.append(dp.d_commit(be, dc, tab, hlen, net))
-    for tab in (T["ssigma_p"], T["sid_p"], h_p, num, den):  # :383-407
-        wiring_opens.append(dp.d_open(be, dc, tab, hlen, pk.challenge_r2, net))
+    # :363-380 / :383-407: independent commits / opens -> one MSM pass and one exchange each
+    tabs8 = [T["ssigma_p"], T["sid_p"], h_p, num, den, v1x, vx0, vx1]
+    wiring_commits += list(dp.d_commit_many(be, dc, tabs8, [hlen] * 8, net))
+    wiring_opens += dp.d_open_many(be, dc, tabs8[:5], [hlen] * 5, [pk.challenge_r2] * 5, net)
     dsp = lambda f, g, length, ch: dp.d_sumcheck_product(be, f, g, length, ch, net)
     wiring_proofs.append(dsp(den, T["eq_r2_p"], hlen, pk.challenge_r2))  # 2.e.1 :411-413
     wiring_proofs.append(dsp(h_p, den, hlen, pk.challenge_r2))
@@ -131,16 +131,21 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     sbits = npar.bit_length() - 1
     cur = {"v1x": v1x, "vx0": vx0, "vx1": vx1, "eq": T["eq_r2_p"]}
     clen = hlen // 2  # current_* = first half
+    lay_tabs, lay_lens, lay_pts = [], [], []
     for i in range(1, n - sbits + 1):
         ch = pk.challenge_r2[i:]
         wiring_proofs.append(dsp(cur["eq"], cur["v1x"], clen, ch))
         wiring_proofs.append(dsp(cur["eq"], cur["vx0"], clen, ch))
         wiring_proofs.append(dsp(cur["vx0"], cur["vx1"], clen, ch))
         for k in ("v1x", "vx0", "vx1"):
-            wiring_opens.append(dp.d_open(be, dc, cur[k], clen, ch, net))
+            lay_tabs.append(cur[k])
+            lay_lens.append(clen)
+            lay_pts.append(ch)
         for k in cur:  # current = current[len/2..]
             cur[k] = _at(cur[k], 32 * (clen // 2))
         clen //= 2
+    # the opens of all layers are independent of each other: one batched pass, same order as the reference
+    wiring_opens += dp.d_open_many(be, dc, lay_tabs, lay_lens, lay_pts, net)
     if top is not None:  # leader-only tail on the N_p-leaf top tree (:480-511)
         tt = np.asarray(top, dtype=np.uint64).reshape(-1, 4)
         half = len(tt) // 2
@@ -178,10 +183,11 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     tm.start("Commit")
     cc, dc = pk.c_commitment, pk.d_commitment
     com = {}
-    for name in ("a_evals", "b_evals", "c_evals"):
-        com[name] = dp.c_commit(be, cc, [T[name]], [L[name]], pp, net)[0]
-    for name in ("I_p", "S1_p", "S2_p"):
-        com[name] = dp.d_commit(be, dc, T[name], L[name], net)
+    names_c, names_d = ("a_evals", "b_evals", "c_evals"), ("I_p", "S1_p", "S2_p")
+    for name, cm in zip(names_c, dp.c_commit(be, cc, [T[x] for x in names_c], [L[x] for x in names_c], pp, net)):
+        com[name] = cm
+    for name, cm in zip(names_d, dp.d_commit_many(be, dc, [T[x] for x in names_d], [L[x] for x in names_d], net)):
+        com[name] = cm
     tm.end()
 
     # Step 3: gate identity (:223-260)
@@ -207,10 +213,10 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     # Open (:517-553)
     tm.start("Open")
     gate_commitments = []
-    for name in ("a_evals", "b_evals", "c_evals"):
-        gate_commitments.append((com[name], dp.c_open(be, cc, T[name], L[name], pk.challenge, pp, net)))
-    for name in ("I_p", "S1_p", "S2_p"):
-        gate_commitments.append((com[name], dp.d_open(be, dc, T[name], L[name], pk.challenge, net)))
+    for name, op in zip(names_c, dp.c_open_many(be, cc, [T[x] for x in names_c], [L[x] for x in names_c], [pk.challenge] * 3, pp, net)):
+        gate_commitments.append((com[name], op))
+    for name, op in zip(names_d, dp.d_open_many(be, dc, [T[x] for x in names_d], [L[x] for x in names_d], [pk.challenge] * 3, net)):
+        gate_commitments.append((com[name], op))
     tm.end()
     tm.end()
     return ((gate_proofs, gate_commitments), (wiring_proofs, wiring_commits, wiring_opens)), tm.t
