@@ -843,7 +843,7 @@ struct HostPool {
     }
 };
 static HostPool* host_pool(zk_ctx* ctx) {
-    if (!ctx->host_pool) ctx->host_pool = new HostPool(std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
+    if (!ctx->host_pool) ctx->host_pool = new HostPool(std::min(64u, std::max(2u, std::thread::hardware_concurrency() / 2)));
     return (HostPool*)ctx->host_pool;
 }
 void msm_host_pool_destroy(zk_ctx* ctx) {

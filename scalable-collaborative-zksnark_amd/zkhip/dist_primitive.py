@@ -310,8 +310,9 @@ def d_open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: 
     ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
     total = cuts[-1]
     pi = be.g1_lincomb_batch(np.stack([np.stack([prfs[p][i] for p in range(net.n_parties)]) for i in range(total)]), ones) if total else np.zeros((0, 18), dtype=np.uint64)
-    roots = open_many(be, powers_of_g, [be.to_device(np.stack([vals[p][i] for p in range(net.n_parties)])) for i in range(k)],
-                      [net.n_parties] * k, [p[:plog] for p in pts])
+    # the k root tables (one value per party each) go up in ONE copy
+    root_tab = be.to_device(np.ascontiguousarray(np.stack([np.stack([vals[p][i] for p in range(net.n_parties)]) for i in range(k)])))
+    roots = open_many(be, powers_of_g, [root_tab.at(32 * net.n_parties * i) for i in range(k)], [net.n_parties] * k, [p[:plog] for p in pts])
     out = []
     for i in range(k):
         root_val, root_proofs = roots[i]
