@@ -97,12 +97,16 @@ class TorchDistNet(Net):
 
         a = np.ascontiguousarray(a)
         t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
-        if self.device is not None:
+        self._count(a.nbytes)
+        if self.device is not None:  # nccl: one device buffer for all parties, ONE copy back
             t = t.to(self.device)
+            out = torch.empty(self.n_parties * t.numel(), dtype=torch.uint8, device=self.device)
+            self.dist.all_gather_into_tensor(out, t, group=self.group)
+            h = out.cpu().numpy().reshape(self.n_parties, -1)
+            return [h[q].view(a.dtype).reshape(a.shape) for q in range(self.n_parties)]
         outs = [torch.empty_like(t) for _ in range(self.n_parties)]
         self.dist.all_gather(outs, t, group=self.group)
-        self._count(a.nbytes)
-        return [o.cpu().numpy().view(a.dtype).reshape(a.shape) for o in outs]
+        return [o.numpy().view(a.dtype).reshape(a.shape) for o in outs]
 
     def all_to_all(self, chunks, echo="slot0"):
         import torch

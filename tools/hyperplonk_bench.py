@@ -3,7 +3,7 @@
 End-to-end collaborative HyperPlonk (hyperplonk/src/dhyperplonk.rs) on MI355X.
 
   python tools/hyperplonk_bench.py --n 16                       # `leader` mode: party 0 alone, no-comm echo net (config 1 style)
-  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/hyperplonk_bench.py --n 20   # l = 1, 8 parties = 8 GPUs
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/hyperplonk_bench.py --nvars 20   # l = 1, 8 parties = 8 GPUs
 
 Prints the reference's timer sections (Commit / Gate identity / Wire identity / Open / total)
 and the Comm: (up, down) byte counters for the leader.
@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=14)
+    ap.add_argument("--n", "--nvars", dest="n", type=int, default=14)  # use --nvars under torch.distributed.run (its own parser grabs --n)
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--data-parallel", action="store_true")
     args = ap.parse_args()
@@ -33,10 +33,16 @@ def main():
         import torch.distributed as dist
         from zkhip.net import TorchDistNet
 
+        # ZK_BENCH_BACKEND=gloo: exercise the 8-party exchanges on a box with fewer GPUs than ranks
+        backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
+        lrank = lrank % torch.cuda.device_count()
         torch.cuda.set_device(lrank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", lrank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", lrank))
+        else:
+            dist.init_process_group(backend)
         assert world == pp.n, "l = 1 needs exactly 8 parties"
-        net = TorchDistNet(device=torch.device("cuda", lrank))
+        net = TorchDistNet(device=torch.device("cuda", lrank) if backend == "nccl" else None)
     else:
         from zkhip.net import LeaderEchoNet
 
@@ -52,7 +58,7 @@ def main():
             if best is None or timers["Distributed HyperPlonk"] < best["Distributed HyperPlonk"]:
                 best = timers
     if rank == 0:
-        print(json.dumps({"n": args.n, "l": 1, "parties": pp.n, "mode": "comm(nccl)" if world > 1 else "leader-echo",
+        print(json.dumps({"n": args.n, "l": 1, "parties": pp.n, "mode": ("comm(" + os.environ.get("ZK_BENCH_BACKEND", "nccl") + ")") if world > 1 else "leader-echo",
                           "setup_s": setup, "timers_s": best, "comm_bytes": [net.upload, net.download]}))
     if world > 1:
         dist.barrier()
@@ -60,4 +66,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if os.environ.get("ZK_PROFILE") and int(os.environ.get("RANK", "0")) == 0:  # host hot spots of rank 0
+        import cProfile, pstats
+
+        cProfile.run("main()", "/tmp/zk_e2e.prof")
+        pstats.Stats("/tmp/zk_e2e.prof").sort_stats("tottime").print_stats(25)
+    else:
+        main()
