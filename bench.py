@@ -34,10 +34,12 @@ FR_MUL_PEAK = 133.0e9  # measured Fr Montgomery mul/s
 
 def pmc_traffic_bytes(kernel: str):
     """
-    HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    Memory-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/*pmc_hbm_traffic.csv: FETCH_SIZE and WRITE_SIZE, KB per dispatch, separate passes).
-    Raw counters: the guide's gfx950 note says FETCH_SIZE can under-report wide streaming reads by
-    up to 2x; the gather pattern here is uncalibrated, so the raw sum is reported.
+    FETCH_SIZE is doubled, as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B):
+    tools/ubench_gather.hip confirms the factor for this kernel's own pattern -- random 96-byte records are
+    1.5 lines of 128 B on average, the counter reports 96 B per record (profiles/r01_fetch_calibration.txt).
+    WRITE_SIZE is taken raw (uncalibrated, 6 % of the total).  Infinity-Cache hits are included.
     """
     import csv
     import glob
@@ -48,7 +50,7 @@ def pmc_traffic_bytes(kernel: str):
     tot = 0.0
     for row in csv.reader(open(files[-1])):
         if len(row) == 4 and row[1] == kernel:
-            tot += float(row[3]) * 1024.0
+            tot += float(row[3]) * 1024.0 * (2.0 if row[0] == "FETCH_SIZE" else 1.0)
     return tot or None
 
 
