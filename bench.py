@@ -152,6 +152,22 @@ def main():
     barrier()
     sc_dt = (time.perf_counter() - s0) / sc_reps
 
+    # second figure: the same step with the scalars coming from host memory (PCIe-inclusive);
+    # never `value`
+    h2d_ms = None
+    if world == 1:
+        tmp = ctx.alloc(32 * n)
+        for _ in range(2):
+            tmp.upload(scal_np)
+            ctx.msm_g1(srs, tmp, n)
+        barrier()
+        h0 = time.perf_counter()
+        for _ in range(3):
+            tmp.upload(scal_np)
+            ctx.msm_g1(srs, tmp, n)
+        barrier()
+        h2d_ms = (time.perf_counter() - h0) / 3 * 1e3
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -187,6 +203,7 @@ def main():
             "windows": windows,
             "entries_per_window": 2 * n,
         },
+        "ms_per_step_scalars_from_host": h2d_ms,
         "msm_phase_ms": {"digits_sort": float(phase[0]), "k_accum_tiles": accum_ms, "fixup": float(phase[2]), "bucket_reduce": float(phase[3]), "host_combine": float(phase[4])},
         "roofline": {
             "kernel": "zk::k_accum_tiles (bucket accumulation)",
