@@ -151,6 +151,14 @@ def main():
         ctx.sumcheck_product(f_t, g_t, n, chal)
     barrier()
     sc_dt = (time.perf_counter() - s0) / sc_reps
+    for _ in range(2):
+        ctx.sumcheck(f_t, n, chal)
+    barrier()
+    s0 = time.perf_counter()
+    for _ in range(sc_reps):
+        ctx.sumcheck(f_t, n, chal)
+    barrier()
+    scp_dt = (time.perf_counter() - s0) / sc_reps
 
     # second figure: the same step with the scalars coming from host memory (PCIe-inclusive);
     # never `value`
@@ -227,6 +235,11 @@ def main():
             "fr_mul_as_written_per_s": 9.0 * n / sc_dt,
             "hbm_algorithmic_GBps": 64.0 * n / sc_dt / 1e9,
             "hbm_frac": 64.0 * n / sc_dt / 1e9 / HBM_PEAK_GBS,
+            "plain": {  # d_sumcheck phase 1 (dsumcheck.rs:301-315): 2N mul + 3N add as the reference writes it
+                "ms": scp_dt * 1e3,
+                "fr_field_ops_per_s": 5.0 * n / scp_dt,
+                "hbm_algorithmic_GBps": 32.0 * n / scp_dt / 1e9,
+            },
         },
     }
 
