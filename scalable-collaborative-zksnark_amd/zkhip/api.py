@@ -7,7 +7,6 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Optional
 
 import numpy as np
 

@@ -18,8 +18,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from .dist_primitive import ZERO, _fr_vec_to_ints, _ints_to_fr, _round_plain, _round_product
-from .field import R_MOD, fr_from_mont, fr_mont, int_to_limbs
+from .dist_primitive import _fr_vec_to_ints, _ints_to_fr, _round_plain, _round_product
+from .field import R_MOD, fr_from_mont, int_to_limbs
 from .net import Net
 
 
