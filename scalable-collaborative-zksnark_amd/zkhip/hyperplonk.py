@@ -106,11 +106,11 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     else:
         s_np = np.concatenate(net.all_gather(local_s_np))
     s_dev = be.to_device(s_np)
-    wiring_commits.append(dp.d_commit(be, dc, local_s_p, 4 * M // npar, net))  # 2.b
+    # 2.b (commit of local_s) and the d_open of local_s in 2.d are independent of everything below: they ride
+    # in the batched passes of :363-407 (same positions in the output lists as in the reference)
     wiring_proofs.append(dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net))  # 2.c
     # 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
     wiring_opens += dp.c_open_many(be, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net)
-    wiring_opens.append(dp.d_open(be, dc, local_s_p, 4 * M // npar, pk.challenge_r2, net))
     # 2.e (:322-340)
     hlen = 4 * M // npar
     num = be.fr_axpb(local_s_p, T["sid_p"], pk.alpha, pk.beta, hlen)
@@ -121,8 +121,8 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     vx0, vx1 = be.fr_deinterleave(subtree, hlen)  # tree[0::2], tree[1::2]  :344-359
     # :363-380 / :383-407: independent commits / opens -> one MSM pass and one exchange each
     tabs8 = [T["ssigma_p"], T["sid_p"], h_p, num, den, v1x, vx0, vx1]
-    wiring_commits += list(dp.d_commit_many(be, dc, tabs8, [hlen] * 8, net))
-    wiring_opens += dp.d_open_many(be, dc, tabs8[:5], [hlen] * 5, [pk.challenge_r2] * 5, net)
+    wiring_commits += list(dp.d_commit_many(be, dc, [local_s_p] + tabs8, [4 * M // npar] + [hlen] * 8, net))  # 2.b, then :363-380
+    lay_tabs, lay_lens, lay_pts = [local_s_p] + tabs8[:5], [4 * M // npar] + [hlen] * 5, [pk.challenge_r2] * 6  # 2.d, then :383-407
     dsp = lambda f, g, length, ch: dp.d_sumcheck_product(be, f, g, length, ch, net)
     wiring_proofs.append(dsp(den, T["eq_r2_p"], hlen, pk.challenge_r2))  # 2.e.1 :411-413
     wiring_proofs.append(dsp(h_p, den, hlen, pk.challenge_r2))
@@ -131,7 +131,6 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     sbits = npar.bit_length() - 1
     cur = {"v1x": v1x, "vx0": vx0, "vx1": vx1, "eq": T["eq_r2_p"]}
     clen = hlen // 2  # current_* = first half
-    lay_tabs, lay_lens, lay_pts = [], [], []
     for i in range(1, n - sbits + 1):
         ch = pk.challenge_r2[i:]
         wiring_proofs.append(dsp(cur["eq"], cur["v1x"], clen, ch))
@@ -144,7 +143,8 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
         for k in cur:  # current = current[len/2..]
             cur[k] = _at(cur[k], 32 * (clen // 2))
         clen //= 2
-    # the opens of all layers are independent of each other: one batched pass, same order as the reference
+    # the opens of local_s, of the five tables and of all layers are independent of each other: one batched
+    # pass, results in the reference's order
     wiring_opens += dp.d_open_many(be, dc, lay_tabs, lay_lens, lay_pts, net)
     if top is not None:  # leader-only tail on the N_p-leaf top tree (:480-511)
         tt = np.asarray(top, dtype=np.uint64).reshape(-1, 4)
