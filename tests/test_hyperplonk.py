@@ -77,6 +77,43 @@ def test_dhyperplonk_leader_echo_config1():
     assert net.upload > 0 and net.upload == net.download
 
 
+def test_dhyperplonk_batched_calls_keep_reference_positions():
+    """
+    the driver batches independent commits / opens; every output must still sit where the reference's
+    sequential calls put it (dhyperplonk.rs:296-407, 417-478): recompute selected entries one call at a time
+    """
+    from zkhip import dist_primitive as dp
+    from zkhip.field import random_fr
+
+    n, seed = 5, 2
+    pp = PackedSharingParams(1)
+    be = OracleBackend()
+    pk = PackedProvingParameters.new(n, pp, be, seed=1)
+    net = LeaderEchoNet(8)
+    (gate, (w_proofs, w_commits, w_opens)), _ = dhyperplonk(n, pk, pp, be, net, seed=seed)
+    T, M, npar = pk.tables, 1 << n, 8
+    hlen = 4 * M // npar
+    local_s_p = be.to_device(random_fr(hlen, seed * 31 + 1))  # as drawn inside dhyperplonk
+    dc, cc = pk.d_commitment, pk.c_commitment
+
+    def same_open(a, b):
+        return (np.asarray(a[0]) == np.asarray(b[0])).all() and np.asarray(a[1]).shape == np.asarray(b[1]).shape and (np.asarray(a[1]) == np.asarray(b[1])).all()
+
+    assert (w_commits[0] == dp.d_commit(be, dc, local_s_p, hlen, net)).all()                   # 2.b
+    assert (w_commits[1] == dp.d_commit(be, dc, T["ssigma_p"], hlen, net)).all()               # first of :363-380
+    assert (w_commits[2] == dp.d_commit(be, dc, T["sid_p"], hlen, net)).all()
+    assert same_open(w_opens[0], dp.c_open(be, cc, T["V"], 4 * M // pp.l, pk.challenge_r1, pp, net))  # 2.d
+    assert same_open(w_opens[1], dp.c_open(be, cc, T["V"], 4 * M // pp.l, pk.challenge_r2, pp, net))
+    assert same_open(w_opens[2], dp.d_open(be, dc, local_s_p, hlen, pk.challenge_r2, net))
+    assert same_open(w_opens[3], dp.d_open(be, dc, T["ssigma_p"], hlen, pk.challenge_r2, net))  # first of :383-407
+    assert same_open(w_opens[4], dp.d_open(be, dc, T["sid_p"], hlen, pk.challenge_r2, net))
+    # gate commitments: (commitment, open) pairs in the order a, b, c, I, S1, S2 (:517-553)
+    assert (gate[1][0][0] == dp.c_commit(be, cc, [T["a_evals"]], [pk.lens["a_evals"]], pp, net)[0]).all()
+    assert same_open(gate[1][1][1], dp.c_open(be, cc, T["b_evals"], pk.lens["b_evals"], pk.challenge, pp, net))
+    assert (gate[1][3][0] == dp.d_commit(be, dc, T["I_p"], pk.lens["I_p"], net)).all()
+    assert same_open(gate[1][5][1], dp.d_open(be, dc, T["S2_p"], pk.lens["S2_p"], pk.challenge, net))
+
+
 @pytest.mark.gpu
 def test_dhyperplonk_gpu_matches_oracle_backed_run():
     import zkhip
