@@ -142,7 +142,11 @@ __device__ __forceinline__ void xyzz30_madd(Xyzz30& acc, const Aff30& p, bool ne
     const Fq30 S2 = f30_mul(p.y, acc.zzz);    // < 2q
     const Fq30 P = f30_sub8(U2, acc.x);       // U2 + 8q - X1 < 10q
     // R = +-S2 - Y1:  S2 + 4q - Y1 < 6q   or   (4q - Y1) + 2q - S2 < 6q
-    const Fq30 R = neg ? f30_sub2(f30_sub4(f30_zero(), acc.y), S2) : f30_sub4(S2, acc.y);
+    Fq30 R;
+#pragma unroll
+    for (int i = 0; i < 13; i++)  // one limb-wise pass for both signs: (KQ2 - S2 | S2) + KQ4 - Y1, every limb stays below 2^32
+        R.l[i] = (neg ? Q30::KQ2(i) + Q30::KQ4(i) - S2.l[i] : S2.l[i] + Q30::KQ4(i)) - acc.y.l[i];
+    f30_norm(R);
     const Fq30 PP = f30_sqr(P);               // 100 q^2 -> < 2q
     const Fq30 PPP = f30_mul(P, PP);          // < 2q
     const Fq30 Q = f30_mul(acc.x, PP);        // 8q * 2q -> < 2q
