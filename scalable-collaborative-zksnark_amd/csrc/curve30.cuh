@@ -157,8 +157,7 @@ __device__ __forceinline__ void xyzz30_madd(Xyzz30& acc, const Aff30& p, bool ne
         else xyzz30_set_inf(acc);
         return;
     }
-    const Fq30 Q2 = f30_add(Q, Q);                              // < 4q
-    const Fq30 X3 = f30_sub4(f30_sub2(f30_sqr(R), PPP), Q2);    // (R^2 + 2q - PPP) + 4q - 2Q < 8q
+    const Fq30 X3 = f30_sub6(f30_sqr(R), f30_add2x(PPP, Q));    // R^2 + 6q - (PPP + 2Q) < 8q
     // R(Q + 8q - X3) + (4q - Y1)*PPP under one reduction: 6q*10q + 4q*2q <= 256 q^2 -> < 2q
     const Fq30 Y3 = f30_mul2add(R, f30_sub8(Q, X3), f30_sub4(f30_zero(), acc.y), PPP);
     acc.zzz = f30_mul(acc.zzz, PPP);
@@ -187,8 +186,7 @@ __device__ __forceinline__ Xyzz30 xyzz30_add(const Xyzz30& a, const Xyzz30& b) {
         else xyzz30_set_inf(r);
         return r;
     }
-    const Fq30 Q2 = f30_add(Q, Q);
-    r.x = f30_sub4(f30_sub2(f30_sqr(R), PPP), Q2);                          // < 8q
+    r.x = f30_sub6(f30_sqr(R), f30_add2x(PPP, Q));                          // R^2 + 6q - (PPP + 2Q) < 8q
     r.y = f30_mul2add(R, f30_sub8(Q, r.x), f30_sub2(f30_zero(), S1), PPP);  // 4q*10q + 2q*2q -> < 2q
     r.zz = ZZ3;
     r.zzz = f30_mul(f30_mul(a.zzz, b.zzz), PPP);
@@ -243,7 +241,7 @@ __device__ __forceinline__ void xyzz30_add_quad(const void* __restrict__ in, siz
         if (role == 0) xyzz30_store(out, io, xyzz30_add(xyzz30_load(in, ia), xyzz30_load(in, ib)));
         return;
     }
-    const Fq30 X3 = f30_sub4(f30_sub2(RR, PPP), f30_add(Q, Q));  // < 8q
+    const Fq30 X3 = f30_sub6(RR, f30_add2x(PPP, Q));  // < 8q
     const Fq30 m4 = f30_mul(f30_sel4(role, B, B, s1, R), f30_sel4(role, PPP, PPP, PPP, f30_sub8(Q, X3)));
     const Fq30 ZZZ3 = f30_quad_bcast<1>(m4), T1 = f30_quad_bcast<2>(m4), T2 = f30_quad_bcast<3>(m4);
     const Fq30 Y3 = f30_sub2(T2, T1);  // < 4q
@@ -269,7 +267,7 @@ __device__ __forceinline__ Xyzz30 xyzz30_acc_quad(const Xyzz30& acc, const void*
     const Fq30 Q = f30_quad_bcast<0>(m3), ZZ3 = f30_quad_bcast<1>(m3), PPP = f30_quad_bcast<2>(m3);
     if (f30_is_zero_2q(ZZ3)) return xyzz30_add(acc, xyzz30_load(in, ib));  // doubling / cancellation: every lane alone, same result
     Xyzz30 r;
-    r.x = f30_sub4(f30_sub2(RR, PPP), f30_add(Q, Q));  // < 8q
+    r.x = f30_sub6(RR, f30_add2x(PPP, Q));  // < 8q
     const Fq30 m4 = f30_mul(f30_sel4(role, B, B, s1, R), f30_sel4(role, PPP, PPP, PPP, f30_sub8(Q, r.x)));
     r.zzz = f30_quad_bcast<1>(m4);
     r.y = f30_sub2(f30_quad_bcast<3>(m4), f30_quad_bcast<2>(m4));  // < 4q

@@ -36,6 +36,10 @@ struct Q30 {
         constexpr u32 t[13] = {0x7ffeaaacu, 0x5feffffeu, 0x54ffffedu, 0x6bfffeb0u, 0x43d89079u, 0x4d2a0f6au, 0x44afd9cbu, 0x4b84f384u, 0x735d91dcu, 0x7b6434b9u, 0x6692c6e8u, 0x6a397fe5u, 0x00680446u};
         return t[i];
     }
+    __host__ __device__ static constexpr u32 KQ6(int i) {
+        constexpr u32 t[13] = {0x7ffe0002u, 0x6fe7fffeu, 0x7f7fffe4u, 0x41fffe08u, 0x65c4d8b7u, 0x53bf171fu, 0x6707c6b1u, 0x71476d46u, 0x4d0c5acau, 0x79164f17u, 0x79dc2a5du, 0x5f563fd8u, 0x009c066au};
+        return t[i];
+    }
     __host__ __device__ static constexpr u32 KQ8(int i) {
         constexpr u32 t[13] = {0x7ffd5558u, 0x7fdffffeu, 0x69ffffdbu, 0x57fffd61u, 0x47b120f4u, 0x5a541ed5u, 0x495fb397u, 0x5709e709u, 0x66bb23b9u, 0x76c86974u, 0x4d258dd2u, 0x5472ffccu, 0x00d0088eu};
         return t[i];
@@ -101,6 +105,14 @@ __device__ __forceinline__ Fq30 f30_add(const Fq30& a, const Fq30& b) {
     f30_norm(r);
     return r;
 }
+// a + 2b  (one pass; limbs < 3 * 2^30 before the carry sweep)
+__device__ __forceinline__ Fq30 f30_add2x(const Fq30& a, const Fq30& b) {
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.l[i] = a.l[i] + 2u * b.l[i];
+    f30_norm(r);
+    return r;
+}
 // a + k*q - b  for a normalised b < k*q.  KQ = redundant limbs of k*q (Q30::KQ2 / KQ4 / KQ8)
 #define ZK_F30_SUB(name, KQ)                                                      \
     __device__ __forceinline__ Fq30 name(const Fq30& a, const Fq30& b) {         \
@@ -111,6 +123,7 @@ __device__ __forceinline__ Fq30 f30_add(const Fq30& a, const Fq30& b) {
     }
 ZK_F30_SUB(f30_sub2, KQ2)  // a + 2q - b,  b < 2q
 ZK_F30_SUB(f30_sub4, KQ4)  // a + 4q - b,  b < 4q
+ZK_F30_SUB(f30_sub6, KQ6)  // a + 6q - b,  b < 6q
 ZK_F30_SUB(f30_sub8, KQ8)  // a + 8q - b,  b < 8q
 // Montgomery product a*b*2^-390 (mod q) for normalised inputs whose bounds multiply to <= 256 q^2;
 // the result is normalised and < 2q.  Product scanning; a column holds at most 15 limb products
