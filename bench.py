@@ -243,7 +243,7 @@ def main():
         },
     }
 
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:  # the CPU leg runs at N = 1 only (rank 0)
         # CPU baseline leg: the oracle (C port of the reference's single-threaded path) on this
         # box's host cores.  Checker/baseline only -- never part of the measured GPU path.
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
