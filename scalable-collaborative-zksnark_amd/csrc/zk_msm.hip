@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ it
 // or -- with a precomputed SRS -- all windows at once) by bucket.  No global atomics; every store
 // stream is either coalesced or confined to a region one workgroup owns (so partial lines merge in
 // that workgroup's L2 instead of bouncing between XCDs):
-//   level 1  the row is cut into chunks; the top bits of the bucket pick one of np <= 256 partitions
+//   level 1  the row is cut into chunks; the top bits of the bucket pick one of np = 256..1024 partitions
 //     k_part_hist     block (chunk, row): partition histogram in LDS      -> hist[row][p][chunk]
 //     k_part_scan     block (p, row): exclusive scan over the chunks      -> hist in place, total[row][p]
 //     k_part_bases    block (row): exclusive scan over the partitions     -> base[row][p], rowtot[row]
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ it
 //     k_part_sort     counts[row][b], offsets[row][b] and the entries grouped by bucket into sorted[]
 // ---------------------------------------------------------------------------------------
 static constexpr int kSortThreads = 1024;
-static constexpr u32 kMaxParts = 256;
+static constexpr u32 kMaxParts = 1024;
 static constexpr u32 kMaxLow = 2048;  // buckets per partition (nb / np), nb <= 2^19
 
 __global__ void __launch_bounds__(kSortThreads) k_part_hist(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
@@ -292,12 +292,12 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* sh, u32* total) 
     return incl - v;
 }
 
-static constexpr int kScanThreads = 256;
+static constexpr int kScanThreads = 1024;  // >= kMaxParts (k_part_bases scans one row's partitions in a block)
 __global__ void __launch_bounds__(kScanThreads) k_part_scan(u32* __restrict__ hist, u32 nchunks, u32* __restrict__ total) {
     __shared__ u32 sh[kScanThreads];
     u32* h = hist + (size_t)blockIdx.x * nchunks;  // blockIdx.x = row * np + p
     u32 carry = 0;
-    for (u32 t0 = 0; t0 < nchunks; t0 += kScanThreads) {
+    for (u32 t0 = 0; t0 < nchunks; t0 += blockDim.x) {
         const u32 i = t0 + threadIdx.x;
         const u32 v = (i < nchunks) ? h[i] : 0u;
         u32 tile_total;
@@ -990,9 +990,15 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         if (T_env) cl.T = T_env;
         cl.tiles_per_w = (cl.row_len + cl.T - 1) / cl.T;
         cl.total_tiles = cl.tiles_per_w * cl.rows;
-        // sort geometry: <= 256 partitions per row (top bits of the bucket), chunks of >= 16 Ki entries,
+        // sort geometry: 256..1024 partitions per row (top bits of the bucket), chunks of >= 16 Ki entries,
         // at most 128 chunks per row
-        cl.np = (u32)std::min<size_t>(cl.nb, kMaxParts);
+        {
+            // 256 partitions per row; more for very long rows so a partition stays near 16 Ki entries (its
+            // level-2 workgroup and the region it scatters into stay small)
+            size_t want = 256;
+            while (want < kMaxParts && cl.row_len / want > 32768) want <<= 1;
+            cl.np = (u32)std::min<size_t>(cl.nb, want);
+        }
         cl.low_bits = 0;
         while (((size_t)cl.np << cl.low_bits) < cl.nb) cl.low_bits++;
         {
@@ -1073,8 +1079,8 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             const dim3 g_chunks((unsigned)(cl.nchunks * cl.rows)), g_parts((unsigned)(cl.np * cl.rows));
             hipLaunchKernelGGL(k_part_hist, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, cl.np,
                                cl.low_bits, hist);
-            hipLaunchKernelGGL(k_part_scan, dim3((unsigned)(cl.rows * cl.np)), dim3(kScanThreads), 0, st, hist, cl.nchunks, ptotal);
-            hipLaunchKernelGGL(k_part_bases, dim3((unsigned)cl.rows), dim3(kScanThreads), 0, st, (const u32*)ptotal, cl.np, pbase, rowtot);
+            hipLaunchKernelGGL(k_part_scan, dim3((unsigned)(cl.rows * cl.np)), dim3(128), 0, st, hist, cl.nchunks, ptotal);  // <= 128 chunks per row
+            hipLaunchKernelGGL(k_part_bases, dim3((unsigned)cl.rows), dim3(cl.np <= 256 ? 256 : kScanThreads), 0, st, (const u32*)ptotal, cl.np, pbase, rowtot);
             hipLaunchKernelGGL(k_part_scatter, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks,
                                cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low);
             hipLaunchKernelGGL(k_part_sort, g_parts, dim3(cl.row_len / cl.np >= 4096 ? kSortThreads : 256), 0, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len,
