@@ -353,6 +353,73 @@ __global__ void __launch_bounds__(kSortThreads) k_part_scatter(const u32* __rest
     }
 }
 
+// the same scatter with the chunk (<= kStageChunk entries) first sorted by partition in LDS: every
+// partition's run then leaves with consecutive-address stores (a run is ~chunk/np entries) instead of one
+// 4-byte store per lane into np different streams.  Used for long rows, where the open store streams of
+// all resident workgroups no longer fit the L2 (measured at 2^24: 4.0 ms -> see DESIGN.md).
+static constexpr u32 kStageChunk = 16384;
+__global__ void __launch_bounds__(kSortThreads) k_part_scatter_staged(const u32* __restrict__ digits, size_t row_len, size_t chunk_len,
+                                                                    u32 nchunks, u32 np, int low_bits, const u32* __restrict__ hist,
+                                                                    const u32* __restrict__ base, int idx_bits,
+                                                                    u32* __restrict__ part_idx, unsigned short* __restrict__ part_low) {
+    extern __shared__ u32 sm[];
+    u32* cnt = sm;                    // [kMaxParts] entries of this chunk per partition, then fill cursors
+    u32* loc = cnt + kMaxParts;       // [kMaxParts] start of the partition's run inside the stage
+    u32* gcur = loc + kMaxParts;      // [kMaxParts] destination of that run in the row
+    u32* sh = gcur + kMaxParts;       // [kSortThreads] scan scratch
+    u32* st_idx = sh + kSortThreads;  // [kStageChunk]
+    u32* st_meta = st_idx + kStageChunk;  // [kStageChunk] (partition << 16) | bucket-in-partition
+    const u32 chunk = blockIdx.x % nchunks, row = blockIdx.x / nchunks;
+    for (u32 p = threadIdx.x; p < kMaxParts; p += kSortThreads) cnt[p] = 0u;
+    __syncthreads();
+    const size_t c0 = (size_t)chunk * chunk_len;
+    const size_t c1 = (c0 + chunk_len < row_len) ? c0 + chunk_len : row_len;
+    const uint4* row4 = reinterpret_cast<const uint4*>(digits + (size_t)row * row_len);
+    for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
+        uint4 d4 = row4[i4];
+        u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (dd[k] != kSkip) atomicAdd(&cnt[(dd[k] & 0x7fffffffu) >> low_bits], 1u);
+    }
+    __syncthreads();
+    {
+        const u32 v = cnt[threadIdx.x];  // kSortThreads == kMaxParts: one partition per thread
+        u32 total;
+        const u32 ex = block_exclusive_scan(v, sh, &total);
+        loc[threadIdx.x] = ex;
+        cnt[threadIdx.x] = ex;  // fill cursor
+        if (threadIdx.x < np) gcur[threadIdx.x] = base[(size_t)row * np + threadIdx.x] + hist[((size_t)row * np + threadIdx.x) * nchunks + chunk];
+        if (threadIdx.x == 0) sh[0] = total;
+    }
+    __syncthreads();
+    const u32 staged = sh[0];
+    const u32 low_mask = (1u << low_bits) - 1u;
+    for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
+        uint4 d4 = row4[i4];
+        u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 d = dd[k];
+            if (d != kSkip) {
+                const u32 b = d & 0x7fffffffu, p = b >> low_bits;
+                const u32 pos = atomicAdd(&cnt[p], 1u);
+                st_idx[pos] = (u32)(4 * i4 + k) | (d & 0x80000000u) | (idx_bits ? ((b & low_mask) << idx_bits) : 0u);
+                st_meta[pos] = (p << 16) | (b & low_mask);
+            }
+        }
+    }
+    __syncthreads();
+    u32* oi = part_idx + (size_t)row * row_len;
+    unsigned short* ol = part_low + (size_t)row * row_len;
+    for (u32 j = threadIdx.x; j < staged; j += kSortThreads) {
+        const u32 meta = st_meta[j], p = meta >> 16;
+        const u32 dst = gcur[p] + (j - loc[p]);
+        oi[dst] = st_idx[j];
+        if (!idx_bits) ol[dst] = (unsigned short)(meta & 0xffffu);
+    }
+}
+
 // launched with 1024 threads for long partitions, 256 for short ones (fewer barrier steps in the scan)
 __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restrict__ part_idx, const unsigned short* __restrict__ part_low,
                                                               size_t row_len, u32 np, int low_bits, int idx_bits, size_t nb,
@@ -869,6 +936,7 @@ struct MsmClass {
     u32 T = 32, nchunks = 0, np = 1;  // sort: chunks per row, partitions per row
     int low_bits = 0;                 // log2(buckets per partition)
     int idx_bits = 0;                 // > 0: level-1 entries carry the bucket-in-partition above the index bits
+    bool staged_scatter = false;      // level-1 scatter through an LDS-sorted chunk (long rows)
     size_t pinned_off = 0;  // byte offset of this class's results in the pinned staging area
     size_t off[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets of this class inside the scratch arenas
 };
@@ -887,6 +955,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     static const bool pair_env = getenv("ZK_MSM_PAIR") && atoi(getenv("ZK_MSM_PAIR")) != 0;
     static const size_t fixq_max = getenv("ZK_MSM_FIXQ") ? (size_t)atol(getenv("ZK_MSM_FIXQ")) : 65536;  // buckets per class
     static const size_t quad_max = getenv("ZK_MSM_QUAD") ? (size_t)atol(getenv("ZK_MSM_QUAD")) : 32768;  // additions per pass (above it the plain pass is faster: measured)
+    static const int stage_env = getenv("ZK_MSM_STAGE") ? atoi(getenv("ZK_MSM_STAGE")) : -1;
     static const int split_env = getenv("ZK_MSM_SPLIT") ? atoi(getenv("ZK_MSM_SPLIT")) : 1;  // measured on MI355X: no gain (every phase is ALU-bound), off by default
     // ---- validate + classify by window width ----
     std::vector<MsmClass> classes;
@@ -991,12 +1060,14 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         cl.tiles_per_w = (cl.row_len + cl.T - 1) / cl.T;
         cl.total_tiles = cl.tiles_per_w * cl.rows;
         // sort geometry: 256..1024 partitions per row (top bits of the bucket), chunks of >= 16 Ki entries,
-        // at most 128 chunks per row
+        // at most 512 chunks per row
         {
             // 256 partitions per row; more for very long rows so a partition stays near 16 Ki entries (its
             // level-2 workgroup and the region it scatters into stay small)
             size_t want = 256;
-            while (want < kMaxParts && cl.row_len / want > 32768) want <<= 1;
+            static const size_t np_env = getenv("ZK_MSM_NP") ? (size_t)atol(getenv("ZK_MSM_NP")) : 0;
+            while (want < kMaxParts && cl.row_len / want > 16384) want <<= 1;
+            if (np_env) want = np_env;
             cl.np = (u32)std::min<size_t>(cl.nb, want);
         }
         cl.low_bits = 0;
@@ -1006,7 +1077,8 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             while (((size_t)1 << ib) < cl.row_len) ib++;
             cl.idx_bits = (ib + cl.low_bits <= 31) ? ib : 0;
         }
-        cl.chunk_len = (std::max<size_t>(16384, (cl.row_len + 127) / 128) + 3) & ~(size_t)3;
+        cl.staged_scatter = stage_env >= 0 ? stage_env != 0 : cl.row_len >= ((size_t)1 << 20);
+        cl.chunk_len = cl.staged_scatter ? kStageChunk : (std::max<size_t>(16384, (cl.row_len + 511) / 512) + 3) & ~(size_t)3;
         cl.nchunks = (u32)((cl.row_len + cl.chunk_len - 1) / cl.chunk_len);
         cl.cc_elems = cl.rows * (size_t)cl.np * cl.nchunks + 2 * cl.rows * (size_t)cl.np + cl.rows;  // hist, total, base, rowtot
         // classes run concurrently on separate streams: each gets its own region of every arena
@@ -1079,10 +1151,17 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             const dim3 g_chunks((unsigned)(cl.nchunks * cl.rows)), g_parts((unsigned)(cl.np * cl.rows));
             hipLaunchKernelGGL(k_part_hist, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, cl.np,
                                cl.low_bits, hist);
-            hipLaunchKernelGGL(k_part_scan, dim3((unsigned)(cl.rows * cl.np)), dim3(128), 0, st, hist, cl.nchunks, ptotal);  // <= 128 chunks per row
+            hipLaunchKernelGGL(k_part_scan, dim3((unsigned)(cl.rows * cl.np)), dim3(128), 0, st, hist, cl.nchunks, ptotal);  // <= 512 chunks per row
             hipLaunchKernelGGL(k_part_bases, dim3((unsigned)cl.rows), dim3(cl.np <= 256 ? 256 : kScanThreads), 0, st, (const u32*)ptotal, cl.np, pbase, rowtot);
-            hipLaunchKernelGGL(k_part_scatter, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks,
-                               cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low);
+            if (cl.staged_scatter) {
+                const size_t lds = (3 * (size_t)kMaxParts + kSortThreads + 2 * (size_t)kStageChunk) * 4;
+                hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL(k_part_scatter_staged, g_chunks, dim3(kSortThreads), lds, st, (const u32*)digits, cl.row_len, cl.chunk_len,
+                                   cl.nchunks, cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low);
+            } else {
+                hipLaunchKernelGGL(k_part_scatter, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks,
+                                   cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low);
+            }
             hipLaunchKernelGGL(k_part_sort, g_parts, dim3(cl.row_len / cl.np >= 4096 ? kSortThreads : 256), 0, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len,
                                cl.np, cl.low_bits, cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, counts, offsets, sorted);
         }
