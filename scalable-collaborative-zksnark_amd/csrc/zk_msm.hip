@@ -1078,6 +1078,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             cl.idx_bits = (ib + cl.low_bits <= 31) ? ib : 0;
         }
         cl.staged_scatter = stage_env >= 0 ? stage_env != 0 : cl.row_len >= ((size_t)1 << 20);
+        if (cl.rows * (size_t)cl.np * (cl.row_len / kStageChunk + 1) > ((size_t)64 << 20)) cl.staged_scatter = false;  // histogram arena <= 256 MiB
         cl.chunk_len = cl.staged_scatter ? kStageChunk : (std::max<size_t>(16384, (cl.row_len + 511) / 512) + 3) & ~(size_t)3;
         cl.nchunks = (u32)((cl.row_len + cl.chunk_len - 1) / cl.chunk_len);
         cl.cc_elems = cl.rows * (size_t)cl.np * cl.nchunks + 2 * cl.rows * (size_t)cl.np + cl.rows;  // hist, total, base, rowtot
