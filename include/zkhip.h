@@ -63,6 +63,10 @@ const char *zk_version(void);
  * synchronisation) and zk_malloc of the same size reuses it; everything is released with the ctx. -- */
 int zk_malloc(zk_ctx *ctx, size_t bytes, void **d_out);
 int zk_free(zk_ctx *ctx, void *d_ptr);
+/* release every parked block to the driver now (other allocators in the process -- torch, RCCL -- cannot
+ * see parked memory); *h_freed_bytes (optional) receives the number of bytes returned.  Every internal
+ * allocation of the library does this by itself, and retries once, when the device is out of memory. */
+int zk_trim(zk_ctx *ctx, size_t *h_freed_bytes);
 int zk_memcpy_h2d(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int zk_memcpy_d2h(zk_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 

@@ -22,6 +22,30 @@ int fail(zk_ctx* ctx, int code, const char* fmt, ...) {
 int hip_fail(zk_ctx* ctx, hipError_t e, const char* what) {
     return fail(ctx, e == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
+// releases every parked zk_free block of the ctx (pool_mu held by the caller)
+static size_t pool_flush_locked(zk_ctx* ctx) {
+    size_t freed = ctx->pool_bytes;
+    if (!ctx->pool_free.empty()) hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pool_free)
+        for (void* p : kv.second) hipFree(p);
+    ctx->pool_free.clear();
+    ctx->pool_bytes = 0;
+    return freed;
+}
+size_t pool_trim(zk_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
+    return pool_flush_locked(ctx);
+}
+// the ONE hipMalloc site of the library: on out-of-memory the parked blocks are dropped and the
+// allocation retried once (the park is invisible to hipMalloc, torch and RCCL otherwise)
+hipError_t device_alloc(zk_ctx* ctx, void** out, size_t bytes, bool pool_locked) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+    if (pool_locked) pool_flush_locked(ctx);
+    else pool_trim(ctx);
+    return hipMalloc(out, bytes);
+}
 void* scratch(zk_ctx* ctx, int slot, size_t bytes) {
     zk_ctx::Arena& a = ctx->scratch[slot];
     if (bytes <= a.cap && a.p) return a.p;
@@ -32,7 +56,7 @@ void* scratch(zk_ctx* ctx, int slot, size_t bytes) {
         a.cap = 0;
     }
     size_t want = bytes < 256 ? 256 : bytes;
-    hipError_t e = hipMalloc(&a.p, want);
+    hipError_t e = device_alloc(ctx, &a.p, want);
     if (e != hipSuccess) {
         hip_fail(ctx, e, "hipMalloc(scratch)");
         a.p = nullptr;
@@ -136,7 +160,7 @@ int zk_ctx_sync(zk_ctx* ctx) {
 // Device buffers are recycled per ctx: zk_free parks the block (exact size) instead of hipFree -- which
 // would synchronise the device -- and zk_malloc hands it out again.  Safe because every use of a ctx's
 // memory is ordered on the ctx stream.  The park is capped (kPoolCapBytes); beyond it blocks are really freed.
-static constexpr size_t kPoolCapBytes = (size_t)64 << 30;
+static constexpr size_t kPoolCapBytes = (size_t)32 << 30;
 int zk_malloc(zk_ctx* ctx, size_t bytes, void** d_out) {
     if (!ctx || !d_out) return ZK_ERR_INVALID;
     if (!bytes) bytes = 1;
@@ -150,17 +174,15 @@ int zk_malloc(zk_ctx* ctx, size_t bytes, void** d_out) {
         return ZK_OK;
     }
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(d_out, bytes);
-    if (e != hipSuccess) {  // out of memory: drop the parked blocks and retry once
-        (void)hipGetLastError();
-        hipStreamSynchronize(ctx->stream);
-        for (auto& kv : ctx->pool_free)
-            for (void* p : kv.second) hipFree(p);
-        ctx->pool_free.clear();
-        ctx->pool_bytes = 0;
-        ZK_HIP(ctx, hipMalloc(d_out, bytes));
-    }
+    ZK_HIP(ctx, device_alloc(ctx, d_out, bytes, /*pool_locked=*/true));
     ctx->pool_size[*d_out] = bytes;
+    return ZK_OK;
+}
+int zk_trim(zk_ctx* ctx, size_t* h_freed_bytes) {
+    if (!ctx) return ZK_ERR_INVALID;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t freed = pool_trim(ctx);
+    if (h_freed_bytes) *h_freed_bytes = freed;
     return ZK_OK;
 }
 int zk_free(zk_ctx* ctx, void* d_ptr) {

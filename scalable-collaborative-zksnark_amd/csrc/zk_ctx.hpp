@@ -57,6 +57,9 @@ int hip_fail(zk_ctx* ctx, hipError_t e, const char* what);
 // returns device scratch of at least `bytes` (slot 0..7), or nullptr after recording the error
 void* scratch(zk_ctx* ctx, int slot, size_t bytes);
 void* pinned(zk_ctx* ctx, size_t bytes);
+// hipMalloc that drops the ctx's parked zk_free blocks and retries once on out-of-memory
+hipError_t device_alloc(zk_ctx* ctx, void** out, size_t bytes, bool pool_locked = false);
+size_t pool_trim(zk_ctx* ctx);
 
 #define ZK_HIP(ctx, call)                                            \
     do {                                                             \

@@ -401,11 +401,8 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         size_t lds = (TWO ? 2 : 1) * m * fr + std::max<size_t>(parked, 1) * fr;
         void* fo = (MODE == 2) ? d_out : d_last_f;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)k_tail<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
+        hipFuncSetAttribute((const void*)k_tail<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         TailChal tc;
         std::memset(&tc, 0, sizeof(tc));
         if (rl > 11) return fail(ctx, ZK_ERR_INVALID, "internal: tail rounds");
@@ -457,9 +454,7 @@ __global__ void __launch_bounds__(kBlock) k_tree(const void* __restrict__ x, voi
     const size_t in_off = (in_level == 0) ? 0 : 2 * N - ((2 * N) >> in_level);
     const void* src = (in_level == 0 && copy_leaves) ? x : tree;
     Fr v = fp_zero<FrCfg>();
-    bool active = i0 + 1 < in_len + 0 || i0 + 1 == in_len - 0;  // i0+1 <= in_len-1
-    active = (i0 + 1) < in_len + 0;
-    if (i0 + 1 < in_len || i0 + 1 == in_len) active = (i0 + 1) <= in_len - 1;
+    const bool active = i0 + 1 < in_len;
     if (active) {
         Fr a = fr_load(src, (in_level == 0 && copy_leaves) ? i0 : in_off + i0);
         Fr b = fr_load(src, (in_level == 0 && copy_leaves) ? i0 + 1 : in_off + i0 + 1);

@@ -1112,6 +1112,16 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         hipEventRecord(ctx->ev_fork, ctx->stream);
         for (int k = 0; k < zk_ctx::kAux; k++) hipStreamWaitEvent(ctx->aux[k], ctx->ev_fork, 0);
     }
+    // an error while classes are in flight: forked aux streams may still read the scratch arenas and the
+    // caller's scalars -- drain the device before handing control (and those buffers) back
+#define ZK_HIP_INFLIGHT(ctx, call)                                   \
+    do {                                                             \
+        hipError_t _e = (call);                                      \
+        if (_e != hipSuccess) {                                      \
+            hipDeviceSynchronize();                                  \
+            return zk::hip_fail(ctx, _e, #call);                     \
+        }                                                            \
+    } while (0)
     size_t cls_i = 0;
     for (auto& cl : classes) {
         const size_t nitems = cl.idx.size(), ns = cl.ns, nb = cl.nb, total = cl.total;
@@ -1140,8 +1150,8 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             h_items[j].pstride = cl.shared ? (u32)it.srs->table_stride : (u32)it.srs->n;  // phi(P_i) sits n points after P_i
         }
         if (t_first) hipEventRecord(ctx->ev[0], st);
-        ZK_HIP(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
-        ZK_HIP(ctx, hipMemsetAsync(longs, 0, 4, st));
+        ZK_HIP_INFLIGHT(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
+        ZK_HIP_INFLIGHT(ctx, hipMemsetAsync(longs, 0, 4, st));
         hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, cl.shared ? 0 : 1, digits);
         {
@@ -1206,17 +1216,18 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             const size_t threads = cl.rows * (size_t)cl.npair;
             hipLaunchKernelGGL(k_finish, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, (const void*)in, out, cl.rows, cl.c, cl.npair, cl.pair ? 1 : 0);
         }
-        ZK_HIP(ctx, hipGetLastError());
-        ZK_HIP(ctx, hipMemcpyAsync(h_pts, out, cl.rows * (size_t)cl.npair * 144, hipMemcpyDeviceToHost, st));
+        ZK_HIP_INFLIGHT(ctx, hipGetLastError());
+        ZK_HIP_INFLIGHT(ctx, hipMemcpyAsync(h_pts, out, cl.rows * (size_t)cl.npair * 144, hipMemcpyDeviceToHost, st));
         if (t_last) hipEventRecord(ctx->ev[3], st);
         while (ctx->ev_cls.size() <= cls_i) {  // one completion event per class: the host starts on a class as soon as it lands
             hipEvent_t e;
-            ZK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ZK_HIP_INFLIGHT(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->ev_cls.push_back(e);
         }
         hipEventRecord(ctx->ev_cls[cls_i], st);
         cls_i++;
     }
+#undef ZK_HIP_INFLIGHT
     if (multi) {  // join: later work on the ctx stream is ordered after every class
         for (int k = 0; k < zk_ctx::kAux; k++) {
             hipEventRecord(ctx->ev_join[k], ctx->aux[k]);
@@ -1298,17 +1309,33 @@ static void srs_endo(zk_ctx* ctx, zk_srs* s) {
     if (blocks) hipLaunchKernelGGL(k_srs_endo, dim3((unsigned)blocks), dim3(kBlk), 0, ctx->stream, s->d_bases, s->n);
 }
 
+// frees a half-built zk_srs (and its device allocation) when a constructor leaves on an error path
+struct SrsGuard {
+    zk_srs* s = nullptr;
+    ~SrsGuard() {
+        if (!s) return;
+        if (s->d_bases) hipFree(s->d_bases);
+        delete s;
+    }
+    zk_srs* release() {
+        zk_srs* r = s;
+        s = nullptr;
+        return r;
+    }
+};
+
 // The device copy of an SRS is kept in the kernels' INTERNAL form (Montgomery radix 2^390, see
 // fq30.cuh): one conversion pass at registration, like the reference's own `mature()` step.
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out) {
     if (!out || (n && !h_bases)) return fail(ctx, ZK_ERR_INVALID, "null argument");
     if (stride != 96 && stride < 97) return fail(ctx, ZK_ERR_INVALID, "stride must be 96 or >= 97 (x, y, infinity flag)");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    zk_srs* s = new zk_srs();
+    SrsGuard guard;
+    zk_srs* s = guard.s = new zk_srs();
     s->n = n;
     s->owned = true;
     if (n) {
-        ZK_HIP(ctx, hipMalloc(&s->d_bases, 2 * n * 96));  // P_i, then phi(P_i)
+        ZK_HIP(ctx, device_alloc(ctx, &s->d_bases, 2 * n * 96));  // P_i, then phi(P_i)
         if (stride == 96) {
             ZK_HIP(ctx, hipMemcpyAsync(s->d_bases, h_bases, n * 96, hipMemcpyHostToDevice, ctx->stream));
             ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1326,23 +1353,24 @@ int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs**
         ZK_HIP(ctx, hipGetLastError());
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    *out = s;
+    *out = guard.release();
     return ZK_OK;
 }
 
 int srs_from_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out) {
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    zk_srs* s = new zk_srs();
+    SrsGuard guard;
+    zk_srs* s = guard.s = new zk_srs();
     s->n = n;
     s->owned = true;
     if (n) {
-        ZK_HIP(ctx, hipMalloc(&s->d_bases, 2 * n * 96));  // P_i, then phi(P_i)
+        ZK_HIP(ctx, device_alloc(ctx, &s->d_bases, 2 * n * 96));  // P_i, then phi(P_i)
         srs_convert(ctx, d_bases96, s->d_bases, n, true);
         srs_endo(ctx, s);
         ZK_HIP(ctx, hipGetLastError());
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    *out = s;
+    *out = guard.release();
     return ZK_OK;
 }
 
@@ -1381,7 +1409,7 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     if (srs->n == 0) return ZK_OK;
     const WinLayout L = msm_layout(c, kFullBits);
     const size_t nsr = (srs->n + 3) & ~(size_t)3;
-    ZK_HIP(ctx, hipMalloc(&srs->d_table, (size_t)L.W * nsr * 96));
+    ZK_HIP(ctx, device_alloc(ctx, &srs->d_table, (size_t)L.W * nsr * 96));
     ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * 96, ctx->stream));
     hipLaunchKernelGGL(k_precompute, dim3((unsigned)((srs->n + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream,
                        (const void*)srs->d_bases, srs->n, nsr, L, srs->d_table);

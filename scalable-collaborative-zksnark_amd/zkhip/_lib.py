@@ -25,6 +25,7 @@ SYMBOLS = [
     ("zk_version", ctypes.c_char_p, []),
     ("zk_malloc", _i, [_vp, _sz, _pp]),
     ("zk_free", _i, [_vp, _vp]),
+    ("zk_trim", _i, [_vp, ctypes.POINTER(ctypes.c_size_t)]),
     ("zk_memcpy_h2d", _i, [_vp, _vp, _vp, _sz]),
     ("zk_memcpy_d2h", _i, [_vp, _vp, _vp, _sz]),
     ("zk_fr_add", _i, [_vp, _vp, _vp, _vp, _sz]),
