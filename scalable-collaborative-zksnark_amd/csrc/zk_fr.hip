@@ -16,13 +16,13 @@
 #include "zk_ctx.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace zk {
 
 static constexpr int kBlock = 256;
-static constexpr size_t kTailMax = 2048;  // elements handled by the single-workgroup tail kernel
 
 struct ChalArgs {
     Fr c[3];
@@ -146,131 +146,155 @@ struct ReducePlan {
     unsigned first[kMax + 1];    // first output index of pass p (prefix sums of nsums); outputs are consecutive in `out`
     int n;
 };
-__global__ void __launch_bounds__(kBlock) k_reduce_all(ReducePlan plan, void* __restrict__ out) {
-    extern __shared__ uint4 lds[];
-    int p = 0;
-    while (p + 1 < plan.n && blockIdx.x >= plan.first[p + 1]) p++;
-    const size_t s = blockIdx.x - plan.first[p], nb = plan.nb[p];
-    Fr acc[1];
-    acc[0] = fp_zero<FrCfg>();
-    for (size_t i = threadIdx.x; i < nb; i += kBlock) acc[0] = fr_add(acc[0], fr_load(plan.partials[p], s * nb + i));
-    block_reduce_store<1>(acc, lds, out, blockIdx.x, 0);
-}
-
-// the tail's challenges travel as kernel arguments (at most log2(kTailMax) = 11 rounds)
+// the challenges of a local stage travel as kernel arguments (at most log2(kLocalMaxE) = 10 rounds)
 struct TailChal {
     uint64_t c[11 * 4];
 };
 
 // ---------------------------------------------------------------------------------------
-// Tail: all remaining rounds on a table of m <= kTailMax elements inside ONE workgroup, the
-// table(s) resident in LDS (2048 x 32 B x 2 tables = 128 KiB of the CU's 160 KiB).
-// Writes: sums -> sums_out[(rd)*W + w]; q -> qbase; final table (m >> rounds) -> fo / go.
+// Local stage: ALL rounds that fit on a table slice living in LDS, in one launch.
+//
+// A table of m = G * E elements is cut cyclically: workgroup w owns the E elements {w + G*t}.  The
+// round pairs (j, j + m/2) then stay inside one workgroup for log2(E) rounds (locally they are the
+// pairs (t, t + E/2)), after which every workgroup is down to one element and the table to G.
+// The same kernel with G = 1 finishes a call: it is the only stage of a table of <= E elements.
+//
+// Inside a workgroup the work is arranged by dependency, not by round:
+//   phase A  the fold chain -- the only true dependency chain of a sumcheck: ONE multiplication per
+//            round (f and g fold side by side in different lanes); every level of the table is kept
+//            (level k at Fr index 2E - 2E/2^k: 2E elements per table in all).  Once a round fits one
+//            wave the workgroup barrier is dropped (a wave's LDS operations execute in order).
+//   phase B  everything the sums need, for all rounds at once: the 3(E-1) pair products of the
+//            product sumcheck are independent of each other given the levels, so they are one
+//            embarrassingly parallel sweep, then one segmented reduction.
+// The old single-workgroup tail did the five multiplications of a pair serially in every round: 6.5 us
+// per round, 65 us for the last ten rounds of a 2^20 product sumcheck.
+//
+// Blocks >= G of the launch reduce the per-block partial sums of the earlier stages (`plan`).
+// sums layout: [(round * W + w) * G + block]  (G = 1: the final result slots).
 // ---------------------------------------------------------------------------------------
+static constexpr int kLocalThreads = 1024;
+static constexpr unsigned kLocalMaxE = 1024;  // one table: 2E Fr = 64 KiB; two tables use E <= 512 (+ 48 KiB of parked products)
+
+__device__ __forceinline__ unsigned lvl_off(unsigned E, int k) { return 2 * E - ((2 * E) >> k); }
+
+__device__ __forceinline__ Fr fr_shfl_down32(const Fr& v, int off) {
+    Fr o;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o.l[k] = __shfl_down(v.l[k], off, 32);
+    return o;
+}
+
+// one output sum of an earlier stage: block `ob` of the reduce part of the launch (1024 threads)
+__device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __restrict__ out, unsigned ob, uint4* lds) {
+    int p = 0;
+    while (p + 1 < plan.n && ob >= plan.first[p + 1]) p++;
+    const size_t s = ob - plan.first[p], nb = plan.nb[p];
+    const int tid = threadIdx.x, grp = tid >> 5, l32 = tid & 31;
+    Fr v = fp_zero<FrCfg>();
+    for (size_t i = tid; i < nb; i += kLocalThreads) v = fr_add(v, fr_load(plan.partials[p], s * nb + i));
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
+    if (l32 == 0) fr_store(lds, grp, v);
+    __syncthreads();
+    if (grp == 0) {
+        v = fr_load(lds, l32);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
+        if (l32 == 0) fr_store(out, ob, v);
+    }
+}
+
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_tail(const void* __restrict__ f, const void* __restrict__ g, size_t m, int rounds,
-                                               TailChal chal, void* __restrict__ sums_out,
-                                               void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go) {
-    // One barrier per round: the per-lane partial sums of every round are parked in LDS and ALL
-    // rounds are reduced together at the end (the sums of round i are not an input of round i+1).
+__global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict__ f, const void* __restrict__ g, unsigned G, unsigned E,
+                                                       int elog, int rounds, TailChal chal, void* __restrict__ sums,
+                                                       void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go,
+                                                       ReducePlan plan, void* __restrict__ red_out) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
-    constexpr int NS = (W == 0) ? 1 : W;
     extern __shared__ uint4 lds[];
-    uint4* tf = lds;
-    uint4* tg = lds + 2 * m;                 // 2 uint4 per Fr
-    uint4* part = lds + (TWO ? 4 : 2) * m;   // parked partial sums
-    const int tid = threadIdx.x;
-    for (size_t i = tid; i < m; i += kBlock) {
-        fr_store(tf, i, fr_load(f, i));
-        if (TWO) fr_store(tg, i, fr_load(g, i));
+    if (blockIdx.x >= G) {
+        reduce_all_body(plan, red_out, blockIdx.x - G, lds);
+        return;
+    }
+    const unsigned w = blockIdx.x, tid = threadIdx.x;
+    uint4* tf = lds;                          // 2E Fr (2 uint4 each)
+    uint4* tg = lds + 4 * (size_t)E;          // 2E Fr
+    uint4* park = lds + (TWO ? 8 : 4) * (size_t)E;
+    for (unsigned t = tid; t < E; t += kLocalThreads) {
+        fr_store(tf, t, fr_load(f, w + (size_t)G * t));
+        if (TWO) fr_store(tg, t, fr_load(g, w + (size_t)G * t));
     }
     __syncthreads();
-    size_t qoff = 0, poff = 0;
-    size_t mm = m;
-    for (int rd = 0; rd < rounds; rd++) {
-        const size_t h = mm >> 1;
-        const size_t cnt = h < (size_t)kBlock ? h : (size_t)kBlock;
-        const Fr r = fr_load(chal.c, rd);  // kernel-argument segment: no H2D copy, no extra buffer
-        Fr acc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; s++) acc[s] = fp_zero<FrCfg>();
-        if (MODE == 1 && 3 * h <= (size_t)kBlock) {
-            // late rounds: more lanes than pairs -> three lanes per pair, two dependent multiplications
-            // per lane instead of five (the round time is the latency of that chain)
-            const size_t role = (size_t)tid / h, j = (size_t)tid % h;
-            Fr nf, ng;
-            bool wf = false, wg = false;
-            if (role < 3) {
-                Fr flo = fr_load(tf, j), fhi = fr_load(tf, j + h), glo = fr_load(tg, j), ghi = fr_load(tg, j + h);
-                Fr df = fr_sub(fhi, flo), dg = fr_sub(ghi, glo);
-                if (role == 0) {
-                    acc[0] = fr_mul(flo, glo);
-                    nf = fr_add(flo, fr_mul(r, df));
-                    wf = true;
-                } else if (role == 1) {
-                    acc[0] = fr_mul(fhi, ghi);
-                    ng = fr_add(glo, fr_mul(r, dg));
-                    wg = true;
-                } else {
-                    acc[0] = fr_mul(fr_add(fhi, df), fr_add(ghi, dg));
+    // ---- phase A: the fold chain ----
+    {
+        unsigned L = E;
+        size_t qoff = 0, mcur = (size_t)G * E;
+        for (int k = 0; k < rounds; k++) {
+            const unsigned h = L >> 1, cur = lvl_off(E, k), nxt = lvl_off(E, k + 1);
+            const unsigned items = TWO ? 2 * h : h;
+            const bool solo = items <= 64;  // this round and every later one fit the first wave
+            if (!solo || tid < 64) {
+                const Fr r = fr_load(chal.c, k);
+                for (unsigned it = tid; it < items; it += kLocalThreads) {
+                    const bool isg = TWO && it >= h;
+                    const unsigned t = isg ? it - h : it;
+                    uint4* T = isg ? tg : tf;
+                    const Fr lo = fr_load(T, cur + t), hi = fr_load(T, cur + t + h);
+                    const Fr d = fr_sub(hi, lo);
+                    if (MODE == 3) fr_store(qbase, qoff + w + (size_t)G * t, d);  // q = hi - lo   dpoly_comm.rs:312
+                    fr_store(T, nxt + t, fr_add(lo, fr_mul(r, d)));              // lo + r (hi - lo)  dsumcheck.rs:14-19
                 }
             }
-            __syncthreads();  // every lane has read its operands before anyone overwrites the tables
-            if (wf) fr_store(tf, j, nf);
-            if (wg) fr_store(tg, j, ng);
-            if (role < 3) fr_store(part, poff + role * cnt + j, acc[0]);  // cnt == h here
-            __syncthreads();
-        } else {
-            for (size_t j = tid; j < h; j += kBlock) {
-                Fr flo = fr_load(tf, j), fhi = fr_load(tf, j + h), glo, ghi, qv;
-                if (TWO) {
-                    glo = fr_load(tg, j);
-                    ghi = fr_load(tg, j + h);
-                }
-                round_pair<MODE>(flo, fhi, glo, ghi, r, acc, qv);
-                if (MODE == 3) fr_store(qbase, qoff + j, qv);
-                fr_store(tf, j, flo);
-                if (TWO) fr_store(tg, j, glo);
-            }
-            if (W != 0 && (size_t)tid < cnt) {
-#pragma unroll
-                for (int w = 0; w < NS; w++) fr_store(part, poff + (size_t)w * cnt + tid, acc[w]);
-            }
-            __syncthreads();
+            if (solo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            else __syncthreads();
+            qoff += mcur >> 1;
+            mcur >>= 1;
+            L = h;
         }
-        qoff += h;
-        poff += cnt * W;
-        mm = h;
+        __syncthreads();
     }
-    for (size_t i = tid; i < mm; i += kBlock) {
-        fr_store(fo, i, fr_load(tf, i));
-        if (TWO) fr_store(go, i, fr_load(tg, i));
+    const unsigned Lf = E >> rounds;
+    for (unsigned t = tid; t < Lf; t += kLocalThreads) {
+        fr_store(fo, w + (size_t)G * t, fr_load(tf, lvl_off(E, rounds) + t));
+        if (TWO) fr_store(go, w + (size_t)G * t, fr_load(tg, lvl_off(E, rounds) + t));
     }
-    if (W != 0) {
-        // reduce every (round, w) vector of parked partials: 8 groups of 32 lanes
-        const int grp = tid >> 5, l32 = tid & 31;
-        size_t off = 0, m2 = m;
-        for (int rd = 0; rd < rounds; rd++) {
-            const size_t h = m2 >> 1;
-            const size_t cnt = h < (size_t)kBlock ? h : (size_t)kBlock;
-            for (int w = 0; w < W; w++) {
-                if (((rd * W + w) & 7) == grp) {  // wave-uniform per 32-lane group
-                    Fr v = fp_zero<FrCfg>();
-                    for (size_t t = l32; t < cnt; t += 32) v = fr_add(v, fr_load(part, off + (size_t)w * cnt + t));
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) {
-                        Fr x;
-#pragma unroll
-                        for (int k = 0; k < 8; k++) x.l[k] = __shfl_down(v.l[k], o, 32);
-                        v = fr_add(v, x);
-                    }
-                    if (l32 == 0) fr_store(sums_out, (size_t)rd * W + w, v);
+    if (W == 0 || rounds == 0) return;
+    // ---- phase B: the sums of every round ----
+    const unsigned P = E - Lf;  // pairs over all rounds: round k holds E/2^(k+1) of them, from index E - E/2^k
+    if (MODE == 1) {
+        for (unsigned it = tid; it < 3 * P; it += kLocalThreads) {
+            const unsigned ws = it / P, p = it - ws * P;
+            const unsigned u = E - p;  // in (E/2^(k+1), E/2^k]
+            const int k = elog - (32 - __clz(u - 1));
+            const unsigned hk = E >> (k + 1), t = p - (E - (E >> k)), off = lvl_off(E, k);
+            Fr a, b;
+            if (ws == 0) {
+                a = fr_load(tf, off + t);
+                b = fr_load(tg, off + t);
+            } else {
+                a = fr_load(tf, off + t + hk);
+                b = fr_load(tg, off + t + hk);
+                if (ws == 2) {  // (2 f_hi - f_lo)(2 g_hi - g_lo)      dsumcheck.rs:55-72
+                    a = fr_add(a, fr_sub(a, fr_load(tf, off + t)));
+                    b = fr_add(b, fr_sub(b, fr_load(tg, off + t)));
                 }
             }
-            off += cnt * W;
-            m2 = h;
+            fr_store(park, it, fr_mul(a, b));
         }
+        __syncthreads();
+    }
+    const int grp = tid >> 5, l32 = tid & 31;
+    for (int vid = grp; vid < rounds * W; vid += kLocalThreads / 32) {
+        const int k = vid / W, ws = vid - k * W;
+        const unsigned cnt = E >> (k + 1);
+        const uint4* src = (MODE == 1) ? park : tf;
+        const unsigned base = (MODE == 1) ? ws * P + (E - (E >> k)) : lvl_off(E, k) + ws * cnt;  // mode 0: lo half | hi half of level k
+        Fr v = fp_zero<FrCfg>();
+        for (unsigned t = l32; t < cnt; t += 32) v = fr_add(v, fr_load(src, base + t));
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
+        if (l32 == 0) fr_store(sums, (size_t)vid * G + w, v);
     }
 }
 
@@ -305,14 +329,49 @@ static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void
     return ZK_OK;
 }
 
+// stage geometry knobs (A/B runs): workgroups of a local stage, rounds fused per HBM pass
+static unsigned sc_local_g() {
+    static const unsigned v = getenv("ZK_SC_LOCAL_G") ? (unsigned)atoi(getenv("ZK_SC_LOCAL_G")) : 256u;
+    return v;
+}
+static int sc_pass_k(int mode) {
+    static const int kp = getenv("ZK_SC_KP") ? atoi(getenv("ZK_SC_KP")) : 2;  // product passes
+    static const int k0 = getenv("ZK_SC_K0") ? atoi(getenv("ZK_SC_K0")) : 3;  // single-table passes
+    return mode == 1 ? kp : k0;
+}
+
+template <int MODE>
+static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, unsigned E, int rl, const uint64_t* chal, void* sums,
+                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out) {
+    constexpr int W = ModeTraits<MODE>::W;
+    constexpr bool TWO = ModeTraits<MODE>::TWO;
+    TailChal tc;
+    std::memset(&tc, 0, sizeof(tc));
+    if (rl > 10) return fail(ctx, ZK_ERR_INVALID, "internal: local rounds");
+    if (rl) std::memcpy(tc.c, chal, (size_t)rl * 32);
+    ReducePlan none;
+    std::memset(&none, 0, sizeof(none));
+    const unsigned extra = rp ? rp->first[rp->n] : 0u;
+    const unsigned Lf = E >> rl;
+    size_t lds = (size_t)(TWO ? 4 : 2) * E * 32 + (MODE == 1 ? (size_t)3 * (E - Lf) * 32 : 0);
+    lds = std::max<size_t>(lds, 32 * 32);
+    int elog = 0;
+    while ((1u << elog) < E) elog++;
+    // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_local<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(kLocalThreads), lds, ctx->stream, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
+                       rp ? *rp : none, red_out);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
 template <int MODE>
 static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, const uint64_t* h_chal, size_t rounds,
                     uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
-    constexpr int KMAX = 3;
-    // tail capacity: tables + parked partial sums must fit the CU's 160 KiB of LDS
-    const size_t tail_max = TWO ? 1024 : kTailMax;
+    const size_t emax = TWO ? kLocalMaxE / 2 : kLocalMaxE;  // table elements a workgroup holds in LDS
+    const size_t local_max = emax * sc_local_g();           // longest table handed to a local stage
     const size_t fr = 32;
     // result block on device: [sums rounds*W][last_f][last_g]
     const size_t res_elems = rounds * W + 2;
@@ -321,95 +380,95 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     void* d_last_f = d_res + rounds * W * fr;
     void* d_last_g = d_res + (rounds * W + 1) * fr;
 
-    const void* cf = d_f;
-    const void* cg = d_g;
-    size_t m = len, done = 0;
-    int flip = 0;
+    // ---- plan: HBM passes (K rounds fused in registers) down to local_max, one multi-workgroup local
+    // stage down to <= 256 elements, one single-workgroup local stage for the rest ----
+    struct Stage {
+        int kind;  // 0 = pass, 1 = local (G > 1)
+        int k;     // rounds
+        size_t m, blocks, part_off;
+        unsigned G, E;
+    };
+    std::vector<Stage> plan;
+    size_t part_bytes = 0, mm = len, dd = 0;
+    while (dd < rounds && mm > emax) {
+        Stage st{};
+        st.m = mm;
+        if (mm > local_max) {
+            st.kind = 0;
+            st.k = (int)std::min<size_t>({(size_t)sc_pass_k(MODE), rounds - dd, (size_t)(ilog2(mm) - ilog2(local_max))});
+            st.blocks = pass_blocks(ctx, mm, st.k);
+        } else {
+            st.kind = 1;
+            st.E = (unsigned)emax;
+            st.G = (unsigned)(mm / emax);
+            st.k = (int)std::min<size_t>((size_t)ilog2(emax), rounds - dd);
+            st.blocks = st.G;
+        }
+        st.part_off = part_bytes;
+        part_bytes += (size_t)st.k * W * st.blocks * fr;
+        plan.push_back(st);
+        mm = st.kind == 0 ? mm >> st.k : (size_t)st.G * (st.E >> st.k);
+        dd += st.k;
+    }
+    if ((int)plan.size() > ReducePlan::kMax) return fail(ctx, ZK_ERR_INVALID, "internal: too many passes");
     void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (len > tail_max && rounds > 0) {
+    if (!plan.empty()) {
         bufs[0] = scratch(ctx, 0, (len / 2) * fr);
-        bufs[1] = scratch(ctx, 1, (len / 4) * fr);
+        bufs[1] = scratch(ctx, 1, std::max<size_t>(len / 4, 1) * fr);
         if (!bufs[0] || !bufs[1]) return ZK_ERR_OOM;
         if (TWO) {
             bufs[2] = scratch(ctx, 2, (len / 2) * fr);
-            bufs[3] = scratch(ctx, 3, (len / 4) * fr);
+            bufs[3] = scratch(ctx, 3, std::max<size_t>(len / 4, 1) * fr);
             if (!bufs[2] || !bufs[3]) return ZK_ERR_OOM;
         }
     }
-    // plan the passes first: every pass parks its per-block partial sums in its own slice of one arena
-    struct Pass {
-        int k;
-        size_t m, blocks, part_off;
-    };
-    std::vector<Pass> plan;
-    size_t part_bytes = 0;
-    {
-        size_t mm = m, dd = 0;
-        while (dd < rounds && mm > tail_max) {
-            const size_t kcap = (MODE == 1) ? 2 : KMAX;  // measured: K = 3 product passes (35 dependent muls per lane) are no faster than K = 2
-            const int k = (int)std::min<size_t>({kcap, rounds - dd, (size_t)(ilog2(mm) - ilog2(tail_max))});
-            const size_t blocks = pass_blocks(ctx, mm, k);
-            plan.push_back(Pass{k, mm, blocks, part_bytes});
-            part_bytes += (size_t)k * W * blocks * fr;
-            mm >>= k;
-            dd += k;
-        }
-    }
-    if ((int)plan.size() > ReducePlan::kMax) return fail(ctx, ZK_ERR_INVALID, "internal: too many passes");
     char* d_part = nullptr;
     if (W != 0 && part_bytes) {
         d_part = (char*)scratch(ctx, 4, part_bytes);
         if (!d_part) return ZK_ERR_OOM;
     }
+    const void* cf = d_f;
+    const void* cg = d_g;
+    size_t m = len, done = 0;
+    int flip = 0;
     ReducePlan rp;
     std::memset(&rp, 0, sizeof(rp));
-    for (const Pass& ps : plan) {
-        const int k = ps.k;
+    for (const Stage& st : plan) {
+        const int k = st.k;
         const bool final_out = (MODE == 2) && (done + k == rounds);
         void* fo = final_out ? d_out : bufs[flip];
         void* go = TWO ? bufs[2 + flip] : nullptr;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
-        void* part = d_part ? d_part + ps.part_off : nullptr;
+        void* part = d_part ? d_part + st.part_off : nullptr;
         int rc;
-        if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
+        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, k, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr);
+        else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
         else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
         else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
         if (rc) return rc;
-        if (W != 0) {  // outputs of this pass: sums of rounds done .. done+k-1, consecutive in d_res
+        if (W != 0) {  // outputs of this stage: sums of rounds done .. done+k-1, consecutive in d_res
             rp.partials[rp.n] = part;
-            rp.nb[rp.n] = (unsigned)ps.blocks;
+            rp.nb[rp.n] = (unsigned)st.blocks;
             rp.first[rp.n] = (unsigned)(done * W);
             rp.n++;
             rp.first[rp.n] = (unsigned)((done + k) * W);
         }
         cf = fo;
         cg = go;
-        m >>= k;
+        m = st.kind == 0 ? m >> k : (size_t)st.G * (st.E >> k);
         done += k;
         flip ^= 1;
     }
-    if (W != 0 && rp.n) {
-        hipLaunchKernelGGL(k_reduce_all, dim3(rp.first[rp.n]), dim3(kBlock), (size_t)kBlock * 32, ctx->stream, rp, (void*)d_res);
-        ZK_HIP(ctx, hipGetLastError());
-    }
     if (done < rounds || MODE != 2) {
-        // tail: the remaining rounds (possibly zero) in one workgroup; also emits the final table
+        // last stage: the remaining rounds (possibly zero) in one workgroup, which also emits the final
+        // table; the other blocks of the launch reduce the partial sums of the earlier stages
         const int rl = (int)(rounds - done);
-        if (m > tail_max) return fail(ctx, ZK_ERR_INVALID, "internal: tail too large");
-        size_t parked = 0;  // sum over rounds of W * min(h, 256) partials
-        for (size_t mm = m, r2 = 0; r2 < (size_t)rl; r2++, mm >>= 1) parked += (size_t)W * std::min<size_t>(mm >> 1, kBlock);
-        size_t lds = (TWO ? 2 : 1) * m * fr + std::max<size_t>(parked, 1) * fr;
+        if (m > emax) return fail(ctx, ZK_ERR_INVALID, "internal: last stage too large");
         void* fo = (MODE == 2) ? d_out : d_last_f;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
-        // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
-        hipFuncSetAttribute((const void*)k_tail<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        TailChal tc;
-        std::memset(&tc, 0, sizeof(tc));
-        if (rl > 11) return fail(ctx, ZK_ERR_INVALID, "internal: tail rounds");
-        if (rl) std::memcpy(tc.c, h_chal + 4 * done, (size_t)rl * fr);
-        hipLaunchKernelGGL((k_tail<MODE>), dim3(1), dim3(kBlock), lds, ctx->stream, cf, cg, m, rl, tc,
-                           (void*)(d_res + done * W * fr), qb, fo, d_last_g);
-        ZK_HIP(ctx, hipGetLastError());
+        int rc = launch_local<MODE>(ctx, cf, cg, 1u, (unsigned)m, rl, h_chal + 4 * done, (void*)(d_res + done * W * fr), qb, fo, d_last_g,
+                                    (W != 0 && rp.n) ? &rp : nullptr, (void*)d_res);
+        if (rc) return rc;
     } else if (rounds == 0) {
         ZK_HIP(ctx, hipMemcpyAsync(d_out, d_f, len * fr, hipMemcpyDeviceToDevice, ctx->stream));
     }
