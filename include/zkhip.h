@@ -47,7 +47,8 @@ typedef enum {
     ZK_ERR_HIP = -3,       /* HIP runtime error */
     ZK_ERR_NO_DEVICE = -4, /* no gfx950 device / library built without device code */
     ZK_ERR_DIV_ZERO = -5,  /* zero denominator in zk_fr_batch_div (reference: inverse().unwrap() panic) */
-    ZK_ERR_OOM = -6
+    ZK_ERR_OOM = -6,
+    ZK_ERR_COMM = -7       /* RCCL error / no communicator (reference: MPCNetError) */
 } zk_status;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -58,7 +59,11 @@ const char *zk_last_error(zk_ctx *ctx);
 int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
 int zk_ctx_sync(zk_ctx *ctx);
 const char *zk_version(void);
+/* number of GPUs visible to the library (a party-per-GPU caller sizes its world with it); < 0: zk_status */
+int zk_device_count(void);
 
+/* free / total bytes of the ctx's GPU (hipMemGetInfo; parked zk_free blocks count as used) */
+int zk_mem_info(zk_ctx *ctx, size_t *h_free, size_t *h_total);
 /* ---- device memory helpers for non-HIP callers.  zk_free parks the block in the ctx (no device
  * synchronisation) and zk_malloc of the same size reuses it; everything is released with the ctx. -- */
 int zk_malloc(zk_ctx *ctx, size_t bytes, void **d_out);
@@ -69,6 +74,7 @@ int zk_free(zk_ctx *ctx, void *d_ptr);
 int zk_trim(zk_ctx *ctx, size_t *h_freed_bytes);
 int zk_memcpy_h2d(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int zk_memcpy_d2h(zk_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int zk_memcpy_d2d(zk_ctx *ctx, void *d_dst, const void *d_src, size_t bytes); /* asynchronous, on the ctx stream */
 
 /* ---- element-wise Fr (hyperplonk/src/dhyperplonk.rs:233-238,251-256,326-339) -------- */
 int zk_fr_add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
@@ -175,6 +181,46 @@ int zk_msm_set_window(zk_ctx *ctx, int c_override);
  * events on the ctx stream: [0] digits+sort, [1] k_accum_tiles (bucket accumulation kernel alone),
  * [2] fix-up, [3] bucket reduction + conversion + D2H, [4] host combine (wall), [5] total */
 int zk_msm_last_timing(zk_ctx *ctx, float h_ms[6]);
+
+/* ---- party exchanges on one node: an RCCL communicator inside the ctx -------------------------
+ * Replaces the typed adapter over mpc-net's TCP star, dist-primitive/src/utils/serializing_net.rs:11-141.
+ * The party axis is the GPU axis (party p = rank p); payloads are raw Montgomery limbs in HBM, moved over
+ * xGMI with no serialisation or compression; every call is enqueued on the ctx stream (zk_ctx_sync, or any
+ * function returning host results, completes it).  RCCL is loaded at run time (librccl.so.1).
+ *   serializing_net.rs pattern                               here
+ *   worker_send_or_leader_receive_element          :11-39    zk_gather(root = 0)
+ *   dynamic_worker_send_or_leader_receive_element  :41-72    zk_gather(root = receiver)
+ *   worker_receive_or_leader_send_element          :74-96    zk_scatter(root = 0)
+ *   dynamic_worker_receive_or_worker_send_element  :98-122   zk_scatter(root = sender)
+ *   leader_compute_element                         :128-141  zk_allgather + the public map on every party
+ *   loops of dynamic scatters over every root (dacc_product.rs:94-104,155-203)   zk_alltoall            */
+#define ZK_COMM_ID_BYTES 128
+/* rank 0 creates the id and hands it to the other parties out of band (once, over any channel) */
+int zk_comm_unique_id(uint8_t h_id[ZK_COMM_ID_BYTES]);
+/* one process per GPU: collective over all `world` parties */
+int zk_comm_init(zk_ctx *ctx, int rank, int world, const uint8_t h_id[ZK_COMM_ID_BYTES]);
+/* one process holding a ctx per GPU (the reference's model: one task per party): ctxs[p] becomes party p */
+int zk_comm_init_all(zk_ctx *const *ctxs, int world);
+int zk_comm_destroy(zk_ctx *ctx); /* also done by zk_ctx_destroy */
+int zk_comm_rank(const zk_ctx *ctx);
+int zk_comm_size(const zk_ctx *ctx);
+/* d_recv[p * bytes ..] = party p's d_send, for every p, on every party */
+int zk_allgather(zk_ctx *ctx, const void *d_send, size_t bytes, void *d_recv);
+/* d_recv[p * bytes ..] = what party p put at d_send[me * bytes ..] */
+int zk_alltoall(zk_ctx *ctx, const void *d_send, size_t bytes_per_peer, void *d_recv);
+/* root receives world x bytes ordered by party (d_recv is ignored elsewhere) */
+int zk_gather(zk_ctx *ctx, const void *d_send, size_t bytes, int root, void *d_recv);
+/* party p receives d_send[p * bytes ..] of the root (d_send is ignored elsewhere) */
+int zk_scatter(zk_ctx *ctx, const void *d_send, size_t bytes, int root, void *d_recv);
+/* d_msm end to end (dmsm.rs:9-43): the batch of local MSMs (:19-24), the gather of the 144-byte results
+ * (:29) as ONE all-gather, and the leader closure unpack2 -> sum -> pack_from_public (:30-39) as the public
+ * linear map  h_out[k] = sum_i coeffs[i] * C_{i,k}  computed by every party for its own slot.
+ * h_coeffs: world x 4 u64 CANONICAL scalars (for party p: coeffs[i] = c_p * lambda_i).  h_lambda (optional,
+ * Montgomery): this party's scalars are multiplied by it on the device before its MSM; callers that pass
+ * lambda_p = sum_j unpack2[j][p] pass coeffs[i] = c_p for all i (7 additions + one scalar multiplication).
+ * h_out: count x 18 u64 normalised Jacobian -- this party's share of every result. */
+int zk_d_msm(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets, const void *const *d_scalars,
+             const size_t *n, const uint64_t *h_lambda, const uint64_t *h_coeffs, uint64_t *h_out);
 
 /* ---- test hooks (used by tests/ only; stable but not part of the drop-in surface) --- */
 int zk_dbg_fq_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);

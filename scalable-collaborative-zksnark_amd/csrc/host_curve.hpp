@@ -237,6 +237,15 @@ static inline Jac scalar_mul(const Aff& P, const uint64_t k[4]) {
     }
     return acc;
 }
+// k*P for a Jacobian P
+static inline Jac scalar_mul_jac(const Jac& P, const uint64_t k[4]) {
+    Jac acc = jac_inf();
+    for (int i = 255; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((k[i / 64] >> (i % 64)) & 1) acc = jac_add(acc, P);
+    }
+    return acc;
+}
 // batch normalisation (one inversion)
 static inline void batch_to_affine(const std::vector<Jac>& in, Aff* out) {
     size_t n = in.size();

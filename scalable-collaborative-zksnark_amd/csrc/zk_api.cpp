@@ -89,6 +89,12 @@ extern "C" {
 
 const char* zk_version(void) { return "zkhip 0.1 (gfx950)"; }
 
+int zk_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return ZK_ERR_NO_DEVICE;
+    return count;
+}
+
 int zk_ctx_create(int device_id, zk_ctx** out) {
     if (!out) return ZK_ERR_INVALID;
     *out = nullptr;
@@ -117,6 +123,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    zk_comm_destroy(ctx);
     for (auto& a : ctx->scratch)
         if (a.p) hipFree(a.p);
     for (auto& kv : ctx->pool_free)
@@ -213,6 +220,21 @@ int zk_memcpy_d2h(zk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     if (!ctx) return ZK_ERR_INVALID;
     ZK_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int zk_mem_info(zk_ctx* ctx, size_t* h_free, size_t* h_total) {
+    if (!ctx) return ZK_ERR_INVALID;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    ZK_HIP(ctx, hipMemGetInfo(&f, &t));
+    if (h_free) *h_free = f;
+    if (h_total) *h_total = t;
+    return ZK_OK;
+}
+int zk_memcpy_d2d(zk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    if (!ctx) return ZK_ERR_INVALID;
+    if (bytes) ZK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return ZK_OK;
 }
 

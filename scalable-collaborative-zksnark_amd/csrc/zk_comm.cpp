@@ -1,0 +1,285 @@
+// zk_comm.cpp -- the party exchanges of the path behind the C ABI: an RCCL communicator inside the ctx.
+//
+// The reference moves every message through a TCP star (mpc-net) wrapped by the typed adapter
+// dist-primitive/src/utils/serializing_net.rs:11-141 -- five patterns: gather to the leader (:11-39),
+// gather to any receiver (:41-72), scatter from the leader (:74-96), scatter from any sender (:98-122)
+// and leader_compute = gather + public map + scatter (:128-141).  On one node the party axis is the GPU
+// axis, so they become collectives on raw Montgomery limbs in HBM over xGMI (no serialisation, no
+// compression): zk_gather / zk_scatter for the four plain patterns, zk_allgather (+ the public map
+// replicated on every party) for leader_compute, zk_alltoall for the looped dynamic scatters of
+// dacc_product.rs:94-104,155-203.  All of them are enqueued on the ctx stream.
+//
+// RCCL is resolved at run time (dlopen of librccl.so.1, re-using the copy a host framework already
+// mapped): libzkhip.so has no link-time dependency on it and loads on machines without it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "zk_ctx.hpp"
+
+namespace zk {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+static Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // a copy that is already mapped (torch ships its own) must be the one we use: one RCCL, one HIP runtime
+        for (const char* n : names)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* n : names)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.handle) {
+            r.err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");
+            return;
+        }
+        bool ok = true;
+        auto sym = [&](const char* n) {
+            void* p = dlsym(r.handle, n);
+            if (!p) {
+                ok = false;
+                r.err = std::string("RCCL symbol missing: ") + n;
+            }
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) r.handle = nullptr;
+    });
+    return r.handle ? &r : nullptr;
+}
+
+static int rccl_missing(zk_ctx* ctx) { return fail(ctx, ZK_ERR_COMM, "RCCL unavailable (librccl.so.1 could not be loaded)"); }
+
+#define ZK_NCCL(ctx, R, call)                                                                 \
+    do {                                                                                       \
+        ncclResult_t _r = (call);                                                              \
+        if (_r != ncclSuccess) return zk::fail(ctx, ZK_ERR_COMM, "%s: %s", #call, (R)->GetErrorString(_r)); \
+    } while (0)
+
+static int need_comm(zk_ctx* ctx, Rccl** r) {
+    if (!ctx) return ZK_ERR_INVALID;
+    if (!ctx->comm) return fail(ctx, ZK_ERR_COMM, "no communicator: call zk_comm_init first");
+    *r = rccl();
+    if (!*r) return rccl_missing(ctx);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
+    return ZK_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+int zk_comm_unique_id(uint8_t h_id[ZK_COMM_ID_BYTES]) {
+    static_assert(ZK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!h_id) return ZK_ERR_INVALID;
+    Rccl* r = rccl();
+    if (!r) return ZK_ERR_COMM;
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess) return ZK_ERR_COMM;
+    std::memcpy(h_id, id.internal, ZK_COMM_ID_BYTES);
+    return ZK_OK;
+}
+
+int zk_comm_init(zk_ctx* ctx, int rank, int world, const uint8_t h_id[ZK_COMM_ID_BYTES]) {
+    if (!ctx) return ZK_ERR_INVALID;
+    if (!h_id || world < 1 || rank < 0 || rank >= world) return fail(ctx, ZK_ERR_INVALID, "zk_comm_init: bad rank / world / id");
+    if (ctx->comm) return fail(ctx, ZK_ERR_INVALID, "zk_comm_init: the ctx already has a communicator");
+    Rccl* r = rccl();
+    if (!r) return rccl_missing(ctx);
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(id.internal, h_id, ZK_COMM_ID_BYTES);
+    ncclComm_t c = nullptr;
+    ZK_NCCL(ctx, r, r->CommInitRank(&c, world, id, rank));
+    ctx->comm = c;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return ZK_OK;
+}
+
+int zk_comm_init_all(zk_ctx* const* ctxs, int world) {
+    if (!ctxs || world < 1) return ZK_ERR_INVALID;
+    for (int i = 0; i < world; i++)
+        if (!ctxs[i] || ctxs[i]->comm) return ZK_ERR_INVALID;
+    Rccl* r = rccl();
+    if (!r) return rccl_missing(ctxs[0]);
+    std::vector<int> devs(world);
+    for (int i = 0; i < world; i++) devs[i] = ctxs[i]->device;
+    std::vector<ncclComm_t> comms(world, nullptr);
+    ZK_NCCL(ctxs[0], r, r->CommInitAll(comms.data(), world, devs.data()));
+    for (int i = 0; i < world; i++) {
+        ctxs[i]->comm = comms[i];
+        ctxs[i]->comm_rank = i;
+        ctxs[i]->comm_world = world;
+    }
+    return ZK_OK;
+}
+
+int zk_comm_destroy(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_INVALID;
+    if (!ctx->comm) return ZK_OK;
+    Rccl* r = rccl();
+    if (r) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+        r->CommDestroy((ncclComm_t)ctx->comm);
+    }
+    ctx->comm = nullptr;
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
+    return ZK_OK;
+}
+
+int zk_comm_rank(const zk_ctx* ctx) { return ctx ? ctx->comm_rank : -1; }
+int zk_comm_size(const zk_ctx* ctx) { return ctx ? ctx->comm_world : -1; }
+
+int zk_allgather(zk_ctx* ctx, const void* d_send, size_t bytes, void* d_recv) {
+    Rccl* r = nullptr;
+    int rc = need_comm(ctx, &r);
+    if (rc) return rc;
+    if (bytes == 0) return ZK_OK;
+    if (!d_send || !d_recv) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    ZK_NCCL(ctx, r, r->AllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream));
+    return ZK_OK;
+}
+
+int zk_alltoall(zk_ctx* ctx, const void* d_send, size_t bytes_per_peer, void* d_recv) {
+    Rccl* r = nullptr;
+    int rc = need_comm(ctx, &r);
+    if (rc) return rc;
+    if (bytes_per_peer == 0) return ZK_OK;
+    if (!d_send || !d_recv) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    const int w = ctx->comm_world;
+    ZK_NCCL(ctx, r, r->GroupStart());
+    for (int p = 0; p < w; p++) {
+        ncclResult_t a = r->Send((const char*)d_send + (size_t)p * bytes_per_peer, bytes_per_peer, ncclUint8, p, (ncclComm_t)ctx->comm, ctx->stream);
+        ncclResult_t b = r->Recv((char*)d_recv + (size_t)p * bytes_per_peer, bytes_per_peer, ncclUint8, p, (ncclComm_t)ctx->comm, ctx->stream);
+        if (a != ncclSuccess || b != ncclSuccess) {
+            r->GroupEnd();
+            return fail(ctx, ZK_ERR_COMM, "ncclSend/ncclRecv: %s", r->GetErrorString(a != ncclSuccess ? a : b));
+        }
+    }
+    ZK_NCCL(ctx, r, r->GroupEnd());
+    return ZK_OK;
+}
+
+int zk_gather(zk_ctx* ctx, const void* d_send, size_t bytes, int root, void* d_recv) {
+    Rccl* r = nullptr;
+    int rc = need_comm(ctx, &r);
+    if (rc) return rc;
+    const int w = ctx->comm_world, me = ctx->comm_rank;
+    if (root < 0 || root >= w) return fail(ctx, ZK_ERR_INVALID, "zk_gather: bad root");
+    if (bytes == 0) return ZK_OK;
+    if (!d_send || (me == root && !d_recv)) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    ZK_NCCL(ctx, r, r->GroupStart());
+    ncclResult_t e = r->Send(d_send, bytes, ncclUint8, root, (ncclComm_t)ctx->comm, ctx->stream);
+    if (me == root)
+        for (int p = 0; p < w && e == ncclSuccess; p++) e = r->Recv((char*)d_recv + (size_t)p * bytes, bytes, ncclUint8, p, (ncclComm_t)ctx->comm, ctx->stream);
+    ncclResult_t g = r->GroupEnd();
+    if (e != ncclSuccess || g != ncclSuccess) return fail(ctx, ZK_ERR_COMM, "zk_gather: %s", r->GetErrorString(e != ncclSuccess ? e : g));
+    return ZK_OK;
+}
+
+int zk_scatter(zk_ctx* ctx, const void* d_send, size_t bytes, int root, void* d_recv) {
+    Rccl* r = nullptr;
+    int rc = need_comm(ctx, &r);
+    if (rc) return rc;
+    const int w = ctx->comm_world, me = ctx->comm_rank;
+    if (root < 0 || root >= w) return fail(ctx, ZK_ERR_INVALID, "zk_scatter: bad root");
+    if (bytes == 0) return ZK_OK;
+    if (!d_recv || (me == root && !d_send)) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    ZK_NCCL(ctx, r, r->GroupStart());
+    ncclResult_t e = r->Recv(d_recv, bytes, ncclUint8, root, (ncclComm_t)ctx->comm, ctx->stream);
+    if (me == root)
+        for (int p = 0; p < w && e == ncclSuccess; p++) e = r->Send((const char*)d_send + (size_t)p * bytes, bytes, ncclUint8, p, (ncclComm_t)ctx->comm, ctx->stream);
+    ncclResult_t g = r->GroupEnd();
+    if (e != ncclSuccess || g != ncclSuccess) return fail(ctx, ZK_ERR_COMM, "zk_scatter: %s", r->GetErrorString(e != ncclSuccess ? e : g));
+    return ZK_OK;
+}
+
+// d_msm end to end (dist-primitive/src/dmsm.rs:9-43): the local MSMs of the batch (:19-24), the gather of
+// the 144-byte results (:29) as one all-gather over xGMI, and the leader's public map unpack2 -> sum ->
+// pack_from_public (:30-39) replicated on every party for its own slot:  out_k = sum_i coeff_i * C_{i,k}.
+// h_lambda (optional, Montgomery): this party's scalars are multiplied by it on the device first
+// (MSM(b, lambda s) = lambda MSM(b, s)); with lambda_p = sum_j unpack2[j][p] every coeff_i collapses to the
+// one pack coefficient c_p and the map is 7 point additions and a single scalar multiplication.
+int zk_d_msm(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* offsets, const void* const* d_scalars, const size_t* n,
+             const uint64_t* h_lambda, const uint64_t* h_coeffs, uint64_t* h_out) {
+    Rccl* r = nullptr;
+    int rc = need_comm(ctx, &r);
+    if (rc) return rc;
+    if (count == 0) return ZK_OK;
+    if (!srs || !d_scalars || !n || !h_coeffs || !h_out) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    const int w = ctx->comm_world;
+    std::vector<MsmItem> items(count);
+    std::vector<void*> scaled;
+    auto release = [&] {
+        for (void* p : scaled) zk_free(ctx, p);
+    };
+    const uint64_t zero[4] = {0, 0, 0, 0};
+    for (size_t k = 0; k < count; k++) {
+        const void* sc = d_scalars[k];
+        if (h_lambda && n[k]) {
+            void* t = nullptr;
+            rc = zk_malloc(ctx, n[k] * 32, &t);
+            if (!rc) {
+                scaled.push_back(t);
+                rc = fr_axpb(ctx, nullptr, sc, h_lambda, zero, t, n[k]);
+            }
+            if (rc) {
+                release();
+                return rc;
+            }
+            sc = t;
+        }
+        items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, sc, n[k]};
+    }
+    std::vector<uint64_t> local(count * 18), all((size_t)w * count * 18);
+    rc = msm_g1_batch(ctx, items.data(), count, local.data());
+    release();
+    if (rc) return rc;
+    const size_t bytes = count * 144;
+    char* d = (char*)scratch(ctx, 7, bytes * (size_t)(w + 1));
+    if (!d) return ZK_ERR_OOM;
+    ZK_HIP(ctx, hipMemcpyAsync(d, local.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_NCCL(ctx, r, r->AllGather(d, d + bytes, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(all.data(), d + bytes, bytes * w, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // rows of the combination: item k <- the w points C_{0,k} .. C_{w-1,k}
+    std::vector<uint64_t> rows((size_t)count * w * 18);
+    for (size_t k = 0; k < count; k++)
+        for (int p = 0; p < w; p++) std::memcpy(&rows[(k * w + p) * 18], &all[((size_t)p * count + k) * 18], 144);
+    return g1_lincomb_batch_host(ctx, rows.data(), h_coeffs, (size_t)w, count, h_out);
+}
+
+}  // extern "C"

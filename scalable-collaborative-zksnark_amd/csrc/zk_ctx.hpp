@@ -48,6 +48,9 @@ struct zk_ctx {
     size_t pool_bytes = 0;
     std::mutex pool_mu;  // a garbage collector may release buffers from another thread
     int cu_count = 256;
+    // party exchanges (zk_comm.cpp): an RCCL communicator bound to this ctx's GPU
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
 };
 
 namespace zk {

@@ -1537,12 +1537,22 @@ int g1_lincomb_batch_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint6
         }
         for (int k = 0; k < 4; k++) ksum[k] = t[k];
     }
+    // all coefficients equal (d_msm with pre-scaled scalars: every coeff_i is the pack coefficient c_p;
+    // d_commit / d_open sums: all ones): sum the points first, then ONE scalar multiplication
+    bool same_k = n > 1;
+    for (size_t i = 1; i < n && same_k; i++) same_k = std::memcmp(h_scalars_canon + 4 * i, h_scalars_canon, 32) == 0;
     auto row_work = [&](size_t r0, size_t r1) {
         for (size_t r = r0; r < r1; r++) {
             bool same = n > 1;
             for (size_t i = 1; i < n && same; i++) same = (pts[r * n + i].x == pts[r * n].x) && (pts[r * n + i].y == pts[r * n].y);
             if (same) {
                 acc[r] = H::scalar_mul(pts[r * n], ksum);
+                continue;
+            }
+            if (same_k && top > 0) {
+                H::Jac sum = H::jac_inf();
+                for (size_t i = 0; i < n; i++) sum = H::jac_add_mixed(sum, pts[r * n + i]);
+                acc[r] = H::scalar_mul_jac(sum, h_scalars_canon);
                 continue;
             }
             for (int b = top; b >= 0; b--) {

@@ -23,11 +23,14 @@ SYMBOLS = [
     ("zk_ctx_set_stream", _i, [_vp, _vp]),
     ("zk_ctx_sync", _i, [_vp]),
     ("zk_version", ctypes.c_char_p, []),
+    ("zk_device_count", _i, []),
+    ("zk_mem_info", _i, [_vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     ("zk_malloc", _i, [_vp, _sz, _pp]),
     ("zk_free", _i, [_vp, _vp]),
     ("zk_trim", _i, [_vp, ctypes.POINTER(ctypes.c_size_t)]),
     ("zk_memcpy_h2d", _i, [_vp, _vp, _vp, _sz]),
     ("zk_memcpy_d2h", _i, [_vp, _vp, _vp, _sz]),
+    ("zk_memcpy_d2d", _i, [_vp, _vp, _vp, _sz]),
     ("zk_fr_add", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_fr_sub", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_fr_mul", _i, [_vp, _vp, _vp, _vp, _sz]),
@@ -56,6 +59,17 @@ SYMBOLS = [
     ("zk_msm_window", _i, [_sz]),
     ("zk_msm_set_window", _i, [_vp, _i]),
     ("zk_msm_last_timing", _i, [_vp, _vp]),
+    ("zk_comm_unique_id", _i, [_vp]),
+    ("zk_comm_init", _i, [_vp, _i, _i, _vp]),
+    ("zk_comm_init_all", _i, [_vp, _i]),
+    ("zk_comm_destroy", _i, [_vp]),
+    ("zk_comm_rank", _i, [_vp]),
+    ("zk_comm_size", _i, [_vp]),
+    ("zk_allgather", _i, [_vp, _vp, _sz, _vp]),
+    ("zk_alltoall", _i, [_vp, _vp, _sz, _vp]),
+    ("zk_gather", _i, [_vp, _vp, _sz, _i, _vp]),
+    ("zk_scatter", _i, [_vp, _vp, _sz, _i, _vp]),
+    ("zk_d_msm", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("zk_dbg_fq_mul", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_fq_add", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_fq_sub", _i, [_vp, _vp, _vp, _vp, _sz]),
@@ -63,7 +77,7 @@ SYMBOLS = [
     ("zk_dbg_g1_op", _i, [_vp, _i, _vp, _vp, _vp, _sz]),
 ]
 
-ZK_OK, ZK_ERR_INVALID, ZK_ERR_LENGTH, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_DIV_ZERO, ZK_ERR_OOM = 0, -1, -2, -3, -4, -5, -6
+ZK_OK, ZK_ERR_INVALID, ZK_ERR_LENGTH, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_DIV_ZERO, ZK_ERR_OOM, ZK_ERR_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 def build(force: bool = False) -> str:

@@ -149,6 +149,18 @@ class Ctx:
         self._check(self.lib.zk_ctx_sync(self.h))
 
     # ---- memory ----
+    def mem_info(self):
+        """(free, total) bytes of this ctx's GPU"""
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._check(self.lib.zk_mem_info(self.h, ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
+    def trim(self) -> int:
+        """hand every parked zk_free block back to the driver; returns the bytes released"""
+        f = ctypes.c_size_t(0)
+        self._check(self.lib.zk_trim(self.h, ctypes.byref(f)))
+        return f.value
+
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
@@ -167,6 +179,9 @@ class Ctx:
         zero = np.zeros(4, dtype=np.uint64)
         self._check(self.lib.zk_fr_axpb(self.h, 0, _ptr(b), _h(al), _h(zero), _ptr(out), n))
         return out
+
+    def copy_d2d(self, dst, src, nbytes: int):
+        self._check(self.lib.zk_memcpy_d2d(self.h, _ptr(dst), _ptr(src), nbytes))
 
     def to_device(self, a: np.ndarray) -> DeviceBuffer:
         a = np.ascontiguousarray(a)
@@ -342,6 +357,70 @@ class Ctx:
         out = np.zeros((count, 18), dtype=np.uint64)
         if count:
             self._check(self.lib.zk_g1_lincomb_batch(self.h, _h(pts), _h(sc), n, count, _h(out)))
+        return out
+
+    # ---- party exchanges through the C ABI (RCCL communicator inside the ctx) ----
+    def comm_unique_id(self) -> bytes:
+        buf = (ctypes.c_uint8 * 128)()
+        rc = self.lib.zk_comm_unique_id(buf)
+        if rc != 0:
+            raise ZkError(rc, "zk_comm_unique_id failed (RCCL not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.zk_comm_init(self.h, rank, world, buf))
+
+    def comm_destroy(self):
+        self._check(self.lib.zk_comm_destroy(self.h))
+
+    @property
+    def comm_rank(self) -> int:
+        return self.lib.zk_comm_rank(self.h)
+
+    @property
+    def comm_size(self) -> int:
+        return self.lib.zk_comm_size(self.h)
+
+    def allgather(self, d_send, nbytes: int, d_recv=None):
+        d_recv = d_recv or self.alloc(max(nbytes * self.comm_size, 1))
+        self._check(self.lib.zk_allgather(self.h, _ptr(d_send), nbytes, _ptr(d_recv)))
+        return d_recv
+
+    def alltoall(self, d_send, nbytes_per_peer: int, d_recv=None):
+        d_recv = d_recv or self.alloc(max(nbytes_per_peer * self.comm_size, 1))
+        self._check(self.lib.zk_alltoall(self.h, _ptr(d_send), nbytes_per_peer, _ptr(d_recv)))
+        return d_recv
+
+    def gather(self, d_send, nbytes: int, root: int, d_recv=None):
+        if self.comm_rank == root:
+            d_recv = d_recv or self.alloc(max(nbytes * self.comm_size, 1))
+        self._check(self.lib.zk_gather(self.h, _ptr(d_send), nbytes, root, _ptr(d_recv)))
+        return d_recv
+
+    def scatter(self, d_send, nbytes: int, root: int, d_recv=None):
+        d_recv = d_recv or self.alloc(max(nbytes, 1))
+        self._check(self.lib.zk_scatter(self.h, _ptr(d_send), nbytes, root, _ptr(d_recv)))
+        return d_recv
+
+    def d_msm(self, srs_list, scalars_list, lens, coeffs_canon: np.ndarray, lam_mont=None, offsets=None) -> np.ndarray:
+        """zk_d_msm: batch of local MSMs + all-gather + this party's row of the public map -> [count, 18]"""
+        count = len(lens)
+        out = np.zeros((count, 18), dtype=np.uint64)
+        if count == 0:
+            return out
+        h = (ctypes.c_void_p * count)(*[s.h for s in srs_list])
+        sp = (ctypes.c_void_p * count)(*[_ptr(s) for s in scalars_list])
+        nn = (ctypes.c_size_t * count)(*[int(x) for x in lens])
+        off = (ctypes.c_size_t * count)(*[int(x) for x in (offsets or [0] * count)])
+        co = np.ascontiguousarray(coeffs_canon, dtype=np.uint64).reshape(-1, 4)
+        assert len(co) == self.comm_size
+        lam = np.ascontiguousarray(lam_mont, dtype=np.uint64) if lam_mont is not None else None
+        rc = self.lib.zk_d_msm(self.h, count, h, off, sp, nn, _h(lam) if lam is not None else 0, _h(co), _h(out))
+        if rc == ZK_ERR_LENGTH:
+            raise MsmLengthError(rc, (self.lib.zk_last_error(self.h) or b"").decode(), 0)
+        self._check(rc)
         return out
 
     def msm_set_window(self, c: int):

@@ -68,6 +68,10 @@ def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: Packe
     lam = sum(pp.unpack2_matrix[j][p] for j in range(pp.l)) % R_MOD
     c_p = sum(pp.pack_matrix[p][j] for j in range(pp.l)) % R_MOD
     lam_m = fr_mont(lam)
+    if getattr(net, "ctx", None) is be and hasattr(be, "d_msm"):
+        # the communicator lives in the same ctx: the whole of d_msm is ONE C-ABI call (zk_d_msm)
+        net._count(144 * len(lens))
+        return be.d_msm(list(bases), list(scalars), list(lens), np.tile(int_to_limbs(c_p, 4), (n, 1)), lam_mont=lam_m)
     scaled = [be.fr_scale(s, lam_m, m, out=be.temp(32 * m, ("d_msm", k)) if hasattr(be, "temp") else None)
               for k, (s, m) in enumerate(zip(scalars, lens))]
     c_shares = be.msm_g1_batch(list(bases), scaled, list(lens))

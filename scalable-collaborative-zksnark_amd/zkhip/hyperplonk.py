@@ -50,8 +50,12 @@ class PackedProvingParameters:
     d_commitment: List = None  # levels 0..n-1          (new_random, dpoly_comm.rs:220-233)
 
     @staticmethod
-    def new(n: int, pp: PackedSharingParams, be, seed: int) -> "PackedProvingParameters":
-        """dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy()"""
+    def new(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = None) -> "PackedProvingParameters":
+        """
+        dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy().  chal_seed: the
+        challenges are public values every party shares (the reference's local mode clones ONE parameter set
+        for all parties, mpc-net/src/multi.rs:344); pass the same chal_seed to parties with different table seeds.
+        """
         l, npar = pp.l, pp.n
         M = 1 << n
         pk = PackedProvingParameters(n=n)
@@ -75,7 +79,7 @@ class PackedProvingParameters:
         ):
             rnd(name, length)
         sd[0] += 1
-        ch = random_fr(3 * n + 4 + 3, sd[0])
+        ch = random_fr(3 * n + 4 + 3, sd[0] if chal_seed is None else chal_seed)
         pk.challenge, pk.challenge_r1, pk.challenge_r2 = ch[:n], ch[n : 2 * n + 2], ch[2 * n + 2 : 3 * n + 4]
         pk.alpha, pk.beta, pk.gamma = ch[3 * n + 4], ch[3 * n + 5], ch[3 * n + 6]
         # synthetic SRS (random points in the reference as well)
@@ -93,7 +97,7 @@ def _at(buf, byte_off):
     return buf.at(byte_off) if hasattr(buf, "at") else buf + byte_off
 
 
-def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_np, eq_top):
+def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top):
     """step 2 of dhyperplonk (:262-514) == the body of dpermcheck (:992-1245)"""
     T, L = pk.tables, pk.lens
     l, npar = pp.l, net.n_parties
@@ -102,10 +106,20 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     wiring_proofs, wiring_commits, wiring_opens = [], [], []
     # 2.a (:268-294): every party broadcasts local_s; s = concatenation over parties (an all-gather)
     if data_parallel:
-        s_np = random_fr(4 * M // l, seed * 31 + 4)
+        s_dev = be.to_device(random_fr(4 * M // l, seed * 31 + 4))
+    elif hasattr(net, "all_gather_device"):
+        # RCCL inside the ctx: the 4M/(l N_p) Fr of every party meet in HBM (256 MiB per party at n = 24),
+        # nothing crosses PCIe
+        s_dev = net.all_gather_device(local_s_l, 32 * (4 * M // npar // l))
+    elif getattr(net, "echo", False) and hasattr(be, "copy_d2d"):
+        # the no-comm fake hands the leader N_p copies of its own message (dhyperplonk.rs:289-293)
+        cnt = 4 * M // npar // l
+        net._count(32 * cnt)
+        s_dev = be.alloc(32 * cnt * npar)
+        for q in range(npar):
+            be.copy_d2d(s_dev.at(32 * cnt * q), local_s_l, 32 * cnt)
     else:
-        s_np = np.concatenate(net.all_gather(local_s_np))
-    s_dev = be.to_device(s_np)
+        s_dev = be.to_device(np.concatenate(net.all_gather(local_s_l.download((4 * M // npar // l, 4)))))
     # 2.b (commit of local_s) and the d_open of local_s in 2.d are independent of everything below: they ride
     # in the batched passes of :363-407 (same positions in the output lists as in the reference)
     wiring_proofs.append(dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net))  # 2.c
@@ -174,7 +188,7 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     tm = Timers(net.is_leader)
     # "Jump from sky" (:187-190)
     local_s_p = be.to_device(random_fr(4 * M // npar, seed * 31 + 1))
-    local_s_np = random_fr(4 * M // npar // l, seed * 31 + 2)
+    local_s_l = be.to_device(random_fr(4 * M // npar // l, seed * 31 + 2))  # resident, like every other table
     eq_top = be.to_device(random_fr(pp.n, seed * 31 + 3))
     net.sync()
     tm.start("Distributed HyperPlonk")
@@ -207,7 +221,7 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
 
     # Step 2: wiring identity (shared with dpermcheck)
     tm.start("Wire identity")
-    wiring_proofs, wiring_commits, wiring_opens = _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_np, eq_top)
+    wiring_proofs, wiring_commits, wiring_opens = _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top)
     tm.end()
 
     # Open (:517-553)
@@ -227,12 +241,12 @@ def dpermcheck(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be,
     l, npar = pp.l, net.n_parties
     M = 1 << n
     tm = Timers(net.is_leader)
-    local_s_np = random_fr(4 * M // npar // l, seed * 31 + 2)
+    local_s_l = be.to_device(random_fr(4 * M // npar // l, seed * 31 + 2))
     local_s_p = be.to_device(random_fr(4 * M // npar, seed * 31 + 1))
     eq_top = be.to_device(random_fr(pp.n, seed * 31 + 3))
     net.sync()
     tm.start("Distributed Permcheck")
-    res = _wiring_identity(n, pk, pp, be, net, seed, False, local_s_p, local_s_np, eq_top)
+    res = _wiring_identity(n, pk, pp, be, net, seed, False, local_s_p, local_s_l, eq_top)
     tm.end()
     return res, tm.t
 

@@ -122,6 +122,59 @@ class TorchDistNet(Net):
         return [r[q] for q in range(self.n_parties)]
 
 
+class RcclNet(Net):
+    """
+    The C-ABI communicator (zk_comm_init / zk_allgather / zk_alltoall, include/zkhip.h): the exchanges run on
+    the ctx stream over RCCL, buffers stay in HBM -- `all_gather_device` moves no byte over PCIe.  The
+    numpy-typed methods of the Net interface stage through one cached device buffer.
+    """
+
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
+        self.ctx, self.party_id, self.n_parties = ctx, rank, world
+        ctx.comm_init(rank, world, unique_id)
+
+    @staticmethod
+    def from_torch_dist(ctx, group=None) -> "RcclNet":
+        """bootstrap: rank 0 creates the RCCL id, torch.distributed (any backend) hands it to the others"""
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return RcclNet(ctx, rank, world, box[0])
+
+    def all_gather_device(self, d_send, nbytes: int, d_recv=None):
+        """-> device buffer with n_parties * nbytes, ordered by party; stays in HBM"""
+        self._count(nbytes)
+        return self.ctx.allgather(d_send, nbytes, d_recv)
+
+    def all_to_all_device(self, d_send, nbytes_per_peer: int, d_recv=None):
+        self._count(nbytes_per_peer)
+        return self.ctx.alltoall(d_send, nbytes_per_peer, d_recv)
+
+    def all_gather(self, a):
+        a = np.ascontiguousarray(a)
+        nb = a.nbytes
+        if nb == 0:
+            return [a.copy() for _ in range(self.n_parties)]
+        buf = self.ctx.temp(nb * (self.n_parties + 1), "rcclnet")
+        buf.upload(a)
+        self.all_gather_device(buf.ptr, nb, buf.at(nb))
+        h = buf.download((self.n_parties, nb), dtype=np.uint8, offset=nb)
+        return [h[q].view(a.dtype).reshape(a.shape) for q in range(self.n_parties)]
+
+    def all_to_all(self, chunks, echo="slot0"):
+        a = np.ascontiguousarray(np.stack(chunks))
+        per = a.nbytes // self.n_parties
+        if per == 0:
+            return [a[q].copy() for q in range(self.n_parties)]
+        buf = self.ctx.temp(2 * a.nbytes, "rcclnet")
+        buf.upload(a)
+        self.all_to_all_device(buf.ptr, per, buf.at(a.nbytes))
+        r = buf.download(a.shape, dtype=a.dtype, offset=a.nbytes)
+        return [r[q] for q in range(self.n_parties)]
+
+
 class _LocalHub:
     def __init__(self, n):
         self.n = n

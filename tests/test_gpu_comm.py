@@ -1,0 +1,187 @@
+"""
+The party exchanges behind the C ABI (zk_comm_* / zk_allgather / zk_alltoall / zk_gather / zk_scatter /
+zk_d_msm, include/zkhip.h) on the GPU box.
+
+  * world size 1: a real RCCL communicator on GPU 0 -- API, layout and the d_msm composite against the oracle;
+  * world size min(8, device_count): one process per GPU over RCCL/xGMI, the protocol primitives
+    (d_msm, d_sumcheck_product, sharded MSM / sumcheck) against the oracle.  Skips itself below 2 GPUs.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import jac_norm_to_affine, pt_ints, pt_mont, rand_fr, synthetic_bases
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cctx():
+    """a ctx of its own carrying a world-1 communicator"""
+    import zkhip
+
+    c = zkhip.Ctx(0)
+    c.comm_init(0, 1, c.comm_unique_id())
+    yield c
+    c.close()
+
+
+def test_collectives_world1(cctx):
+    assert (cctx.comm_rank, cctx.comm_size) == (0, 1)
+    a = rand_fr(37, 5)
+    d = cctx.to_device(a)
+    for fn in (lambda: cctx.allgather(d, a.nbytes), lambda: cctx.alltoall(d, a.nbytes), lambda: cctx.gather(d, a.nbytes, 0),
+               lambda: cctx.scatter(d, a.nbytes, 0)):
+        out = fn()
+        assert (out.download(a.shape) == a).all()
+
+
+def test_comm_errors(ctx, cctx):
+    import zkhip
+    from zkhip._lib import ZK_ERR_COMM, ZK_ERR_INVALID
+
+    d = ctx.to_device(rand_fr(4, 1))
+    with pytest.raises(zkhip.ZkError) as e:  # the session ctx has no communicator
+        ctx.allgather(d, 128)
+    assert e.value.code == ZK_ERR_COMM
+    with pytest.raises(zkhip.ZkError) as e:
+        cctx.gather(cctx.to_device(rand_fr(4, 1)), 128, 3)
+    assert e.value.code == ZK_ERR_INVALID
+    with pytest.raises(zkhip.ZkError) as e:  # a second communicator on the same ctx
+        cctx.comm_init(0, 1, cctx.comm_unique_id())
+    assert e.value.code == ZK_ERR_INVALID
+
+
+def test_d_msm_world1_against_oracle(cctx, co):
+    """one party: out = coeff * MSM(bases, lambda * scalars); batch of two sizes"""
+    import pyoracle as po
+
+    lam, coeff = 0x1234567890ABCDEF1122334455667788, 0x0FEDCBA987654321
+    outs, exp = None, []
+    srs_l, sc_l, lens = [], [], []
+    for n, seed in ((300, 3), (1024, 4)):
+        bases, _ = synthetic_bases(n, seed)
+        sc = rand_fr(n, seed + 10)
+        srs_l.append(cctx.srs_register(bases))
+        sc_l.append(cctx.to_device(sc))
+        lens.append(n)
+        plain = pt_ints(co.msm_g1(bases, sc))
+        exp.append(po.g1_mul(plain, lam * coeff % po.R_MOD))
+    co_limbs = np.array([[(coeff >> (64 * i)) & (2**64 - 1) for i in range(4)]], dtype=np.uint64)
+    lam_m = np.array(po.fr_to_mont_limbs(lam), dtype=np.uint64)
+    outs = cctx.d_msm(srs_l, sc_l, lens, co_limbs, lam_mont=lam_m)
+    for k in range(2):
+        assert pt_ints(jac_norm_to_affine(outs[k])) == exp[k]
+    # without the pre-scaling
+    outs = cctx.d_msm(srs_l, sc_l, lens, co_limbs)
+    for k in range(2):
+        assert po.g1_mul(pt_ints(jac_norm_to_affine(outs[k])), lam) == exp[k]
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import pyoracle as po
+from helpers import pt_ints, pt_mont, jac_norm_to_affine
+import zkhip
+from zkhip import dist_primitive as dp, sharding as sh
+from zkhip.net import RcclNet, TorchDistNet
+from zkhip.pss import PackedSharingParams
+rank, world, lrank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(lrank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", lrank))
+ctx = zkhip.Ctx(lrank)
+net = RcclNet.from_torch_dist(ctx)              # the C-ABI communicator (RCCL inside the ctx)
+tnet = TorchDistNet(device=torch.device("cuda", lrank))  # torch.distributed's RCCL, same semantics
+W, p = net.n_parties, net.party_id
+to_m = lambda xs: np.array([po.fr_to_mont_limbs(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
+ints = lambda a: [po.fr_from_mont_limbs(r) for r in np.asarray(a).reshape(-1, 4)]
+rng = po.SplitMix64(4321)          # same stream on every rank: every rank can rebuild all inputs
+# raw collectives: every rank's payload is recognisable
+mine = np.full((5, 4), p + 1, dtype=np.uint64)
+got = net.all_gather(mine)
+assert all((got[q] == q + 1).all() for q in range(W))
+got = net.all_to_all([np.full((3, 4), 100 * p + q, dtype=np.uint64) for q in range(W)])
+assert all((got[q] == 100 * q + p).all() for q in range(W))
+d = ctx.to_device(mine)
+g = ctx.gather(d, mine.nbytes, W - 1)
+if p == W - 1:
+    h = g.download((W, 5, 4))
+    assert all((h[q] == q + 1).all() for q in range(W))
+src = ctx.to_device(np.arange(W * 8, dtype=np.uint64)) if p == 0 else None
+r = ctx.scatter(src, 64, 0)
+assert (r.download((8,)) == np.arange(8 * p, 8 * p + 8)).all()
+# protocol primitives over both nets
+n = 6
+pf = [rng.fr_vec(1 << n) for _ in range(W)]
+pg = [rng.fr_vec(1 << n) for _ in range(W)]
+s = W.bit_length() - 1
+ch = rng.fr_vec(n + s)
+for nt in (net, tnet):
+    out = dp.d_sumcheck_product(ctx, ctx.to_device(to_m(pf[p])), ctx.to_device(to_m(pg[p])), 1 << n, to_m(ch), nt)
+    if p == 0:
+        assert [tuple(ints(t)) for t in out] == po.d_sumcheck_product_all(pf, pg, ch)
+    else:
+        assert len(out) == 0
+    N = 1 << 10
+    full_f, full_g, chs = rng.fr_vec(N), rng.fr_vec(N), rng.fr_vec(10)
+    got = sh.sharded_sumcheck_product(ctx, ctx.to_device(sh.cyclic_shard(to_m(full_f), p, W)), ctx.to_device(sh.cyclic_shard(to_m(full_g), p, W)), N // W, to_m(chs), nt)
+    assert [tuple(ints(t)) for t in got] == po.sumcheck_product(full_f, full_g, chs)
+    pts, scs = po.g1_bases(64, 77), rng.fr_vec(64)
+    per = 64 // W
+    got = sh.sharded_msm(ctx, ctx.srs_register(np.array([pt_mont(P) for P in pts[p*per:(p+1)*per]])), ctx.to_device(to_m(scs[p*per:(p+1)*per])), per, nt)
+    assert pt_ints(jac_norm_to_affine(got)) == po.g1_msm(pts, scs)
+if W == 8:                           # the l = 1, 8-party d_msm: zk_d_msm (C ABI) and the torch.distributed path
+    pp, opp = PackedSharingParams(1), po.PackedSharingParams(1)
+    bases = [[po.g1_bases(40, 50 + q)] for q in range(W)]
+    scal = [[rng.fr_vec(40)] for _ in range(W)]
+    exp = po.d_msm_all(bases, scal, opp)
+    srs = ctx.srs_register(np.array([pt_mont(P) for P in bases[p][0]]))
+    for nt in (net, tnet):
+        got = dp.d_msm(ctx, [srs], [ctx.to_device(to_m(scal[p][0]))], [40], pp, nt)
+        assert pt_ints(jac_norm_to_affine(got[0])) == exp[p][0]
+dist.barrier()
+print("RANK_OK", p)
+ctx.close()
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_multi_rank_protocol():
+    import zkhip
+
+    ndev = zkhip.lib().zk_device_count()  # (not torch: its bundled HIP/RCCL must not be mapped into this process after ours)
+    if ndev < 2:
+        pytest.skip(f"{ndev} GPU visible: the multi-rank RCCL test needs at least 2")
+    world = 8 if ndev >= 8 else (4 if ndev >= 4 else 2)
+    script = "ROOT = %r\n" % ROOT + WORKER
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "--no-python", sys.executable, "-c", script]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("RANK_OK") == world
+
+
+def test_rccl_worker_script_world1():
+    """the same worker under torchrun with ONE rank: keeps the script itself exercised on 1-GPU boxes"""
+    script = "ROOT = %r\n" % ROOT + WORKER
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "--no-python", sys.executable, "-c", script]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("RANK_OK") == 1

@@ -6,7 +6,10 @@ End-to-end collaborative HyperPlonk (hyperplonk/src/dhyperplonk.rs) on MI355X.
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/hyperplonk_bench.py --nvars 20   # l = 1, 8 parties = 8 GPUs
 
 Prints the reference's timer sections (Commit / Gate identity / Wire identity / Open / total)
-and the Comm: (up, down) byte counters for the leader.
+and the Comm: (up, down) byte counters for the leader.  Every run is SELF-CHECKING (unless --no-check):
+all sumcheck transcripts must pass their verifier chains (zkhip.verify, dsumcheck.rs:541-588), sampled
+commits / opens must equal a one-call-at-a-time recomputation, and the timed repetitions must reproduce
+the same transcript bit for bit; a failed check exits non-zero.
 """
 import argparse, json, os, sys, time
 
@@ -14,11 +17,59 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd"))
 
 
+def digest(res):
+    import hashlib
+
+    import numpy as np
+
+    h = hashlib.sha256()
+
+    def feed(x):
+        if isinstance(x, np.ndarray):
+            h.update(np.ascontiguousarray(x, dtype=np.uint64).tobytes())
+        elif isinstance(x, (list, tuple)):
+            for e in x:
+                feed(e)
+
+    feed(res)
+    return h.hexdigest()
+
+
+def self_check(n, res, digests, pk, pp, ctx, net, run_seed, world):
+    """size-independent properties of a finished run (see tests/test_gpu_e2e_fullsize.py); "ok" or the failures"""
+    import numpy as np
+
+    from zkhip import dist_primitive as dp
+    from zkhip.field import random_fr
+    from zkhip.verify import check_dhyperplonk_transcripts
+
+    bad = list(check_dhyperplonk_transcripts(n, res, pk, pp.n, net.is_leader, world == 1))
+    if len(set(digests)) != 1:
+        bad.append("repetitions disagree")
+    (gate_proofs, gate_comms), (w_proofs, w_commits, w_opens) = res
+    T, M = pk.tables, 1 << n
+    hlen = 4 * M // pp.n
+    same = lambda a, b: (np.asarray(a[0]) == np.asarray(b[0])).all() and np.asarray(a[1]).shape == np.asarray(b[1]).shape and (np.asarray(a[1]) == np.asarray(b[1])).all()
+    # one call at a time (collective calls: every rank takes part)
+    local_s_p = ctx.to_device(random_fr(hlen, run_seed * 31 + 1))
+    if not (w_commits[0] == dp.d_commit(ctx, pk.d_commitment, local_s_p, hlen, net)).all():
+        bad.append("d_commit(local_s) differs from the single call")
+    if not same(w_opens[4], dp.d_open(ctx, pk.d_commitment, T["sid_p"], hlen, pk.challenge_r2, net)):
+        bad.append("d_open(sid_p) differs from the single call")
+    if not same(w_opens[1], dp.c_open(ctx, pk.c_commitment, T["V"], 4 * M, pk.challenge_r2, pp, net)):
+        bad.append("c_open(V) differs from the single call")
+    if not (gate_comms[0][0] == dp.c_commit(ctx, pk.c_commitment, [T["a_evals"]], [pk.lens["a_evals"]], pp, net)[0]).all():
+        bad.append("c_commit(a) differs from the single call")
+    return "ok" if not bad else bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", "--nvars", dest="n", type=int, default=14)  # use --nvars under torch.distributed.run (its own parser grabs --n)
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--data-parallel", action="store_true")
+    ap.add_argument("--net", choices=("rccl", "torch"), default="rccl", help="multi-rank exchanges: the C-ABI communicator (RCCL inside the ctx, device-resident) or torch.distributed")
+    ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
     import zkhip
     from zkhip.hyperplonk import PackedProvingParameters, dhyperplonk
@@ -42,27 +93,40 @@ def main():
         else:
             dist.init_process_group(backend)
         assert world == pp.n, "l = 1 needs exactly 8 parties"
-        net = TorchDistNet(device=torch.device("cuda", lrank) if backend == "nccl" else None)
+    ctx = zkhip.Ctx(lrank)
+    if world > 1:
+        from zkhip.net import RcclNet
+
+        if args.net == "rccl" and backend == "nccl":
+            net = RcclNet.from_torch_dist(ctx)
+        else:
+            net = TorchDistNet(device=torch.device("cuda", lrank) if backend == "nccl" else None)
     else:
         from zkhip.net import LeaderEchoNet
 
         net = LeaderEchoNet(pp.n)
-    ctx = zkhip.Ctx(lrank)
     t0 = time.perf_counter()
-    pk = PackedProvingParameters.new(args.n, pp, ctx, seed=0x5CA1AB1E % 1000 + rank)
+    pk = PackedProvingParameters.new(args.n, pp, ctx, seed=0x5CA1AB1E % 1000 + rank, chal_seed=0xC4A1)  # challenges are shared public values
     setup = time.perf_counter() - t0
-    best = None
+    best, digests, res = None, [], None
     for r in range(args.reps + 1):
         res, timers = dhyperplonk(args.n, pk, pp, ctx, net, seed=7 + rank, data_parallel=args.data_parallel)
+        digests.append(digest(res))
         if r > 0 or args.reps == 0:
             if best is None or timers["Distributed HyperPlonk"] < best["Distributed HyperPlonk"]:
                 best = timers
+    checks = "skipped"
+    if not args.no_check:
+        checks = self_check(args.n, res, digests, pk, pp, ctx, net, 7 + rank, world)
     if rank == 0:
-        print(json.dumps({"n": args.n, "l": 1, "parties": pp.n, "mode": ("comm(" + os.environ.get("ZK_BENCH_BACKEND", "nccl") + ")") if world > 1 else "leader-echo",
-                          "setup_s": setup, "timers_s": best, "comm_bytes": [net.upload, net.download]}))
+        print(json.dumps({"n": args.n, "l": 1, "parties": pp.n, "mode": ("comm(" + os.environ.get("ZK_BENCH_BACKEND", "nccl") + "," + type(net).__name__ + ")") if world > 1 else "leader-echo",
+                          "setup_s": setup, "timers_s": best, "comm_bytes": [net.upload, net.download], "checks": checks}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if checks not in ("ok", "skipped"):
+        print("rank", rank, "self-check failed:", checks, file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":
