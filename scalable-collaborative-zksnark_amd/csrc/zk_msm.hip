@@ -1420,48 +1420,30 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     return ZK_OK;
 }
 
+// zk_srs.hip: d_out96[i] = start + i * step in the internal affine form
+int fill_sequence_affine(zk_ctx* ctx, const zkhost::Aff& start, const zkhost::Aff& step, size_t n, void* d_out96);
+
 int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, zk_srs** out) {
     namespace H = zkhost;
     if (!out) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
     H::Aff G{H::to_mont(H::GX_CANON), H::to_mont(H::GY_CANON)};
-    H::Aff start = H::jac_to_aff(H::scalar_mul(G, k0));
-    H::Aff step = H::jac_to_aff(H::scalar_mul(G, k1));
-    std::vector<H::Aff> pts(n);
-    const size_t CH = 4096;
-    // chunk k starts at start + k*CH*step; chunks are independent -> host threads (setup only)
-    const size_t nchunk = (n + CH - 1) / CH;
-    std::vector<H::Jac> chunk_start(nchunk);
-    {
-        uint64_t chs[4] = {CH, 0, 0, 0};
-        H::Aff stride = H::jac_to_aff(H::scalar_mul(step, chs));
-        H::Jac cur = H::aff_inf(start) ? H::jac_inf() : H::Jac{start.x, start.y, H::ONE};
-        for (size_t k = 0; k < nchunk; k++) {
-            chunk_start[k] = cur;
-            cur = H::jac_add_mixed(cur, stride);
-        }
+    const H::Aff start = H::jac_to_aff(H::scalar_mul(G, k0));
+    const H::Aff step = H::jac_to_aff(H::scalar_mul(G, k1));
+    SrsGuard guard;
+    zk_srs* s = guard.s = new zk_srs();
+    s->n = n;
+    s->owned = true;
+    if (n) {
+        ZK_HIP(ctx, device_alloc(ctx, &s->d_bases, 2 * n * 96));  // P_i, then phi(P_i)
+        int rc = fill_sequence_affine(ctx, start, step, n, s->d_bases);  // the walk and the normalisation run on the device
+        if (rc) return rc;
+        srs_endo(ctx, s);
+        ZK_HIP(ctx, hipGetLastError());
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    auto work = [&](size_t k0c, size_t k1c) {
-        std::vector<H::Jac> chunk;
-        for (size_t k = k0c; k < k1c; k++) {
-            const size_t base = k * CH, m = std::min(CH, n - base);
-            chunk.resize(m);
-            H::Jac cur = chunk_start[k];
-            for (size_t i = 0; i < m; i++) {
-                chunk[i] = cur;
-                cur = H::jac_add_mixed(cur, step);
-            }
-            H::batch_to_affine(chunk, &pts[base]);
-        }
-    };
-    const size_t nth = std::min<size_t>({nchunk, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)64});
-    if (nth <= 1) {
-        work(0, nchunk);
-    } else {
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nth; t++) th.emplace_back(work, nchunk * t / nth, nchunk * (t + 1) / nth);
-        for (auto& x : th) x.join();
-    }
-    return srs_pack(ctx, pts.data(), 96, n, out);
+    *out = guard.release();
+    return ZK_OK;
 }
 
 // K9: tiny public linear maps on points (PSS unpack2 / pack of d_msm's leader closure,
