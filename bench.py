@@ -243,7 +243,7 @@ def main():
                     if best is None or tm.get("Distributed HyperPlonk", 1e9) < best.get("Distributed HyperPlonk", 1e9):
                         best = tm
                 bad = check_dhyperplonk_transcripts(e_n, res, pk, 8, e_net.is_leader, world == 1)
-                extra["e2e"] = {"n": e_n, "l": 1, "parties": 8, "mode": "leader (party 0's full work, no-comm echo net)" if world == 1 else "8 parties = 8 GPUs, RCCL inside the ctx",
+                extra["e2e"] = {"n": e_n, "l": 1, "parties": 8, "mode": "leader (party 0's full work, no-comm echo net)" if world == 1 else f"8 parties = 8 ranks, exchanges: {type(e_net).__name__} ({backend})",
                                 "setup_s": setup_s, "timers_s": best, "scalar_muls_per_proof": 24903603, "transcript_checks": "ok" if not bad else bad}
                 if bad:
                     extra["e2e"]["timers_s"] = None  # an unverified figure is not a figure
