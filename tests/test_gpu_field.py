@@ -157,3 +157,20 @@ def test_quad_lane_additions(tmp_path):
                            "-o", exe, os.path.join(root, "tools", "quad_selftest.hip")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "add_quad mismatches 0, acc_quad mismatches 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_share_file_to_device_and_back(ctx, tmp_path):
+    """examples/delegator.rs share files <-> resident Montgomery tables, conversions on the GPU"""
+    import pyoracle as po
+    from zkhip import serialize as ser
+
+    rng = po.SplitMix64(77)
+    xs = rng.fr_vec(1000) + [0, 1, po.R_MOD - 1]
+    p = tmp_path / "worker_0"
+    p.write_bytes(ser.fr_vec_serialize(xs))
+    buf, n = ser.fr_file_to_device(ctx, str(p))
+    assert n == len(xs)
+    mont = buf.download((n, 4))
+    assert [po.fr_from_mont_limbs(r) for r in mont] == xs
+    ser.fr_device_to_file(ctx, buf, n, str(tmp_path / "out"))
+    assert (tmp_path / "out").read_bytes() == p.read_bytes()
