@@ -135,6 +135,22 @@ int zk_srs_wrap_device(zk_ctx *ctx, const void *d_bases96, size_t n, zk_srs **ou
 /* Synthetic SRS on device: P_i = (k0 + i*k1)*G, the generator G1; mirrors the random-point SRS of
  * PolynomialCommitmentCub::new_single/new_random (dpoly_comm.rs:197-233). k0,k1 canonical 4xu64. */
 int zk_srs_generate(zk_ctx *ctx, const uint64_t h_k0[4], const uint64_t h_k1[4], size_t n, zk_srs **out);
+/* Structured SRS, PolynomialCommitmentCub::new (dpoly_comm.rs:37-67): out_levels[k], k = 0..nvars, receives
+ * powers_of_g[k] = g^{E_k[j]}, E_0 = [1], E_{k+1} = E_k (1 - s_{nvars-k-1}) ++ E_k s_{nvars-k-1}  (2^k points).
+ * h_g96: the base in the reference affine layout (NULL: the G1 generator); h_s: nvars Fr (Montgomery).
+ * The exponents are expanded in Fr on the device and every point is one fixed-base multiplication. */
+int zk_srs_powers(zk_ctx *ctx, const void *h_g96, const uint64_t *h_s, size_t nvars, zk_srs **out_levels);
+/* One party's packed level, PolynomialCommitmentCub::to_packed (dpoly_comm.rs:164-194): out[k] = sum_{j<l}
+ * row[j] * level[k l + j] with row = this party's row of the pack_from_public matrix (l CANONICAL 4 x u64
+ * scalars); a level shorter than l is zero-extended to one chunk. */
+int zk_srs_to_packed(zk_ctx *ctx, const zk_srs *level, const uint64_t *h_row, size_t l, zk_srs **out);
+/* zk_fr_apply_matrix on G1 points -- the PSS maps are generic over DomainCoeff (pss.rs:93-171; the leader's
+ * unpack2 / pack_from_public on commitments, dmsm.rs:30-39): device buffers of affine points in the reference
+ * layout (96 B, x = y = 0: infinity), h_matrix = rows*cols CANONICAL 4 x u64 scalars,
+ *   out[j*out_vec_stride + r*out_row_stride] = sum_c M[r*cols + c] * in[j*in_vec_stride + c*in_comp_stride]. */
+int zk_g1_apply_matrix(zk_ctx *ctx, const uint64_t *h_matrix, size_t rows, size_t cols, const void *d_in96,
+                       size_t in_vec_stride, size_t in_comp_stride, void *d_out96, size_t out_vec_stride,
+                       size_t out_row_stride, size_t k);
 /* Optional, once per SRS level (setup, like uploading it): build the table 2^{o_w} * P_i for every
  * window offset o_w of a `window_bits`-wide signed-digit decomposition (0 = pick for the level's
  * length).  MSMs on this SRS then use ONE bucket set for all windows: 1/W of the bucket-reduction

@@ -873,3 +873,30 @@ def c_acc_product_and_share_all(shares, masks, unmask0, unmask1, unmask2, pp: Pa
         s2 = [v * unmask2[me][i] % R_MOD for i, v in enumerate(s2)]
         outs.append((s0, s1, s2))
     return outs
+
+
+# --------------------------------------------------------------------------
+# Structured SRS (dist-primitive/src/dpoly_comm.rs:37-67, :164-194)
+# --------------------------------------------------------------------------
+def srs_powers(g: Point, s: Sequence[int]) -> List[List[Point]]:
+    """PolynomialCommitmentCub::new: powers_of_g[0] = [g]; level i+1 = [e*(1-s_{n-i-1})] ++ [e*s_{n-i-1}]"""
+    n = len(s)
+    levels = [[g]]
+    for i in range(n):
+        sv = s[n - i - 1] % R_MOD
+        prev = levels[i]
+        levels.append([g1_mul(e, (1 - sv) % R_MOD) for e in prev] + [g1_mul(e, sv) for e in prev])
+    return levels
+
+
+def srs_to_packed(levels: Sequence[Sequence[Point]], pp: "PackedSharingParams") -> List[List[List[Point]]]:
+    """to_packed (:164-194): result[party][level] = that party's share of every l-chunk of the level"""
+    out = [[None] * len(levels) for _ in range(pp.n)]
+    for i, v in enumerate(levels):
+        if len(v) < pp.l:
+            chunks = [pp.pack_from_public_g1(list(v) + [None] * (pp.l - len(v)))]
+        else:
+            chunks = [pp.pack_from_public_g1(list(v[k : k + pp.l])) for k in range(0, len(v), pp.l)]
+        for j in range(pp.n):
+            out[j][i] = [c[j] for c in chunks]
+    return out

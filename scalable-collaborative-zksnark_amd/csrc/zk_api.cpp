@@ -320,6 +320,20 @@ int zk_srs_generate(zk_ctx* ctx, const uint64_t k0[4], const uint64_t k1[4], siz
     NEED(ctx, out && k0 && k1);
     return srs_generate(ctx, k0, k1, n, out);
 }
+int zk_srs_powers(zk_ctx* ctx, const void* h_g96, const uint64_t* h_s, size_t nvars, zk_srs** out_levels) {
+    NEED(ctx, out_levels && (nvars == 0 || h_s));
+    return srs_powers(ctx, h_g96, h_s, nvars, out_levels);
+}
+int zk_srs_to_packed(zk_ctx* ctx, const zk_srs* level, const uint64_t* h_row, size_t l, zk_srs** out) {
+    NEED(ctx, level && h_row && out);
+    return srs_to_packed(ctx, level, h_row, l, out);
+}
+int zk_g1_apply_matrix(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_t cols, const void* d_in96, size_t in_vec_stride,
+                       size_t in_comp_stride, void* d_out96, size_t out_vec_stride, size_t out_row_stride, size_t k) {
+    NEED(ctx, k == 0 || rows == 0 || (h_matrix && d_in96 && d_out96));
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    return g1_apply_matrix_ref(ctx, h_matrix, rows, cols, d_in96, in_vec_stride, in_comp_stride, d_out96, out_vec_stride, out_row_stride, k);
+}
 int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs, int window_bits) {
     NEED(ctx, srs);
     return srs_precompute(ctx, srs, window_bits);

@@ -98,6 +98,11 @@ void msm_host_pool_destroy(zk_ctx* ctx);
 int srs_from_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out);
 int srs_download(zk_ctx* ctx, const zk_srs* srs, void* h_out96);
 int srs_generate(zk_ctx* ctx, const uint64_t* k0, const uint64_t* k1, size_t n, zk_srs** out);
+// ---- zk_srs.hip ----
+int srs_powers(zk_ctx* ctx, const void* h_g96, const uint64_t* h_s, size_t nvars, zk_srs** out_levels);
+int srs_to_packed(zk_ctx* ctx, const zk_srs* level, const uint64_t* h_row, size_t l, zk_srs** out);
+int g1_apply_matrix_ref(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_t cols, const void* d_in, size_t isv, size_t isc, void* d_out,
+                        size_t osv, size_t osr, size_t k);
 int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n);
 int msm_pick_window(size_t n);
 int g1_lincomb_batch_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h_scalars_canon, size_t n, size_t count,

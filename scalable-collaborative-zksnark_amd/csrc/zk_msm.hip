@@ -1420,6 +1420,9 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     return ZK_OK;
 }
 
+void srs_finish_endo(zk_ctx* ctx, zk_srs* s) { srs_endo(ctx, s); }
+void srs_convert_form(zk_ctx* ctx, const void* in, void* out, size_t npoints, bool to_internal) { srs_convert(ctx, in, out, npoints, to_internal); }
+
 // zk_srs.hip: d_out96[i] = start + i * step in the internal affine form
 int fill_sequence_affine(zk_ctx* ctx, const zkhost::Aff& start, const zkhost::Aff& step, size_t n, void* d_out96);
 

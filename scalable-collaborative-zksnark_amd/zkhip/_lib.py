@@ -46,6 +46,9 @@ SYMBOLS = [
     ("zk_srs_register", _i, [_vp, _vp, _sz, _sz, _pp]),
     ("zk_srs_wrap_device", _i, [_vp, _vp, _sz, _pp]),
     ("zk_srs_generate", _i, [_vp, _vp, _vp, _sz, _pp]),
+    ("zk_srs_powers", _i, [_vp, _vp, _vp, _sz, _vp]),
+    ("zk_srs_to_packed", _i, [_vp, _vp, _vp, _sz, _pp]),
+    ("zk_g1_apply_matrix", _i, [_vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _sz]),
     ("zk_srs_precompute", _i, [_vp, _vp, _i]),
     ("zk_srs_free", _i, [_vp, _vp]),
     ("zk_srs_len", _sz, [_vp]),

@@ -293,6 +293,32 @@ class Ctx:
         self._check(self.lib.zk_srs_generate(self.h, _h(a), _h(b), n, ctypes.byref(h)))
         return Srs(self, h.value)
 
+    def srs_powers(self, s: np.ndarray, g: np.ndarray = None):
+        """PolynomialCommitmentCub::new (dpoly_comm.rs:37-67): s [n,4] Montgomery -> list of n+1 Srs levels"""
+        s = np.ascontiguousarray(s, dtype=np.uint64).reshape(-1, 4)
+        n = len(s)
+        handles = (ctypes.c_void_p * (n + 1))()
+        gp = np.ascontiguousarray(g, dtype=np.uint64) if g is not None else None
+        self._check(self.lib.zk_srs_powers(self.h, _h(gp) if gp is not None else 0, _h(s) if n else 0, n, handles))
+        return [Srs(self, handles[k]) for k in range(n + 1)]
+
+    def srs_to_packed(self, level: Srs, row_canon: np.ndarray, l: int) -> Srs:
+        """to_packed (dpoly_comm.rs:164-194) for one party: row_canon [l,4] canonical pack coefficients"""
+        row = np.ascontiguousarray(row_canon, dtype=np.uint64).reshape(-1, 4)
+        assert len(row) >= min(l, len(level))
+        h = ctypes.c_void_p()
+        self._check(self.lib.zk_srs_to_packed(self.h, level.h, _h(row), l, ctypes.byref(h)))
+        return Srs(self, h.value)
+
+    def g1_apply_matrix(self, matrix_canon: np.ndarray, d_in, in_vec_stride: int, in_comp_stride: int, k: int, out_vec_stride: int, out_row_stride: int, out=None):
+        """zk_fr_apply_matrix on affine G1 points (reference layout, 96 B): matrix [rows, cols, 4] CANONICAL scalars"""
+        m = np.ascontiguousarray(matrix_canon, dtype=np.uint64)
+        rows, cols = m.shape[0], m.shape[1]
+        span = (k - 1) * out_vec_stride + (rows - 1) * out_row_stride + 1 if k and rows else 1
+        out = out or self.alloc(96 * span)
+        self._check(self.lib.zk_g1_apply_matrix(self.h, _h(m), rows, cols, _ptr(d_in), in_vec_stride, in_comp_stride, _ptr(out), out_vec_stride, out_row_stride, k))
+        return out
+
     def msm_g1(self, srs: Srs, scalars, n: int, offset: int = 0) -> np.ndarray:
         """-> normalised Jacobian [18] uint64"""
         out = np.zeros(18, dtype=np.uint64)

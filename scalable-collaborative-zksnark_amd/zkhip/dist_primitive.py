@@ -215,6 +215,41 @@ def d_acc_product(be, inputs, N: int, net: Net):
 # ---------------------------------------------------------------------------------------
 # polynomial commitment (dpoly_comm.rs:236-464).  powers_of_g: list of Srs, level k has 2^k points
 # ---------------------------------------------------------------------------------------
+class PolynomialCommitmentCub:
+    """
+    dpoly_comm.rs:18-28,36-234: the un-matured parameter set (`powers_of_g[k]` = one Srs level of 2^k points,
+    resident in HBM).  `mature()` (:141-151, projective -> affine) has nothing left to do here: levels are
+    built and kept as affine records.  powers_of_g2 is not carried (G2 only serves the pairing check `verify`).
+    """
+
+    def __init__(self, powers_of_g: List):
+        self.powers_of_g = powers_of_g
+
+    @staticmethod
+    def new(be, s: np.ndarray, g: np.ndarray = None) -> "PolynomialCommitmentCub":
+        """:37-67: s = [n,4] Montgomery Fr; level k = g^{eq-basis over s_{n-k}..s_{n-1}} (one device pass per level)"""
+        return PolynomialCommitmentCub(be.srs_powers(s, g))
+
+    @staticmethod
+    def new_single(be, len_log_2: int, pp: PackedSharingParams, seed: int = 1) -> "PolynomialCommitmentCub":
+        """:197-219: a toy single-party parameter set, level i holds max(1, 2^i / l) synthetic points"""
+        return PolynomialCommitmentCub([be.srs_generate(seed * 7919 + 2 * i + 1, seed * 104729 + 2 * i + 3, max(1, (1 << i) // pp.l)) for i in range(len_log_2 + 1)])
+
+    @staticmethod
+    def new_random(be, len_log_2: int, party_count: int, seed: int = 1) -> "PolynomialCommitmentCub":
+        """:220-233: levels 0 .. len_log_2 - log2(party_count) of 2^i synthetic points"""
+        top = len_log_2 - (party_count.bit_length() - 1)
+        return PolynomialCommitmentCub([be.srs_generate(seed * 6007 + 2 * i + 5, seed * 15485863 + 2 * i + 7, 1 << i) for i in range(top + 1)])
+
+    def to_packed(self, be, pp: PackedSharingParams, party: int) -> "PolynomialCommitmentCub":
+        """:164-194 for ONE party (every GPU builds its own share): level i -> pack_from_public of every l-chunk"""
+        row = np.array([int_to_limbs(pp.pack_matrix[party][j], 4) for j in range(pp.l)], dtype=np.uint64)
+        return PolynomialCommitmentCub([be.srs_to_packed(lv, row, pp.l) for lv in self.powers_of_g])
+
+    def mature(self) -> List:
+        return self.powers_of_g
+
+
 def commit(be, powers_of_g, peval, length: int) -> np.ndarray:
     """dpoly_comm.rs:237-243 (= d_local_commit :269-275)"""
     level = length.bit_length() - 1

@@ -1,0 +1,137 @@
+"""Structured SRS, packed SRS and the PSS maps on G1 points, all on the device, against the oracle's literal
+restatement of PolynomialCommitmentCub::new / to_packed (dpoly_comm.rs:37-67,164-194) and pss.rs:93-171."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+from helpers import jac_norm_to_affine, pt_ints, pt_mont, rand_fr
+
+pytestmark = pytest.mark.gpu
+
+
+def _canon(xs):
+    return np.array([[(int(x) >> (64 * i)) & (2**64 - 1) for i in range(4)] for x in xs], dtype=np.uint64)
+
+
+def _mont(xs):
+    return np.array([po.fr_to_mont_limbs(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
+
+
+def test_srs_powers_matches_reference_construction(ctx):
+    rng = po.SplitMix64(2024)
+    n = 5
+    s = rng.fr_vec(n)
+    exp = po.srs_powers(po.G1_GEN, s)
+    levels = ctx.srs_powers(_mont(s))
+    assert len(levels) == n + 1
+    for k in range(n + 1):
+        got = levels[k].download()
+        assert [pt_ints(r) for r in got] == exp[k], f"level {k}"
+    # another base, and a commitment against the structured level equals the oracle MSM
+    g = po.g1_mul(po.G1_GEN, 0xDEADBEEF)
+    lv = ctx.srs_powers(_mont(s[:3]), g=pt_mont(g))
+    assert [pt_ints(r) for r in lv[3].download()] == po.srs_powers(g, s[:3])[3]
+    sc = rng.fr_vec(1 << n)
+    got = ctx.msm_g1(levels[n], ctx.to_device(_mont(sc)), 1 << n)
+    assert pt_ints(jac_norm_to_affine(got)) == po.g1_msm(exp[n], sc)
+
+
+def test_srs_powers_large_is_a_valid_eq_basis(ctx, co):
+    """2^16 points: sum of the level = g (the eq weights sum to 1) and a random linear check against the exponents"""
+    rng = po.SplitMix64(5)
+    n = 16
+    s = rng.fr_vec(n)
+    levels = ctx.srs_powers(_mont(s))
+    ones = ctx.to_device(_mont([1] * (1 << n)))
+    for k in (n - 1, n):
+        got = ctx.msm_g1(levels[k], ones, 1 << k)
+        assert pt_ints(jac_norm_to_affine(got)) == po.G1_GEN
+    # <level_n, t> == g^{sum_j E_n[j] t_j}: E_n[j] = prod_i (s_i if bit else 1 - s_i); index bit (n-1-i) <-> s_i ... checked on 16 sampled j
+    E = [1]
+    for i in range(n):
+        sv = s[n - i - 1]
+        E = [e * (1 - sv) % po.R_MOD for e in E] + [e * sv % po.R_MOD for e in E]
+    pts = levels[n].download()
+    for j in (0, 1, 2, 12345, (1 << n) - 1):
+        assert pt_ints(pts[j]) == po.g1_mul(po.G1_GEN, E[j])
+
+
+@pytest.mark.parametrize("l", [1, 2, 4])
+def test_srs_to_packed_matches_reference(ctx, l):
+    from zkhip.pss import PackedSharingParams
+
+    rng = po.SplitMix64(77 + l)
+    n = 4
+    s = rng.fr_vec(n)
+    exp_levels = po.srs_powers(po.G1_GEN, s)
+    opp, pp = po.PackedSharingParams(l), PackedSharingParams(l)
+    exp = po.srs_to_packed(exp_levels, opp)
+    levels = ctx.srs_powers(_mont(s))
+    for party in (0, 3, pp.n - 1):
+        row = _canon([pp.pack_matrix[party][j] for j in range(l)])
+        for k in range(n + 1):
+            got = ctx.srs_to_packed(levels[k], row, l).download()
+            assert [pt_ints(r) for r in got] == exp[party][k], (party, k)
+
+
+@pytest.mark.parametrize("l", [1, 2])
+def test_g1_pss_maps_on_device(ctx, l):
+    """pack_from_public / unpack2 on vectors of points through zk_g1_apply_matrix == the oracle's group FFTs"""
+    from zkhip.pss import PackedSharingParams
+
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    k = 5
+    pts = po.g1_bases(k * pp.n, 9) + []
+    pts[3] = None  # an infinity among the inputs
+    d_in = ctx.to_device(np.array([pt_mont(P) for P in pts]))
+    # unpack2: vectors of n shares (contiguous) -> l secrets each
+    m = _canon([v for row in pp.unpack2_matrix for v in row]).reshape(l, pp.n, 4)
+    out = ctx.g1_apply_matrix(m, d_in, pp.n, 1, k, l, 1).download((k * l, 12))
+    for j in range(k):
+        exp = opp.unpack2_g1(pts[j * pp.n : (j + 1) * pp.n])
+        assert [pt_ints(r) for r in out[j * l : (j + 1) * l]] == exp
+    # pack_from_public: vectors of l secrets -> n shares, written party-major (out[p*k + j])
+    secrets = pts[: k * l]
+    d_s = ctx.to_device(np.array([pt_mont(P) for P in secrets]))
+    mp = _canon([pp.pack_matrix[p][j] for p in range(pp.n) for j in range(l)]).reshape(pp.n, l, 4)
+    out = ctx.g1_apply_matrix(mp, d_s, l, 1, k, 1, k).download((pp.n * k, 12))
+    for j in range(k):
+        exp = opp.pack_from_public_g1(secrets[j * l : (j + 1) * l])
+        assert [pt_ints(out[p * k + j]) for p in range(pp.n)] == exp
+
+
+def test_packed_commitment_shares_recombine(ctx):
+    """
+    the reference's own property (dpoly_comm.rs:502-531 / dmsm.rs:92-138): c_commit against the PACKED structured
+    SRS with packed scalar shares, unpack2 over the parties' results == commit of the plain polynomial
+    """
+    from zkhip import dist_primitive as dp
+    from zkhip.net import LocalTestNet
+    from zkhip.pss import PackedSharingParams
+
+    l, n = 2, 5
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    rng = po.SplitMix64(99)
+    s, poly = rng.fr_vec(n), rng.fr_vec(1 << n)
+    cub = dp.PolynomialCommitmentCub.new(ctx, _mont(s))
+    plain = dp.commit(ctx, cub.mature(), ctx.to_device(_mont(poly)), 1 << n)
+    # scalar shares: pack every l-chunk, party p collects share p
+    sh = [[] for _ in range(pp.n)]
+    for k in range(0, 1 << n, l):
+        for p, v in enumerate(pp.pack_from_public(poly[k : k + l])):
+            sh[p].append(v)
+
+    import zkhip
+
+    def party(net):
+        be = zkhip.Ctx(0)  # one ctx per party thread (calls on one ctx are not concurrent)
+        try:
+            packed = cub.to_packed(be, pp, net.party_id).mature()
+            return dp.c_commit(be, packed, [be.to_device(_mont(sh[net.party_id]))], [(1 << n) // l], pp, net)[0]
+        finally:
+            be.close()
+
+    outs = LocalTestNet.simulate_network_round(pp.n, party)
+    # every party's output is its share of the packed result [C; l]: unpack recovers C in every slot
+    got = opp.unpack_g1([pt_ints(jac_norm_to_affine(o)) for o in outs])
+    assert got == [pt_ints(jac_norm_to_affine(plain))] * l
