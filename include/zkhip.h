@@ -92,6 +92,17 @@ int zk_fr_axpb(zk_ctx *ctx, const void *d_a, const void *d_b, const uint64_t h_a
 int zk_fr_apply_matrix(zk_ctx *ctx, const uint64_t *h_matrix, size_t rows, size_t cols, const void *d_in,
                        size_t in_vec_stride, size_t in_comp_stride, void *d_out, size_t out_vec_stride,
                        size_t out_row_stride, size_t k);
+/* The same maps by transforms, as the reference computes them (ark-poly radix-2 (coset) FFTs, pss.rs:93-171),
+ * for packing factors where the dense matrix is the slower form (8l >= 64): every vector is interpolated on a
+ * domain of size A, cut / zero-extended to min(A, B) coefficients, and evaluated on a domain of size B:
+ *   c = IDFT_A(in[0..n_in) zero-padded);  c[i] *= scale[i];  e = DFT_B(c zero-padded);  out[r] = e[r * step], r < take.
+ * h_winv: A/2 powers of omega_A^-1, h_w: B/2 powers of omega_B, h_scale: min(A, B) factors A^-1 (offB/offA)^i
+ * (the coset offsets of `get_coset`), all Montgomery Fr; A, B powers of two <= 512.  Strides as above.
+ *   pack_from_public: A = 2l (coset g), B = 8l, n_in = l (or 2l), take = 8l
+ *   unpack:  A = 8l, B = 2l (coset g), take = l          unpack2: A = 8l, B = 4l (coset g), take = l, step = 2 */
+int zk_fr_ntt_map(zk_ctx *ctx, size_t A, const uint64_t *h_winv, size_t B, const uint64_t *h_w, const uint64_t *h_scale,
+                  size_t n_in, size_t take, size_t step, const void *d_in, size_t in_vec_stride, size_t in_comp_stride,
+                  void *d_out, size_t out_vec_stride, size_t out_row_stride, size_t k);
 /* strided views of the product tree (dacc_product.rs:41-55, dhyperplonk.rs:344-359):
  * even[i] = t[2i] (v(x,0)), odd[i] = t[2i+1] (v(x,1)), i < n; v(1,x) is the contiguous upper half. */
 int zk_fr_deinterleave(zk_ctx *ctx, const void *d_t, void *d_even, void *d_odd, size_t n);

@@ -265,6 +265,12 @@ int zk_fr_apply_matrix(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_
     NEED(ctx, k == 0 || rows == 0 || (h_matrix && d_in && d_out));
     return fr_apply_matrix(ctx, h_matrix, rows, cols, d_in, in_vec_stride, in_comp_stride, d_out, out_vec_stride, out_row_stride, k);
 }
+int zk_fr_ntt_map(zk_ctx* ctx, size_t A, const uint64_t* h_winv, size_t B, const uint64_t* h_w, const uint64_t* h_scale, size_t n_in,
+                  size_t take, size_t step, const void* d_in, size_t in_vec_stride, size_t in_comp_stride, void* d_out, size_t out_vec_stride,
+                  size_t out_row_stride, size_t k) {
+    NEED(ctx, k == 0 || take == 0 || (h_winv && h_w && h_scale && d_in && d_out));
+    return fr_ntt_map(ctx, A, h_winv, B, h_w, h_scale, n_in, take, step, d_in, in_vec_stride, in_comp_stride, d_out, out_vec_stride, out_row_stride, k);
+}
 int zk_fr_deinterleave(zk_ctx* ctx, const void* d_t, void* d_even, void* d_odd, size_t n) {
     NEED(ctx, n == 0 || (d_t && d_even && d_odd));
     return fr_deinterleave(ctx, d_t, d_even, d_odd, n);

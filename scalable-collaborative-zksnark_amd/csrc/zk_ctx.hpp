@@ -75,6 +75,8 @@ int fr_binary(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size
 int fr_axpb(zk_ctx* ctx, const void* a, const void* b, const uint64_t* alpha, const uint64_t* beta, void* out, size_t n);
 int fr_apply_matrix(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_t cols, const void* d_in, size_t isv, size_t isc,
                     void* d_out, size_t osv, size_t osr, size_t k);
+int fr_ntt_map(zk_ctx* ctx, size_t A, const uint64_t* h_winv, size_t B, const uint64_t* h_w, const uint64_t* h_scale, size_t nin, size_t take,
+               size_t step, const void* d_in, size_t isv, size_t isc, void* d_out, size_t osv, size_t osr, size_t k);
 int fr_deinterleave(zk_ctx* ctx, const void* t, void* even, void* odd, size_t n);
 int fr_batch_div(zk_ctx* ctx, const void* num, const void* den, void* out, size_t n);
 // mode 0 plain sums, 1 product sums, 2 fold only, 3 open quotients

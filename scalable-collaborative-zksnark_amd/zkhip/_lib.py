@@ -36,6 +36,7 @@ SYMBOLS = [
     ("zk_fr_mul", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_fr_axpb", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     ("zk_fr_apply_matrix", _i, [_vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _sz]),
+    ("zk_fr_ntt_map", _i, [_vp, _sz, _vp, _sz, _vp, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _sz]),
     ("zk_fr_deinterleave", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_fr_batch_div", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_sumcheck", _i, [_vp, _vp, _sz, _vp, _vp, _vp]),

@@ -211,6 +211,15 @@ class Ctx:
         self._check(self.lib.zk_fr_apply_matrix(self.h, _h(m), rows, cols, _ptr(d_in), in_vec_stride, in_comp_stride, _ptr(out), out_vec_stride, out_row_stride, k))
         return out
 
+    def fr_ntt_map(self, tables: dict, d_in, in_vec_stride: int, in_comp_stride: int, k: int, out_vec_stride: int, out_row_stride: int, out=None):
+        """a PSS map by transforms (zk_fr_ntt_map); tables = PackedSharingParams.ntt_tables(kind)"""
+        t = tables
+        span = (k - 1) * out_vec_stride + (t["take"] - 1) * out_row_stride + 1 if k else 1
+        out = out or self.alloc(32 * span)
+        self._check(self.lib.zk_fr_ntt_map(self.h, t["A"], _h(t["winv"]), t["B"], _h(t["w"]), _h(t["scale"]), t["n_in"], t["take"], t["step"],
+                                           _ptr(d_in), in_vec_stride, in_comp_stride, _ptr(out), out_vec_stride, out_row_stride, k))
+        return out
+
     def fr_deinterleave(self, t, n):
         """(t[0::2], t[1::2]) for a table of 2n Fr -> two device buffers of n Fr"""
         even, odd = self.alloc(max(32 * n, 1)), self.alloc(max(32 * n, 1))

@@ -19,6 +19,7 @@ from .net import Net
 from .pss import PackedSharingParams
 
 ZERO = np.zeros(4, dtype=np.uint64)
+NTT_FROM_N = 64  # party counts from which the PSS maps on Fr run as transforms (zk_fr_ntt_map) instead of the dense matrix
 
 
 def _fr_vec_to_ints(a) -> List[int]:
@@ -444,7 +445,10 @@ def _unpack2_many_device(be, gathered: Sequence[np.ndarray], pp: PackedSharingPa
     if k == 0:
         return np.zeros((0, 4), dtype=np.uint64)
     d_in = be.to_device(np.concatenate([np.asarray(g, dtype=np.uint64).reshape(-1, 4) for g in gathered]))  # [n][k]
-    out = be.fr_apply_matrix(_mont_matrix(pp.unpack2_matrix), d_in, 1, k, k, pp.l, 1)  # out[j*l + r]
+    if pp.n >= NTT_FROM_N and hasattr(be, "fr_ntt_map"):  # the reference's own form: ifft on the share domain, fft on the secret2 coset
+        out = be.fr_ntt_map(pp.ntt_tables("unpack2"), d_in, 1, k, k, pp.l, 1)
+    else:
+        out = be.fr_apply_matrix(_mont_matrix(pp.unpack2_matrix), d_in, 1, k, k, pp.l, 1)  # out[j*l + r]
     return out.download((k * pp.l, 4))
 
 
@@ -576,8 +580,11 @@ def _pack_chunks(be, vals: np.ndarray, pp: PackedSharingParams) -> List[np.ndarr
     k = (len(vals) + l - 1) // l
     if len(vals) != k * l:
         vals = np.concatenate([vals, np.zeros((k * l - len(vals), 4), dtype=np.uint64)])
-    m = _mont_matrix([row[:l] for row in pp.pack_matrix])  # [n, l]
-    out = be.fr_apply_matrix(m, be.to_device(vals), l, 1, k, 1, k).download((pp.n * k, 4))  # out[p*k + j]
+    if pp.n >= NTT_FROM_N and hasattr(be, "fr_ntt_map"):
+        out = be.fr_ntt_map(pp.ntt_tables("pack"), be.to_device(vals), l, 1, k, 1, k).download((pp.n * k, 4))  # out[p*k + j]
+    else:
+        m = _mont_matrix([row[:l] for row in pp.pack_matrix])  # [n, l]
+        out = be.fr_apply_matrix(m, be.to_device(vals), l, 1, k, 1, k).download((pp.n * k, 4))  # out[p*k + j]
     return [np.ascontiguousarray(out[p * k : (p + 1) * k]) for p in range(pp.n)]
 
 

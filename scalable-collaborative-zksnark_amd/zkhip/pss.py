@@ -88,6 +88,34 @@ class PackedSharingParams:
         assert len(shares) == self.n
         return self.secret2.fft(self.share.ifft(shares))[0 : 2 * self.l : 2]
 
+    def ntt_tables(self, kind: str) -> dict:
+        """
+        twiddles and scales of one map for zk_fr_ntt_map (Montgomery limbs): the transform form of the reference's
+        own FFT pipeline -- ifft on the input domain, resize, fft on the output domain (pss.rs:93-171).
+        kind: "pack" (l secrets -> 8l shares), "unpack" (8l -> l), "unpack2" (8l -> l, slots 0, 2, ..).
+        """
+        import numpy as np
+
+        from .field import fr_mont
+
+        cache = self.__dict__.setdefault("_ntt", {})
+        if kind in cache:
+            return cache[kind]
+        l = self.l
+        src, dst, n_in, take, step = {"pack": (self.secret, self.share, l, self.n, 1), "unpack": (self.share, self.secret, self.n, l, 1),
+                                      "unpack2": (self.share, self.secret2, self.n, l, 2)}[kind]
+        A, B = src.size, dst.size
+        winv = pow(src.omega, -1, R_MOD)
+        ratio = dst.offset * pow(src.offset, -1, R_MOD) % R_MOD
+        ainv = pow(A, -1, R_MOD)
+        lim = lambda xs: np.array([fr_mont(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
+        t = dict(A=A, B=B, n_in=n_in, take=take, step=step,
+                 winv=lim([pow(winv, i, R_MOD) for i in range(max(A // 2, 1))]),
+                 w=lim([pow(dst.omega, i, R_MOD) for i in range(max(B // 2, 1))]),
+                 scale=lim([ainv * pow(ratio, i, R_MOD) % R_MOD for i in range(min(A, B))]))
+        cache[kind] = t
+        return t
+
     # --- coefficient rows used by the distributed primitives ---
     def dmsm_coeffs(self, party: int) -> List[int]:
         """

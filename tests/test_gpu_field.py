@@ -174,3 +174,32 @@ def test_share_file_to_device_and_back(ctx, tmp_path):
     assert [po.fr_from_mont_limbs(r) for r in mont] == xs
     ser.fr_device_to_file(ctx, buf, n, str(tmp_path / "out"))
     assert (tmp_path / "out").read_bytes() == p.read_bytes()
+
+
+@pytest.mark.parametrize("l", [1, 2, 8, 16])
+def test_pss_maps_by_transforms(ctx, l):
+    """zk_fr_ntt_map (ifft -> resize -> fft, pss.rs:93-171) against the oracle's maps and the dense-matrix kernel"""
+    import pyoracle as po
+    from zkhip.dist_primitive import _mont_matrix
+    from zkhip.pss import PackedSharingParams
+
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    rng = po.SplitMix64(600 + l)
+    k = 37
+    to_m = lambda xs: np.array([po.fr_to_mont_limbs(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
+    ints = lambda a: [po.fr_from_mont_limbs(r) for r in np.asarray(a).reshape(-1, 4)]
+    # pack: k chunks of l secrets -> out[p*k + j]
+    sec = rng.fr_vec(k * l)
+    out = ints(ctx.fr_ntt_map(pp.ntt_tables("pack"), ctx.to_device(to_m(sec)), l, 1, k, 1, k).download((pp.n * k, 4)))
+    for j in (0, 1, k - 1):
+        assert [out[p * k + j] for p in range(pp.n)] == opp.pack_from_public(sec[j * l : (j + 1) * l])
+    dense = ints(ctx.fr_apply_matrix(_mont_matrix([row[:l] for row in pp.pack_matrix]), ctx.to_device(to_m(sec)), l, 1, k, 1, k).download((pp.n * k, 4)))
+    assert out == dense
+    # unpack / unpack2: shares laid out party-major [n][k] (what an all-gather delivers) -> out[j*l + r]
+    sh = rng.fr_vec(pp.n * k)
+    d_sh = ctx.to_device(to_m(sh))
+    for kind, fn, mat in (("unpack", opp.unpack, pp.unpack_matrix), ("unpack2", opp.unpack2, pp.unpack2_matrix)):
+        out = ints(ctx.fr_ntt_map(pp.ntt_tables(kind), d_sh, 1, k, k, l, 1).download((k * l, 4)))
+        for j in (0, 5, k - 1):
+            assert out[j * l : (j + 1) * l] == fn([sh[i * k + j] for i in range(pp.n)]), (kind, j)
+        assert out == ints(ctx.fr_apply_matrix(_mont_matrix(mat), d_sh, 1, k, k, l, 1).download((k * l, 4)))
