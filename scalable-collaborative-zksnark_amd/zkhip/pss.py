@@ -29,27 +29,37 @@ class _Domain:
         v = list(v[: self.size])
         return v + [0] * (self.size - len(v))
 
+    def _pows(self):
+        if not hasattr(self, "_w"):
+            w, winv = [1], [1]
+            wi = pow(self.omega, -1, R_MOD)
+            for _ in range(self.size - 1):
+                w.append(w[-1] * self.omega % R_MOD)
+                winv.append(winv[-1] * wi % R_MOD)
+            self._w, self._winv = w, winv
+        return self._w, self._winv
+
     def fft(self, coeffs: Sequence[int]) -> List[int]:
+        """evaluate sum_k c_k x^k at x_j = offset * omega^j (dense DFT: the sizes are tiny)"""
         c = self._resize(coeffs)
-        out = []
-        for j in range(self.size):
-            x = self.offset * pow(self.omega, j, R_MOD) % R_MOD
-            acc, xp = 0, 1
-            for k in range(self.size):
-                acc = (acc + c[k] * xp) % R_MOD
-                xp = xp * x % R_MOD
-            out.append(acc)
-        return out
+        w, _ = self._pows()
+        n = self.size
+        cs, op = [], 1
+        for k in range(n):  # fold the coset offset into the coefficients
+            cs.append(c[k] * op % R_MOD)
+            op = op * self.offset % R_MOD
+        return [sum(cs[k] * w[(j * k) % n] for k in range(n) if cs[k]) % R_MOD for j in range(n)]
 
     def ifft(self, evals: Sequence[int]) -> List[int]:
         e = self._resize(evals)
-        ninv, oinv, winv = pow(self.size, -1, R_MOD), pow(self.offset, -1, R_MOD), pow(self.omega, -1, R_MOD)
-        out = []
-        for k in range(self.size):
-            acc = 0
-            for j in range(self.size):
-                acc = (acc + e[j] * pow(winv, j * k, R_MOD)) % R_MOD
-            out.append(acc * ninv % R_MOD * pow(oinv, k, R_MOD) % R_MOD)
+        _, winv = self._pows()
+        n = self.size
+        ninv, oinv = pow(n, -1, R_MOD), pow(self.offset, -1, R_MOD)
+        out, op = [], ninv
+        for k in range(n):
+            acc = sum(e[j] * winv[(j * k) % n] for j in range(n) if e[j]) % R_MOD
+            out.append(acc * op % R_MOD)
+            op = op * oinv % R_MOD
         return out
 
 
