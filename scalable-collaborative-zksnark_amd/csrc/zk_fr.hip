@@ -13,7 +13,6 @@
 // {j + s*m/2^K} can run K rounds in registers: one HBM sweep per K rounds instead of per round.
 // All sums are exact modular sums, so any association order is bit-identical to the reference.
 #include "fp.cuh"
-#include "fr29.cuh"
 #include "zk_ctx.hpp"
 
 #include <algorithm>
@@ -136,84 +135,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
         if (TWO) fr_store(go, j, eg[0]);
     }
     if (W != 0) block_reduce_store<NS>(acc, lds, partials, blockIdx.x, gridDim.x);
-}
-
-// ---------------------------------------------------------------------------------------
-// The product-sumcheck pass on the UNSATURATED field (fr29.cuh): same data flow as k_pass<K, 1>, the five
-// multiplications per pair run as carry-free v_mad_u64_u32 chains (~1.4x the saturated multiplier at the two
-// waves per SIMD this register-heavy kernel gets).  Conventions of this kernel:
-//   * ch.c[rd] holds 32 * challenge (host-prepared): the fold lo + r (hi - lo) is then exact;
-//   * the three product sums of every round leave with the common factor 2^-5 (the host removes it);
-//   * static bounds (multiples of r) are written next to every line; accumulators are carry-normalised once per
-//     iteration and reduced once per thread (iters = grid-stride iterations, capped by the launch at 32).
-// ---------------------------------------------------------------------------------------
-template <int RD>
-__device__ __forceinline__ Fr29 f29_diff(const Fr29& hi, const Fr29& lo) {  // hi - lo + k r, k >= bound(lo): 1 | 2.1 | 3.2
-    return RD == 0 ? f29_sub2(hi, lo) : f29_sub4(hi, lo);
-}
-template <int K>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2))) k_pass29(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo, void* __restrict__ go,
-                                                                                             size_t m, ChalArgs ch, void* __restrict__ partials, int iters) {
-    constexpr int E = 1 << K, NS = 3 * K;
-    extern __shared__ uint4 lds[];
-    const size_t q = m >> K;
-    Fr29 c[K];
-#pragma unroll
-    for (int rd = 0; rd < K; rd++) c[rd] = f29_from_fr(ch.c[rd]);  // canonical
-    Fr29 acc[NS];
-#pragma unroll
-    for (int s = 0; s < NS; s++) acc[s] = f29_zero();
-    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += (size_t)gridDim.x * kBlock) {
-        Fr29 ef[E], eg[E];
-#pragma unroll
-        for (int s = 0; s < E; s++) {
-            ef[s] = f29_from_fr(fr_load(f, j + (size_t)s * q));  // < r
-            eg[s] = f29_from_fr(fr_load(g, j + (size_t)s * q));
-        }
-#pragma unroll
-        for (int rd = 0; rd < K; rd++) {  // table values entering round rd: < 1 | 2.1 | 3.2 r
-            const int half = E >> (rd + 1);
-#pragma unroll
-            for (int s = 0; s < E / 2; s++) {
-                if (s < half) {
-                    Fr29 &flo = ef[s], &glo = eg[s];
-                    const Fr29 &fhi = ef[s + half], &ghi = eg[s + half];
-                    const Fr29 df = rd == 0 ? f29_diff<0>(fhi, flo) : f29_diff<1>(fhi, flo);  // < 3 | 6.1 | 7.2 r
-                    const Fr29 dg = rd == 0 ? f29_diff<0>(ghi, glo) : f29_diff<1>(ghi, glo);
-                    const Fr29 p0 = f29_mul(flo, glo);                                   // < 1.2 r  (x 2^-5)
-                    const Fr29 p1 = f29_mul(fhi, ghi);
-                    const Fr29 p2 = f29_mul(f29_add(fhi, df), f29_add(ghi, dg));           // (2 f_hi - f_lo)(2 g_hi - g_lo): < 10.4^2 / 70.66 + 1 = 2.6 r
-#pragma unroll
-                    for (int i = 0; i < 9; i++) {  // limb-wise, normalised once per iteration below (<= 4 addends of < 2^29 per limb)
-                        acc[3 * rd].l[i] += p0.l[i];
-                        acc[3 * rd + 1].l[i] += p1.l[i];
-                        acc[3 * rd + 2].l[i] += p2.l[i];
-                    }
-                    flo = f29_add(flo, f29_mul(c[rd], df));  // lo + r (hi - lo): < b + 1.1 r
-                    glo = f29_add(glo, f29_mul(c[rd], dg));
-                }
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < NS; s++) f29_norm(acc[s]);  // grows by < 4 * 2.6 r per iteration: < 340 r after 32 (565 r fit)
-        // tables leave canonical (< 3.2 r after two rounds, < 4.3 r after three)
-        fr_store(fo, j, f29_to_fr(K == 3 ? f29_canon4(f29_csub_4r(ef[0])) : f29_canon4(ef[0])));
-        fr_store(go, j, f29_to_fr(K == 3 ? f29_canon4(f29_csub_4r(eg[0])) : f29_canon4(eg[0])));
-    }
-    Fr accs[NS];
-    Fr29 one261;  // 2^261 mod r: f29_mul(x, 2^261) = x (mod r), < x / 70.66 + 1
-    {
-        constexpr u32 t[9] = {ZK_R29_2P261};
-#pragma unroll
-        for (int i = 0; i < 9; i++) one261.l[i] = t[i];
-    }
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-        Fr29 v = acc[s];
-        if (iters > 1) v = f29_mul(v, one261);  // < 340 r -> < 5.9 r
-        accs[s] = f29_to_fr(f29_canon16(v));    // one iteration: < 4 * 2.6 = 10.4 r
-    }
-    block_reduce_store<NS>(accs, lds, partials, blockIdx.x, gridDim.x);
 }
 
 // the per-block partial sums of ALL passes of one call, reduced in a single launch after the last
@@ -413,55 +334,10 @@ static unsigned sc_local_g() {
     static const unsigned v = getenv("ZK_SC_LOCAL_G") ? (unsigned)atoi(getenv("ZK_SC_LOCAL_G")) : 256u;
     return v;
 }
-static bool sc_use29() {
-    static const bool v = !(getenv("ZK_SC_FR29") && atoi(getenv("ZK_SC_FR29")) == 0);
-    return v;
-}
 static int sc_pass_k(int mode) {
     static const int kp = getenv("ZK_SC_KP") ? atoi(getenv("ZK_SC_KP")) : 2;  // product passes
     static const int k0 = getenv("ZK_SC_K0") ? atoi(getenv("ZK_SC_K0")) : 3;  // single-table passes
     return mode == 1 ? kp : k0;
-}
-
-// ---- host helpers on Montgomery-form Fr (4 x u64): doubling mod r (the Montgomery map is linear) ----
-static void fr_host_dbl(uint64_t a[4]) {
-    static const uint64_t RM[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
-    uint64_t d[4], c = 0;
-    for (int i = 0; i < 4; i++) {  // r < 2^255: no carry out of the top limb
-        const uint64_t hi = a[i] >> 63;
-        d[i] = (a[i] << 1) | c;
-        c = hi;
-    }
-    uint64_t s[4];
-    unsigned __int128 bw = 0;
-    for (int i = 0; i < 4; i++) {
-        unsigned __int128 t = (unsigned __int128)d[i] - RM[i] - (uint64_t)bw;
-        s[i] = (uint64_t)t;
-        bw = (t >> 64) & 1;
-    }
-    for (int i = 0; i < 4; i++) a[i] = bw ? d[i] : s[i];
-}
-static void fr_host_mul32(uint64_t a[4]) {
-    for (int k = 0; k < 5; k++) fr_host_dbl(a);
-}
-
-template <int K>
-static int launch_pass29(zk_ctx* ctx, const void* f, const void* g, void* fo, void* go, size_t m, size_t blocks, const uint64_t* chal, void* partials) {
-    ChalArgs ch;
-    std::memset(&ch, 0, sizeof(ch));
-    for (int rd = 0; rd < K; rd++) {
-        uint64_t c[4];
-        std::memcpy(c, chal + 4 * rd, 32);
-        fr_host_mul32(c);  // r' = 32 r: the unsaturated product carries 2^-5 (fr29.cuh)
-        std::memcpy(&ch.c[rd], c, 32);
-    }
-    const size_t q = m >> K;
-    const int iters = (int)((q + blocks * kBlock - 1) / (blocks * kBlock));
-    const size_t lds = (size_t)3 * K * kBlock * 32;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_pass29<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((k_pass29<K>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials, iters);
-    ZK_HIP(ctx, hipGetLastError());
-    return ZK_OK;
 }
 
 template <int MODE>
@@ -555,7 +431,6 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     const void* cg = d_g;
     size_t m = len, done = 0;
     int flip = 0;
-    std::vector<char> scaled(rounds + 1, 0);  // rounds whose sums carry the factor 2^-5 of the unsaturated pass
     ReducePlan rp;
     std::memset(&rp, 0, sizeof(rp));
     for (const Stage& st : plan) {
@@ -566,11 +441,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
         void* part = d_part ? d_part + st.part_off : nullptr;
         int rc;
-        const bool unsat = MODE == 1 && st.kind == 0 && k >= 2 && sc_use29();
-        if (unsat) {
-            for (int rd = 0; rd < k; rd++) scaled[done + rd] = 1;
-            rc = k == 3 ? launch_pass29<3>(ctx, cf, cg, fo, go, m, st.blocks, h_chal + 4 * done, part) : launch_pass29<2>(ctx, cf, cg, fo, go, m, st.blocks, h_chal + 4 * done, part);
-        } else if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, k, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr);
+        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, k, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr);
         else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
         else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
         else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
@@ -606,12 +477,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         if (!h) return ZK_ERR_OOM;
         ZK_HIP(ctx, hipMemcpyAsync(h, d_res, res_elems * fr, hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (h_sums && rounds * W) {
-            std::memcpy(h_sums, h, rounds * W * fr);
-            for (size_t rd = 0; rd < rounds; rd++)
-                if (scaled[rd])
-                    for (int w = 0; w < W; w++) fr_host_mul32(h_sums + (rd * W + w) * 4);
-        }
+        if (h_sums && rounds * W) std::memcpy(h_sums, h, rounds * W * fr);
         if (h_last_f) std::memcpy(h_last_f, h + rounds * W * fr, fr);
         if (TWO && h_last_g) std::memcpy(h_last_g, h + (rounds * W + 1) * fr, fr);
     }
