@@ -57,3 +57,20 @@ def test_status_codes_and_version():
     assert lib.zk_msm_window(1 << 20) == 17  # 129-bit scalar halves: 8 windows of 16-17 bits
     h = ctypes.c_void_p()
     assert lib.zk_ctx_create(0, None) == zkhip._lib.ZK_ERR_INVALID
+
+
+def test_rust_sys_is_in_sync():
+    """rust/zkhip_sys.rs is generated from the header: regenerating must reproduce the committed file"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "tools", "gen_rust_sys.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    committed = open(os.path.join(ROOT, "rust", "zkhip_sys.rs")).read()
+    assert mod.generate() == committed, "run: python tools/gen_rust_sys.py > rust/zkhip_sys.rs"
+    declared = _header_symbols()
+    for name in declared:
+        assert f"pub fn {name}(" in committed, name
+    patched = open(os.path.join(ROOT, "rust", "dmsm_patched.rs")).read()
+    for used in re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", patched):
+        assert used in declared, f"rust/dmsm_patched.rs calls {used}, which the header does not declare"
