@@ -15,7 +15,7 @@ use ark_bls12_381::{Fr, G1Projective};
 use ark_ff::{BigInteger, PrimeField};
 use secret_sharing::pss::PackedSharingParams;
 
-/// one GPU = one party: owns the zk_ctx (stream, scratch, RCCL communicator)
+/// one GPU = one party: owns the context handle (stream, scratch, RCCL communicator)
 pub struct ZkParty {
     pub ctx: *mut ZkCtx,
     pub party_id: usize,
