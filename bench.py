@@ -54,10 +54,13 @@ def pmc_traffic(kernel: str):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))
     if not files:
         return None, None
-    tot = 0.0
+    best = {}  # counter -> (dispatches, KB): the launch geometry with the most dispatches is the headline loop's
     for row in csv.reader(open(files[-1])):
-        if len(row) == 4 and row[1] == kernel:
-            tot += float(row[3]) * 1024.0 * (2.0 if row[0] == "FETCH_SIZE" else 1.0)
+        if len(row) >= 4 and row[1] == kernel and row[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+            disp, kb = int(row[-2]), float(row[-1])
+            if row[0] not in best or disp > best[row[0]][0]:
+                best[row[0]] = (disp, kb)
+    tot = sum(kb * 1024.0 * (2.0 if c == "FETCH_SIZE" else 1.0) for c, (_, kb) in best.items())
     return (tot or None), os.path.relpath(files[-1], ROOT)
 
 
@@ -96,6 +99,7 @@ def main():
     ap.add_argument("--cpu-e2e-n", type=int, default=13, help="log2 constraints of the CPU end-to-end sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline + roofline only (profiling runs)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (counter-collection runs)")
     ap.add_argument("--big", type=int, default=24, help="log2 size of the large strong-scaling / sumcheck legs")
     args = ap.parse_args()
 
@@ -224,7 +228,7 @@ def main():
         ctx.trim()
 
         # ---- end to end: collaborative HyperPlonk l = 1, n = 20 (BASELINE configs[3]) ----
-        if world in (1, 8):
+        if world in (1, 8) and not args.no_e2e:
             try:
                 from zkhip.hyperplonk import PackedProvingParameters, dhyperplonk
                 from zkhip.net import LeaderEchoNet

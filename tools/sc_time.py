@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd"))
 import numpy as np, zkhip
 from zkhip.field import random_fr
 ctx = zkhip.Ctx(0)
+only = os.environ.get("SC_MODE")  # one of product / plain / fold / open: counter-collection runs (tools/sc_pmc.sh)
 sizes = [int(x) for x in sys.argv[1:]] or [12, 16, 20, 22, 24]
 for lg in sizes:
     n = 1 << lg
@@ -13,8 +14,10 @@ for lg in sizes:
     out, q = ctx.alloc(32), ctx.alloc(32 * n)
     for name, fn, byt in (("product", lambda: ctx.sumcheck_product(f, g, n, ch), 64), ("plain", lambda: ctx.sumcheck(f, n, ch), 32),
                           ("fold", lambda: (ctx.fold(f, n, ch, out=out), ctx.sync()), 32), ("open", lambda: ctx.open_rounds(f, n, ch, q_out=q), 64)):
+        if only and name != only: continue
         for _ in range(3): fn()
         R = 20 if lg <= 22 else 5
+        if only: print(f"calls {name} {3 + R}")
         t0 = time.perf_counter()
         for _ in range(R): fn()
         dt = (time.perf_counter() - t0) / R
