@@ -185,6 +185,15 @@ int zk_msm_g1(zk_ctx *ctx, const zk_srs *srs, size_t offset, const void *d_scala
  * offsets may be NULL (all zero).  h_out: count x 18 u64. */
 int zk_msm_g1_batch(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets,
                     const void *const *d_scalars, const size_t *n, uint64_t *h_out);
+/* ---- G2: `d_msm` / `G::msm` are generic over CurveGroup (dmsm.rs:9,23); the reference's parameters carry G2 points
+ * in powers_of_g2 (dpoly_comm.rs:27,59-62).  Same pipeline, coordinates in Fq2 = Fq[u]/(u^2 + 1).
+ * Layouts (ark-bls12-381): G2Affine = { x: Fq2{c0, c1}, y: Fq2, infinity } -> 192-byte records x.c0|x.c1|y.c0|y.c1,
+ * stride 192 or the Rust struct's stride (flag byte at offset 192); results G2Projective = 3 x Fq2 = 36 u64, normalised.
+ * zk_srs_download on a G2 vector writes 192-byte records; zk_srs_len / zk_srs_free apply unchanged. */
+int zk_srs_register_g2(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n, zk_srs **out);
+int zk_msm_g2(zk_ctx *ctx, const zk_srs *srs, size_t offset, const void *d_scalars, size_t n, uint64_t h_out[36]);
+int zk_msm_g2_batch(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets,
+                    const void *const *d_scalars, const size_t *n, uint64_t *h_out);
 /* Drop-in for `G::msm(&[Affine], &[Fr]) -> Result<G, usize>` on host slices (dmsm.rs:23):
  * returns ZK_ERR_LENGTH when n_bases != n_scalars and stores min(n_bases, n_scalars) in *h_err_len. */
 int zk_msm_g1_host(zk_ctx *ctx, const void *h_bases, size_t stride, size_t n_bases,
@@ -258,6 +267,10 @@ int zk_dbg_fq_mul2add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out
 /* device XYZZ formulas on pairs of packed affine points; h_out[i] = 18 u64 normalised Jacobian.
  * mode 0: p+q (mixed add)  1: (p+q)+p (full add)  2: (p+q)+(p+q) (doubling path)  3: p-q */
 int zk_dbg_g1_op(zk_ctx *ctx, int mode, const void *d_p96, const void *d_q96, void *h_out, size_t n);
+
+/* the G2 formulas on pairs of affine points (192 B, reference form); h_out[i] = 36 u64 normalised Jacobian.
+ * mode 0: p+q  1: (p+q)+p  2: (p+q)+(p+q) (full-addition doubling path)  3: p-q  4: 2(p+q) (doubling)  5: (p+q)-(p+q) */
+int zk_dbg_g2_op(zk_ctx *ctx, int mode, const void *d_p192, const void *d_q192, void *h_out, size_t n);
 
 #ifdef __cplusplus
 }

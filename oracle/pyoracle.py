@@ -900,3 +900,100 @@ def srs_to_packed(levels: Sequence[Sequence[Point]], pp: "PackedSharingParams") 
         for j in range(pp.n):
             out[j][i] = [c[j] for c in chunks]
     return out
+
+
+# --------------------------------------------------------------------------
+# G2: the twist y^2 = x^3 + 4 (1 + u) over Fq2 = Fq[u] / (u^2 + 1)   (ark-bls12-381 g2::Config).
+# `d_msm` is generic over CurveGroup (dmsm.rs:9); powers_of_g2 holds G2 points (dpoly_comm.rs:27,59-62).
+# Points are ((x0, x1), (y0, y1)) tuples of python ints or None; affine formulas with a field inversion.
+# --------------------------------------------------------------------------
+Fq2 = Tuple[int, int]
+Point2 = Optional[Tuple[Fq2, Fq2]]
+
+
+def fq2_add(a, b):
+    return ((a[0] + b[0]) % Q_MOD, (a[1] + b[1]) % Q_MOD)
+
+
+def fq2_sub(a, b):
+    return ((a[0] - b[0]) % Q_MOD, (a[1] - b[1]) % Q_MOD)
+
+
+def fq2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % Q_MOD, (a[0] * b[1] + a[1] * b[0]) % Q_MOD)
+
+
+def fq2_inv(a):
+    n = pow(a[0] * a[0] + a[1] * a[1], -1, Q_MOD)
+    return (a[0] * n % Q_MOD, -a[1] * n % Q_MOD)
+
+
+G2_B = (4, 4)
+# the standard generator (ark-bls12-381 G2_GENERATOR_X / _Y); on-curve and r * G2 = O are re-checked in
+# tests/test_oracle_anchors.py
+G2_GEN = (
+    (0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+     0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+    (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+     0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE),
+)
+
+
+def g2_is_on_curve(P: Point2) -> bool:
+    if P is None:
+        return True
+    x, y = P
+    return fq2_mul(y, y) == fq2_add(fq2_mul(fq2_mul(x, x), x), G2_B)
+
+
+def g2_neg(P: Point2) -> Point2:
+    return None if P is None else (P[0], ((-P[1][0]) % Q_MOD, (-P[1][1]) % Q_MOD))
+
+
+def g2_add(P: Point2, Q: Point2) -> Point2:
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    (x1, y1), (x2, y2) = P, Q
+    if x1 == x2:
+        if y1 != y2 or y1 == (0, 0):
+            return None
+        lam = fq2_mul(fq2_mul((3, 0), fq2_mul(x1, x1)), fq2_inv(fq2_add(y1, y1)))
+    else:
+        lam = fq2_mul(fq2_sub(y2, y1), fq2_inv(fq2_sub(x2, x1)))
+    x3 = fq2_sub(fq2_sub(fq2_mul(lam, lam), x1), x2)
+    return (x3, fq2_sub(fq2_mul(lam, fq2_sub(x1, x3)), y1))
+
+
+def g2_mul(P: Point2, k: int) -> Point2:
+    k %= R_MOD
+    acc = None
+    for bit in bin(k)[2:] if k else "":
+        acc = g2_add(acc, acc)
+        if bit == "1":
+            acc = g2_add(acc, P)
+    return acc
+
+
+def g2_msm(bases: Sequence[Point2], scalars: Sequence[int]) -> Point2:
+    """sum_i scalars[i] * bases[i] -- plain double-and-add per term (checker for small inputs)"""
+    acc = None
+    for P, s in zip(bases, scalars):
+        acc = g2_add(acc, g2_mul(P, s))
+    return acc
+
+
+def g2_to_mont_limbs(P: Point2) -> List[int]:
+    """192-byte affine record x.c0 | x.c1 | y.c0 | y.c1 as 24 u64 Montgomery limbs (zeros = infinity)"""
+    if P is None:
+        return [0] * 24
+    return fq_to_mont_limbs(P[0][0]) + fq_to_mont_limbs(P[0][1]) + fq_to_mont_limbs(P[1][0]) + fq_to_mont_limbs(P[1][1])
+
+
+def g2_from_mont_limbs(a) -> Point2:
+    a = [int(v) for v in a]
+    if not any(a[:24]):
+        return None
+    c = [fq_from_mont_limbs(a[6 * i : 6 * i + 6]) for i in range(4)]
+    return ((c[0], c[1]), (c[2], c[3]))

@@ -44,6 +44,10 @@ struct Q30 {
         constexpr u32 t[13] = {0x7ffd5558u, 0x7fdffffeu, 0x69ffffdbu, 0x57fffd61u, 0x47b120f4u, 0x5a541ed5u, 0x495fb397u, 0x5709e709u, 0x66bb23b9u, 0x76c86974u, 0x4d258dd2u, 0x5472ffccu, 0x00d0088eu};
         return t[i];
     }
+    __host__ __device__ static constexpr u32 KQ12(int i) {
+        constexpr u32 t[13] = {0x7ffc0004u, 0x5fcffffeu, 0x7effffcau, 0x43fffc12u, 0x4b89b16fu, 0x677e2e40u, 0x4e0f8d63u, 0x628eda8eu, 0x5a18b596u, 0x722c9e2fu, 0x73b854bcu, 0x7eac7fb2u, 0x01380cd5u};
+        return t[i];
+    }
     __host__ __device__ static constexpr u32 Q(int i) {
         constexpr u32 t[13] = {0x3fffaaabu, 0x27fbffffu, 0x153ffffbu, 0x2affffacu, 0x30f6241eu, 0x034a83dau, 0x112bf673u, 0x12e13ce1u, 0x2cd76477u, 0x1ed90d2eu, 0x29a4b1bau, 0x3a8e5ff9u, 0x001a0111u};
         return t[i];
@@ -125,6 +129,7 @@ ZK_F30_SUB(f30_sub2, KQ2)  // a + 2q - b,  b < 2q
 ZK_F30_SUB(f30_sub4, KQ4)  // a + 4q - b,  b < 4q
 ZK_F30_SUB(f30_sub6, KQ6)  // a + 6q - b,  b < 6q
 ZK_F30_SUB(f30_sub8, KQ8)  // a + 8q - b,  b < 8q
+ZK_F30_SUB(f30_sub12, KQ12)  // a + 12q - b, b < 12q  (the Fq2 formulas of curve30_g2.cuh)
 // Montgomery product a*b*2^-390 (mod q) for normalised inputs whose bounds multiply to <= 256 q^2;
 // the result is normalised and < 2q.  Product scanning; a column holds at most 15 limb products
 // (15 * (2^30-1)^2 + carry < 2^64) before its high part is folded into the next column.

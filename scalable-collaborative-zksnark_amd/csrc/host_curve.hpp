@@ -136,101 +136,168 @@ static inline Fq inv(const Fq& a) {  // a^(q-2)
     return acc;
 }
 
-struct Aff {
-    Fq x, y;  // x = y = 0: infinity
+// ---- Fq2 = Fq[u] / (u^2 + 1): the coordinate field of G2 ----
+struct Fq2 {
+    Fq c0, c1;
 };
-struct Jac {
-    Fq x, y, z;  // z = 0: infinity
+static inline bool operator==(const Fq2& a, const Fq2& b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+static inline bool is_zero(const Fq2& a) { return is_zero(a.c0) && is_zero(a.c1); }
+static inline Fq2 add(const Fq2& a, const Fq2& b) { return Fq2{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+static inline Fq2 sub(const Fq2& a, const Fq2& b) { return Fq2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+static inline Fq2 neg(const Fq2& a) { return Fq2{neg(a.c0), neg(a.c1)}; }
+static inline Fq2 dbl(const Fq2& a) { return add(a, a); }
+static inline Fq2 mul(const Fq2& a, const Fq2& b) {  // Karatsuba: 3 multiplications
+    const Fq t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1);
+    const Fq t2 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    return Fq2{sub(t0, t1), sub(sub(t2, t0), t1)};
+}
+static inline Fq2 sqr(const Fq2& a) { return Fq2{mul(add(a.c0, a.c1), sub(a.c0, a.c1)), dbl(mul(a.c0, a.c1))}; }
+static inline Fq2 inv(const Fq2& a) {  // conj(a) / (a0^2 + a1^2)
+    const Fq n = inv(add(sqr(a.c0), sqr(a.c1)));
+    return Fq2{mul(a.c0, n), neg(mul(a.c1, n))};
+}
+template <class F>
+struct FieldConst;
+template <>
+struct FieldConst<Fq> {
+    static Fq one() { return ONE; }
+    static Fq zero() { return ZERO; }
 };
-static inline Jac jac_inf() { return Jac{ONE, ONE, ZERO}; }
-static inline bool aff_inf(const Aff& p) { return is_zero(p.x) && is_zero(p.y); }
+template <>
+struct FieldConst<Fq2> {
+    static Fq2 one() { return Fq2{ONE, ZERO}; }
+    static Fq2 zero() { return Fq2{ZERO, ZERO}; }
+};
 
-static inline Jac jac_dbl(const Jac& p) {  // dbl-2009-l
+// ---- short Weierstrass curves with a = 0 over F (G1: F = Fq, G2: F = Fq2) ----
+template <class F>
+struct AffT {
+    F x, y;  // x = y = 0: infinity
+};
+template <class F>
+struct JacT {
+    F x, y, z;  // z = 0: infinity
+};
+typedef AffT<Fq> Aff;
+typedef JacT<Fq> Jac;
+typedef AffT<Fq2> Aff2;
+typedef JacT<Fq2> Jac2;
+template <class F>
+static inline JacT<F> jac_inf_t() {
+    return JacT<F>{FieldConst<F>::one(), FieldConst<F>::one(), FieldConst<F>::zero()};
+}
+static inline Jac jac_inf() { return jac_inf_t<Fq>(); }
+template <class F>
+static inline bool aff_inf(const AffT<F>& p) {
+    return is_zero(p.x) && is_zero(p.y);
+}
+
+template <class F>
+static inline JacT<F> jac_dbl(const JacT<F>& p) {  // dbl-2009-l
     if (is_zero(p.z)) return p;
-    Fq A = sqr(p.x), B = sqr(p.y), C = sqr(B);
-    Fq t = add(p.x, B);
-    Fq D = dbl(sub(sub(sqr(t), A), C));
-    Fq E = add(dbl(A), A);
-    Fq F = sqr(E);
-    Jac r;
-    r.x = sub(F, dbl(D));
+    F A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+    F t = add(p.x, B);
+    F D = dbl(sub(sub(sqr(t), A), C));
+    F E = add(dbl(A), A);
+    F Fv = sqr(E);
+    JacT<F> r;
+    r.x = sub(Fv, dbl(D));
     r.z = dbl(mul(p.y, p.z));
-    Fq C8 = dbl(dbl(dbl(C)));
+    F C8 = dbl(dbl(dbl(C)));
     r.y = sub(mul(E, sub(D, r.x)), C8);
     return r;
 }
-static inline Jac jac_add(const Jac& p, const Jac& q) {  // add-2007-bl
+template <class F>
+static inline JacT<F> jac_add(const JacT<F>& p, const JacT<F>& q) {  // add-2007-bl
     if (is_zero(p.z)) return q;
     if (is_zero(q.z)) return p;
-    Fq Z1Z1 = sqr(p.z), Z2Z2 = sqr(q.z);
-    Fq U1 = mul(p.x, Z2Z2), U2 = mul(q.x, Z1Z1);
-    Fq S1 = mul(mul(p.y, q.z), Z2Z2), S2 = mul(mul(q.y, p.z), Z1Z1);
+    F Z1Z1 = sqr(p.z), Z2Z2 = sqr(q.z);
+    F U1 = mul(p.x, Z2Z2), U2 = mul(q.x, Z1Z1);
+    F S1 = mul(mul(p.y, q.z), Z2Z2), S2 = mul(mul(q.y, p.z), Z1Z1);
     if (U1 == U2) {
         if (S1 == S2) return jac_dbl(p);
-        return jac_inf();
+        return jac_inf_t<F>();
     }
-    Fq H = sub(U2, U1);
-    Fq I = sqr(dbl(H));
-    Fq J = mul(H, I);
-    Fq rr = dbl(sub(S2, S1));
-    Fq V = mul(U1, I);
-    Jac r;
+    F H = sub(U2, U1);
+    F I = sqr(dbl(H));
+    F J = mul(H, I);
+    F rr = dbl(sub(S2, S1));
+    F V = mul(U1, I);
+    JacT<F> r;
     r.x = sub(sub(sqr(rr), J), dbl(V));
     r.y = sub(mul(rr, sub(V, r.x)), dbl(mul(S1, J)));
     r.z = mul(sub(sub(sqr(add(p.z, q.z)), Z1Z1), Z2Z2), H);
     return r;
 }
-static inline Jac jac_add_mixed(const Jac& p, const Aff& q) {  // madd-2007-bl
+template <class F>
+static inline JacT<F> jac_add_mixed(const JacT<F>& p, const AffT<F>& q) {  // madd-2007-bl
     if (aff_inf(q)) return p;
-    if (is_zero(p.z)) return Jac{q.x, q.y, ONE};
-    Fq Z1Z1 = sqr(p.z);
-    Fq U2 = mul(q.x, Z1Z1);
-    Fq S2 = mul(mul(q.y, p.z), Z1Z1);
+    if (is_zero(p.z)) return JacT<F>{q.x, q.y, FieldConst<F>::one()};
+    F Z1Z1 = sqr(p.z);
+    F U2 = mul(q.x, Z1Z1);
+    F S2 = mul(mul(q.y, p.z), Z1Z1);
     if (U2 == p.x) {
         if (S2 == p.y) return jac_dbl(p);
-        return jac_inf();
+        return jac_inf_t<F>();
     }
-    Fq H = sub(U2, p.x);
-    Fq HH = sqr(H);
-    Fq I = dbl(dbl(HH));
-    Fq J = mul(H, I);
-    Fq rr = dbl(sub(S2, p.y));
-    Fq V = mul(p.x, I);
-    Jac r;
+    F H = sub(U2, p.x);
+    F HH = sqr(H);
+    F I = dbl(dbl(HH));
+    F J = mul(H, I);
+    F rr = dbl(sub(S2, p.y));
+    F V = mul(p.x, I);
+    JacT<F> r;
     r.x = sub(sub(sqr(rr), J), dbl(V));
     r.y = sub(mul(rr, sub(V, r.x)), dbl(mul(p.y, J)));
     r.z = sub(sub(sqr(add(p.z, H)), Z1Z1), HH);
     return r;
 }
-// XYZZ (x = X/ZZ, y = Y/ZZZ) -> Jacobian with Z = ZZZ/ZZ would need an inversion; instead use
-// the valid Jacobian representative (X*ZZ^2... ) : (X', Y', Z') = (X*ZZ, Y*ZZZ... ) derived from
-// x = X/ZZ = (X*ZZ)/ZZ^2, y = Y/ZZZ = (Y*ZZZ)/ZZZ^2 and ZZZ^2 = ZZ^3 => Z' = ZZ: x = X'/Z'^2, y = Y'/Z'^3.
+// XYZZ (x = X/ZZ, y = Y/ZZZ) -> the Jacobian representative (X*ZZ, Y*ZZZ, ZZ): x = X'/Z'^2, y = Y'/Z'^3
+// (ZZZ^2 = ZZ^3); no inversion needed.
 static inline Jac xyzz_to_jac(const Fq& X, const Fq& Y, const Fq& ZZ, const Fq& ZZZ) {
     if (is_zero(ZZ)) return jac_inf();
     return Jac{mul(X, ZZ), mul(Y, ZZZ), ZZ};
 }
-static inline Aff jac_to_aff(const Jac& p) {
-    if (is_zero(p.z)) return Aff{ZERO, ZERO};
-    Fq zi = inv(p.z);
-    Fq zi2 = sqr(zi);
-    return Aff{mul(p.x, zi2), mul(p.y, mul(zi2, zi))};
+template <class F>
+static inline AffT<F> jac_to_aff(const JacT<F>& p) {
+    if (is_zero(p.z)) return AffT<F>{FieldConst<F>::zero(), FieldConst<F>::zero()};
+    F zi = inv(p.z);
+    F zi2 = sqr(zi);
+    return AffT<F>{mul(p.x, zi2), mul(p.y, mul(zi2, zi))};
 }
-// normalised Jacobian as 18 u64 (ark-ec Projective layout): (x, y, R) or (R, R, 0) for infinity
-static inline void write_normalised(const Jac& p, uint64_t out[18]) {
-    Aff a = jac_to_aff(p);
+static inline void put_fe(const Fq& v, uint64_t* out) { memcpy(out, v.data(), 48); }
+static inline void put_fe(const Fq2& v, uint64_t* out) {
+    memcpy(out, v.c0.data(), 48);
+    memcpy(out + 6, v.c1.data(), 48);
+}
+static inline void get_fe(Fq& v, const uint64_t* in) { memcpy(v.data(), in, 48); }
+static inline void get_fe(Fq2& v, const uint64_t* in) {
+    memcpy(v.c0.data(), in, 48);
+    memcpy(v.c1.data(), in + 6, 48);
+}
+template <class F>
+constexpr size_t fe_words() {
+    return sizeof(F) / 8;
+}
+// normalised Jacobian in ark-ec's Projective layout {x, y, z}: (x, y, 1) or (1, 1, 0) for infinity; 18 u64 (G1) / 36 (G2)
+template <class F>
+static inline void write_normalised(const JacT<F>& p, uint64_t* out) {
+    constexpr size_t w = fe_words<F>();
     if (is_zero(p.z)) {
-        memcpy(out, ONE.data(), 48);
-        memcpy(out + 6, ONE.data(), 48);
-        memset(out + 12, 0, 48);
+        put_fe(FieldConst<F>::one(), out);
+        put_fe(FieldConst<F>::one(), out + w);
+        put_fe(FieldConst<F>::zero(), out + 2 * w);
         return;
     }
-    memcpy(out, a.x.data(), 48);
-    memcpy(out + 6, a.y.data(), 48);
-    memcpy(out + 12, ONE.data(), 48);
+    AffT<F> a = jac_to_aff(p);
+    put_fe(a.x, out);
+    put_fe(a.y, out + w);
+    put_fe(FieldConst<F>::one(), out + 2 * w);
 }
 // k*P, k = 4 canonical u64 limbs
-static inline Jac scalar_mul(const Aff& P, const uint64_t k[4]) {
-    Jac acc = jac_inf();
+template <class F>
+static inline JacT<F> scalar_mul(const AffT<F>& P, const uint64_t k[4]) {
+    JacT<F> acc = jac_inf_t<F>();
     for (int i = 255; i >= 0; i--) {
         acc = jac_dbl(acc);
         if ((k[i / 64] >> (i % 64)) & 1) acc = jac_add_mixed(acc, P);
@@ -238,8 +305,9 @@ static inline Jac scalar_mul(const Aff& P, const uint64_t k[4]) {
     return acc;
 }
 // k*P for a Jacobian P
-static inline Jac scalar_mul_jac(const Jac& P, const uint64_t k[4]) {
-    Jac acc = jac_inf();
+template <class F>
+static inline JacT<F> scalar_mul_jac(const JacT<F>& P, const uint64_t k[4]) {
+    JacT<F> acc = jac_inf_t<F>();
     for (int i = 255; i >= 0; i--) {
         acc = jac_dbl(acc);
         if ((k[i / 64] >> (i % 64)) & 1) acc = jac_add(acc, P);
@@ -247,24 +315,25 @@ static inline Jac scalar_mul_jac(const Jac& P, const uint64_t k[4]) {
     return acc;
 }
 // batch normalisation (one inversion)
-static inline void batch_to_affine(const std::vector<Jac>& in, Aff* out) {
+template <class F>
+static inline void batch_to_affine(const std::vector<JacT<F>>& in, AffT<F>* out) {
     size_t n = in.size();
-    std::vector<Fq> pref(n);
-    Fq acc = ONE;
+    std::vector<F> pref(n);
+    F acc = FieldConst<F>::one();
     for (size_t i = 0; i < n; i++) {
         pref[i] = acc;
         if (!is_zero(in[i].z)) acc = mul(acc, in[i].z);
     }
-    Fq iv = inv(acc);
+    F iv = inv(acc);
     for (size_t i = n; i-- > 0;) {
         if (is_zero(in[i].z)) {
-            out[i] = Aff{ZERO, ZERO};
+            out[i] = AffT<F>{FieldConst<F>::zero(), FieldConst<F>::zero()};
             continue;
         }
-        Fq zi = mul(iv, pref[i]);
+        F zi = mul(iv, pref[i]);
         iv = mul(iv, in[i].z);
-        Fq zi2 = sqr(zi);
-        out[i] = Aff{mul(in[i].x, zi2), mul(in[i].y, mul(zi2, zi))};
+        F zi2 = sqr(zi);
+        out[i] = AffT<F>{mul(in[i].x, zi2), mul(in[i].y, mul(zi2, zi))};
     }
 }
 

@@ -371,6 +371,22 @@ int zk_msm_g1_batch(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const s
     for (size_t k = 0; k < count; k++) items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, d_scalars[k], n[k]};
     return msm_g1_batch(ctx, items.data(), count, h_out);
 }
+int zk_srs_register_g2(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out) {
+    NEED(ctx, out);
+    return srs_pack_g2(ctx, h_bases, stride, n, out);
+}
+int zk_msm_g2(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t h_out[36]) {
+    NEED(ctx, srs && h_out && (n == 0 || d_scalars));
+    MsmItem it{srs, offset, d_scalars, n};
+    return msm_g2_batch(ctx, &it, 1, h_out);
+}
+int zk_msm_g2_batch(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* offsets, const void* const* d_scalars,
+                    const size_t* n, uint64_t* h_out) {
+    NEED(ctx, count == 0 || (srs && d_scalars && n && h_out));
+    std::vector<MsmItem> items(count);
+    for (size_t k = 0; k < count; k++) items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, d_scalars[k], n[k]};
+    return msm_g2_batch(ctx, items.data(), count, h_out);
+}
 int zk_msm_g1_host(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n_bases, const uint64_t* h_scalars, size_t n_scalars,
                    uint64_t h_out[18], size_t* h_err_len) {
     NEED(ctx, h_out);
@@ -426,6 +442,11 @@ int zk_dbg_fq_mul(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n
 int zk_dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n) {
     NEED(ctx, n == 0 || (p && q && h_out));
     return dbg_g1_op(ctx, mode, p, q, h_out, n);
+}
+
+int zk_dbg_g2_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n) {
+    NEED(ctx, n == 0 || (p && q && h_out));
+    return dbg_g2_op(ctx, mode, p, q, h_out, n);
 }
 
 }  // extern "C"

@@ -13,6 +13,7 @@ struct zk_srs {
     void* d_bases = nullptr;  // packed 96-B affine points (x||y Montgomery, x=y=0: infinity)
     size_t n = 0;
     bool owned = true;
+    bool g2 = false;  // points of G2 (192-byte affine records over Fq2, no endomorphism copies)
     // optional precomputed table: copy w of point i = 2^{bit_offset(w)} * P_i at d_table[w * table_stride + i]
     void* d_table = nullptr;
     int table_c = 0;
@@ -93,6 +94,8 @@ struct MsmItem {
     size_t n;
 };
 int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out);
+int msm_g2_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out);  // h_out: 36 u64 per item
+int srs_pack_g2(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out);
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
 int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c);
@@ -106,6 +109,7 @@ int srs_to_packed(zk_ctx* ctx, const zk_srs* level, const uint64_t* h_row, size_
 int g1_apply_matrix_ref(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_t cols, const void* d_in, size_t isv, size_t isc, void* d_out,
                         size_t osv, size_t osr, size_t k);
 int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n);
+int dbg_g2_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n);
 int msm_pick_window(size_t n);
 int g1_lincomb_batch_host(zk_ctx* ctx, const uint64_t* h_points_jac, const uint64_t* h_scalars_canon, size_t n, size_t count,
                           uint64_t* h_out);

@@ -21,6 +21,7 @@
 // All additions are exact group operations, so the affine result is independent of the
 // (non-deterministic) order in which the sort places points inside a bucket.
 #include "curve30.cuh"
+#include "curve30_g2.cuh"
 #include "host_curve.hpp"
 #include "zk_ctx.hpp"
 
@@ -39,6 +40,68 @@ namespace zk {
 
 static constexpr int kBlk = 256;
 static constexpr u32 kSkip = 0xffffffffu;
+
+
+// ---------------------------------------------------------------------------------------
+// The pipeline is generic over the curve (`d_msm<G: CurveGroup>`, dmsm.rs:9): G1 over Fq (curve30.cuh) and G2
+// over Fq2 (curve30_g2.cuh).  A traits struct names the point types and operations; for G1 it forwards to the
+// functions the kernels always used (identical code), G2 instantiates the same kernels a second time.
+// ---------------------------------------------------------------------------------------
+struct CvG1 {
+    typedef Aff30 Aff;
+    typedef Xyzz30 Xyzz;
+    typedef zkhost::Fq HostF;
+    static constexpr size_t kAffBytes = 96, kXyzzBytes = 192, kJacBytes = 144;
+    static constexpr bool kEndo = true;  // scalars split with the endomorphism, SRS holds phi(P_i) after P_i
+    static constexpr bool kQuad = true;  // quad-lane fix-up / reduction kernels exist
+    __device__ static __forceinline__ Aff aff_load(const void* b, size_t i) { return aff30_load(b, i); }
+    __device__ static __forceinline__ Xyzz load(const void* b, size_t i) { return xyzz30_load(b, i); }
+    __device__ static __forceinline__ void store(void* b, size_t i, const Xyzz& p) { xyzz30_store(b, i, p); }
+    __device__ static __forceinline__ void set_inf(Xyzz& p) { xyzz30_set_inf(p); }
+    __device__ static __forceinline__ bool is_inf(const Xyzz& p) { return xyzz30_is_inf(p); }
+    __device__ static __forceinline__ void madd(Xyzz& acc, const Aff& p, bool neg) { xyzz30_madd(acc, p, neg); }
+    __device__ static __forceinline__ Xyzz add(const Xyzz& a, const Xyzz& b) { return xyzz30_add(a, b); }
+    __device__ static __forceinline__ Xyzz dbl(const Xyzz& a) { return xyzz30_dbl(a); }
+    // (X*ZZ, Y*ZZZ, ZZ) is a Jacobian representative; written in the REFERENCE Montgomery form
+    __device__ static __forceinline__ void finish(const Xyzz& acc, void* out, size_t t) {
+        Fq30 X = f30_zero(), Y = f30_zero(), Z = f30_zero();
+        if (!xyzz30_is_inf(acc)) {
+            X = f30_to_ref(f30_mul(acc.x, acc.zz));
+            Y = f30_to_ref(f30_mul(acc.y, acc.zzz));
+            Z = f30_to_ref(acc.zz);
+        }
+        f30_store(out, t * 144, X);
+        f30_store(out, t * 144 + 48, Y);
+        f30_store(out, t * 144 + 96, Z);
+    }
+};
+struct CvG2 {
+    typedef Aff2 Aff;
+    typedef Xyzz2 Xyzz;
+    typedef zkhost::Fq2 HostF;
+    static constexpr size_t kAffBytes = 192, kXyzzBytes = 384, kJacBytes = 288;
+    static constexpr bool kEndo = false;
+    static constexpr bool kQuad = false;
+    __device__ static __forceinline__ Aff aff_load(const void* b, size_t i) { return aff2_load(b, i); }
+    __device__ static __forceinline__ Xyzz load(const void* b, size_t i) { return xyzz2_load(b, i); }
+    __device__ static __forceinline__ void store(void* b, size_t i, const Xyzz& p) { xyzz2_store(b, i, p); }
+    __device__ static __forceinline__ void set_inf(Xyzz& p) { xyzz2_set_inf(p); }
+    __device__ static __forceinline__ bool is_inf(const Xyzz& p) { return xyzz2_is_inf(p); }
+    __device__ static __forceinline__ void madd(Xyzz& acc, const Aff& p, bool neg) { xyzz2_madd(acc, p, neg); }
+    __device__ static __forceinline__ Xyzz add(const Xyzz& a, const Xyzz& b) { return xyzz2_add(a, b); }
+    __device__ static __forceinline__ Xyzz dbl(const Xyzz& a) { return xyzz2_dbl(a); }
+    __device__ static __forceinline__ void finish(const Xyzz& acc, void* out, size_t t) {
+        Fq2x X = f2_zero(), Y = f2_zero(), Z = f2_zero();
+        if (!xyzz2_is_inf(acc)) {
+            X = f2_mul<2>(acc.x, acc.zz);
+            Y = f2_mul<2>(acc.y, acc.zzz);
+            Z = acc.zz;
+        }
+        const Fq30 c[6] = {X.c0, X.c1, Y.c0, Y.c1, Z.c0, Z.c1};
+#pragma unroll
+        for (int k = 0; k < 6; k++) f30_store(out, t * 288 + 48 * k, f30_to_ref(c[k]));
+    }
+};
 
 // The scalar is split with the curve endomorphism (see k_digits): k = k1 + k2*lambda, k1, k2 < 2^128,
 // and the MSM runs over the 2n points P_i, phi(P_i) with 128-bit scalars: half the windows, hence half
@@ -474,6 +537,7 @@ __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restric
 // sorted entries; runs that are whole buckets are stored directly, the (at most two) runs cut by
 // the tile boundary go to heads[] / tails[] and are stitched by k_fixup.
 // ---------------------------------------------------------------------------------------
+template <class Cv>
 __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict__ items, int rows_per_item,
                                                     const u32* __restrict__ sorted, const u32* __restrict__ offsets,
                                                     const u32* __restrict__ counts, size_t ns, u32 nsi, size_t nb, u32 T,
@@ -509,34 +573,34 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
     u32 bstart = off[b], bend = bstart + cnt[b];
     u32 ps = e0;  // start of the current run
     const u32* run = sorted + w * ns;
-    Xyzz30 acc;
-    xyzz30_set_inf(acc);
+    typename Cv::Xyzz acc;
+    Cv::set_inf(acc);
     u32 v = run[e0];
-    Aff30 p = aff30_load(bases, pidx(v));
+    typename Cv::Aff p = Cv::aff_load(bases, pidx(v));
     for (u32 e = e0; e < e1; e++) {
         if (e == bend) {  // run finished: flush and move to the next non-empty bucket
-            if (ps == bstart) xyzz30_store(buckets, w * nb + b, acc);  // whole bucket
-            else xyzz30_store(heads, g, acc);                            // started before this tile
+            if (ps == bstart) Cv::store(buckets, w * nb + b, acc);  // whole bucket
+            else Cv::store(heads, g, acc);                            // started before this tile
             do {
                 b++;
                 bstart = off[b];
                 bend = bstart + cnt[b];
             } while (bend == bstart);
             ps = e;
-            xyzz30_set_inf(acc);
+            Cv::set_inf(acc);
         }
         const bool neg = (v >> 31) != 0;
-        Aff30 cur = p;
+        typename Cv::Aff cur = p;
         if (e + 1 < e1) {  // prefetch the next point while this one is being added
             v = run[e + 1];
-            p = aff30_load(bases, pidx(v));
+            p = Cv::aff_load(bases, pidx(v));
         }
-        xyzz30_madd(acc, cur, neg);
+        Cv::madd(acc, cur, neg);
     }
     // last run of the tile
-    if (ps == bstart && e1 == bend) xyzz30_store(buckets, w * nb + b, acc);
-    else if (ps == e0) xyzz30_store(heads, g, acc);  // single run covering the tile from its start
-    else xyzz30_store(tails, g, acc);
+    if (ps == bstart && e1 == bend) Cv::store(buckets, w * nb + b, acc);
+    else if (ps == e0) Cv::store(heads, g, acc);  // single run covering the tile from its start
+    else Cv::store(tails, g, acc);
 }
 
 // which bucket rows belong to a window one bit narrower than the widest: row r of the launch is window
@@ -550,6 +614,7 @@ struct NarrowRows {
 // stitch the runs cut by tile boundaries; also writes infinity for empty buckets.  Buckets that
 // span more than kLongSpan tiles (skewed scalars: many equal digits) are queued for k_fixup_long.
 static constexpr u32 kLongSpan = 24;
+template <class Cv>
 __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, NarrowRows nr, u32 T,
                                               size_t tiles_per_w, size_t total, void* __restrict__ buckets,
                                               const void* __restrict__ heads, const void* __restrict__ tails,
@@ -560,9 +625,9 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets,
     if (nr.narrow(w) && (g % nb) >= nb / 2) return;  // never populated, never read by the reduction
     const u32 s = offsets[g], c = counts[g];
     if (c == 0) {
-        Xyzz30 z;
-        xyzz30_set_inf(z);
-        xyzz30_store(buckets, g, z);
+        typename Cv::Xyzz z;
+        Cv::set_inf(z);
+        Cv::store(buckets, g, z);
         return;
     }
     const u32 e = s + c;
@@ -573,9 +638,9 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets,
         return;
     }
     const size_t base = w * tiles_per_w;
-    Xyzz30 acc = (s == t0 * T) ? xyzz30_load(heads, base + t0) : xyzz30_load(tails, base + t0);
-    for (u32 t = t0 + 1; t <= t1; t++) acc = xyzz30_add(acc, xyzz30_load(heads, base + t));
-    xyzz30_store(buckets, g, acc);
+    typename Cv::Xyzz acc = (s == t0 * T) ? Cv::load(heads, base + t0) : Cv::load(tails, base + t0);
+    for (u32 t = t0 + 1; t <= t1; t++) acc = Cv::add(acc, Cv::load(heads, base + t));
+    Cv::store(buckets, g, acc);
 }
 
 // the same with one bucket per QUAD of lanes (small and mid-size MSMs: the chain of dependent additions
@@ -609,11 +674,12 @@ __global__ void __launch_bounds__(kBlk) k_fixup_quad(const u32* __restrict__ off
 }
 
 // one workgroup per long bucket: strided partial sums per lane, then an LDS tree
+template <class Cv>
 __global__ void __launch_bounds__(kBlk) k_fixup_long(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, u32 T,
                                                    size_t tiles_per_w, void* __restrict__ buckets, const void* __restrict__ heads,
                                                    const void* __restrict__ tails, const u32* __restrict__ long_count,
                                                    const u32* __restrict__ long_list) {
-    __shared__ uint4 red[kBlk * 12];  // 256 XYZZ points
+    extern __shared__ uint4 red[];  // blockDim.x XYZZ points
     const u32 nlong = *long_count;
     for (u32 i = blockIdx.x; i < nlong; i += gridDim.x) {
         const size_t g = long_list[i];
@@ -621,27 +687,28 @@ __global__ void __launch_bounds__(kBlk) k_fixup_long(const u32* __restrict__ off
         const u32 s = offsets[g], e = s + counts[g];
         const u32 t0 = s / T, t1 = (e - 1) / T;
         const size_t base = w * tiles_per_w;
-        Xyzz30 acc;
-        xyzz30_set_inf(acc);
-        for (u32 k = threadIdx.x; k <= t1 - t0; k += kBlk) {
-            Xyzz30 piece = (k == 0 && s != t0 * T) ? xyzz30_load(tails, base + t0) : xyzz30_load(heads, base + t0 + k);
-            acc = xyzz30_add(acc, piece);
+        typename Cv::Xyzz acc;
+        Cv::set_inf(acc);
+        for (u32 k = threadIdx.x; k <= t1 - t0; k += blockDim.x) {
+            typename Cv::Xyzz piece = (k == 0 && s != t0 * T) ? Cv::load(tails, base + t0) : Cv::load(heads, base + t0 + k);
+            acc = Cv::add(acc, piece);
         }
-        xyzz30_store(red, threadIdx.x, acc);
+        Cv::store(red, threadIdx.x, acc);
         __syncthreads();
-        for (int stride = kBlk / 2; stride > 0; stride >>= 1) {
+        for (int stride = (int)blockDim.x / 2; stride > 0; stride >>= 1) {
             if ((int)threadIdx.x < stride) {
-                Xyzz30 a = xyzz30_load(red, threadIdx.x), b2 = xyzz30_load(red, threadIdx.x + stride);
-                xyzz30_store(red, threadIdx.x, xyzz30_add(a, b2));
+                typename Cv::Xyzz a = Cv::load(red, threadIdx.x), b2 = Cv::load(red, threadIdx.x + stride);
+                Cv::store(red, threadIdx.x, Cv::add(a, b2));
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) xyzz30_store(buckets, g, xyzz30_load(red, 0));
+        if (threadIdx.x == 0) Cv::store(buckets, g, Cv::load(red, 0));
         __syncthreads();
     }
 }
 
 // one bit-plane pass of the bucket reduction.  in: [W][rows][len], out: [W][rows+1][len/2]
+template <class Cv>
 __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len, NarrowRows nr) {
     const size_t half = len >> 1;
     const size_t per_w = (size_t)(rows + 1) * half;
@@ -654,17 +721,17 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
     if (2 * j >= eff) return;
     const size_t in_w = w * (size_t)rows * len;
     const size_t src_row = (r < rows - 1) ? (size_t)r : (size_t)(rows - 1);  // rows-1 = the L row
-    Xyzz30 b;
-    if (2 * j + 1 < eff) b = xyzz30_load(in, in_w + src_row * len + 2 * j + 1);
-    else xyzz30_set_inf(b);
-    Xyzz30 res;
+    typename Cv::Xyzz b;
+    if (2 * j + 1 < eff) b = Cv::load(in, in_w + src_row * len + 2 * j + 1);
+    else Cv::set_inf(b);
+    typename Cv::Xyzz res;
     if (r == rows - 1) {
         res = b;  // odd elements of L become the new plane row
     } else {
-        Xyzz30 a = xyzz30_load(in, in_w + src_row * len + 2 * j);
-        res = xyzz30_add(a, b);
+        typename Cv::Xyzz a = Cv::load(in, in_w + src_row * len + 2 * j);
+        res = Cv::add(a, b);
     }
-    xyzz30_store(out, t, res);
+    Cv::store(out, t, res);
 }
 
 // the same pass with one addition per QUAD of lanes (curve30.cuh: xyzz30_add_quad): for the late passes,
@@ -703,30 +770,23 @@ __global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in
 // U_j = T_2j + 2*T_{2j+1} (+ T_all for j = 0), halving the host's additions at the price of a longer
 // device chain (measured: a wash at 2^20).
 // in: [rows][c] XYZZ, out: [rows][nout] Jacobian; nout = c, or max(1, c/2) when pairing.
+template <class Cv>
 __global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void* __restrict__ out, size_t rows, int c, int nout, int pair) {
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= rows * (size_t)nout) return;
     const size_t row = t / nout;
     const int j = (int)(t % nout);
-    Xyzz30 acc;
+    typename Cv::Xyzz acc;
     if (!pair) {
-        acc = xyzz30_load(in, row * c + j);
+        acc = Cv::load(in, row * c + j);
     } else {
         const int planes = c - 1;  // T_0 .. T_{c-2}; index c-1 is T_all
-        xyzz30_set_inf(acc);
-        if (2 * j < planes) acc = xyzz30_load(in, row * c + 2 * j);
-        if (j == 0) acc = xyzz30_add(acc, xyzz30_load(in, row * c + (c - 1)));
-        if (2 * j + 1 < planes) acc = xyzz30_add(acc, xyzz30_dbl(xyzz30_load(in, row * c + 2 * j + 1)));
+        Cv::set_inf(acc);
+        if (2 * j < planes) acc = Cv::load(in, row * c + 2 * j);
+        if (j == 0) acc = Cv::add(acc, Cv::load(in, row * c + (c - 1)));
+        if (2 * j + 1 < planes) acc = Cv::add(acc, Cv::dbl(Cv::load(in, row * c + 2 * j + 1)));
     }
-    Fq30 X = f30_zero(), Y = f30_zero(), Z = f30_zero();
-    if (!xyzz30_is_inf(acc)) {  // (X*ZZ, Y*ZZZ, ZZ) is a Jacobian representative: x = X*ZZ/ZZ^2, y = Y*ZZZ/ZZ^3
-        X = f30_to_ref(f30_mul(acc.x, acc.zz));
-        Y = f30_to_ref(f30_mul(acc.y, acc.zzz));
-        Z = f30_to_ref(acc.zz);
-    }
-    f30_store(out, t * 144, X);
-    f30_store(out, t * 144 + 48, Y);
-    f30_store(out, t * 144 + 96, Z);
+    Cv::finish(acc, out, t);
 }
 
 // SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine, packed 96 B), one lane per point.
@@ -817,6 +877,38 @@ __global__ void __launch_bounds__(kBlk) k_dbg_g1(const void* __restrict__ p, con
     xyzz30_store_flat(out, i, r);
 }
 
+// test hook: the G2 formulas on pairs of affine points (reference form, 192 B); output through CvG2::finish (288 B Jacobian)
+// mode 0: p + q   1: (p + q) + p   2: (p + q) + (p + q)   3: p - q   4: 2 (p + q) by the doubling   5: (p + q) - (p + q)
+__global__ void __launch_bounds__(64) k_dbg_g2(const void* __restrict__ p, const void* __restrict__ q, void* __restrict__ out, size_t n, int mode) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    Aff2 a, b;
+    a.x = Fq2x{f30_from_ref(f30_load(p, i * 192)), f30_from_ref(f30_load(p, i * 192 + 48))};
+    a.y = Fq2x{f30_from_ref(f30_load(p, i * 192 + 96)), f30_from_ref(f30_load(p, i * 192 + 144))};
+    b.x = Fq2x{f30_from_ref(f30_load(q, i * 192)), f30_from_ref(f30_load(q, i * 192 + 48))};
+    b.y = Fq2x{f30_from_ref(f30_load(q, i * 192 + 96)), f30_from_ref(f30_load(q, i * 192 + 144))};
+    Xyzz2 s;
+    xyzz2_set_inf(s);
+    xyzz2_madd(s, a, false);
+    xyzz2_madd(s, b, mode == 3);
+    Xyzz2 r = s;
+    if (mode == 1) {
+        Xyzz2 pa;
+        xyzz2_set_inf(pa);
+        xyzz2_madd(pa, a, false);
+        r = xyzz2_add(s, pa);
+    } else if (mode == 2) {
+        r = xyzz2_add(s, s);
+    } else if (mode == 4) {
+        r = xyzz2_dbl(s);
+    } else if (mode == 5) {
+        Xyzz2 m = s;
+        m.y = f2_sub4(f2_zero(), s.y);  // -(p + q): 4q - Y < 4q
+        r = xyzz2_add(s, m);
+    }
+    CvG2::finish(r, out, i);
+}
+
 // ---------------------------------------------------------------------------------------
 // device XYZZ (internal Montgomery form 2^390, coordinates < 8q) -> host Jacobian in the reference form:
 // one host multiplication by 2^-6 per coordinate (K = 2^378 mod q = the 2^384-form of 2^-6)
@@ -837,17 +929,20 @@ static zkhost::Jac load_xyzz_host(const uint64_t* p) {
 // run in pieces: combine_windows() continues `acc` through the positions of windows [w0, w0 + wc),
 // which must be the next lower ones (a class may hold only part of the windows, highest part first).
 // (Splitting the chain over host threads was measured: thread start-up costs what the shorter chain saves.)
-static void combine_windows(zkhost::Jac& acc, const uint64_t* h, const WinLayout& L, int w0, int wc, int c, int nout, bool pair) {
+template <class HF>
+static void combine_windows(zkhost::JacT<HF>& acc, const uint64_t* h, const WinLayout& L, int w0, int wc, int c, int nout, bool pair) {
+    typedef zkhost::JacT<HF> J;
+    constexpr size_t fw = zkhost::fe_words<HF>();
     const size_t p_lo = (size_t)L.bit_offset(w0);
     const size_t p_hi = (w0 + wc >= L.W) ? (size_t)L.bit_offset(L.W - 1) + L.width(L.W - 1) + c + 2 : (size_t)L.bit_offset(w0 + wc);
-    std::vector<zkhost::Jac> pos(p_hi - p_lo, zkhost::jac_inf());
+    std::vector<J> pos(p_hi - p_lo, zkhost::jac_inf_t<HF>());
     for (int w = 0; w < wc; w++) {
         for (int j = 0; j < nout; j++) {
-            const uint64_t* src = h + ((size_t)w * nout + j) * 18;
-            zkhost::Jac pt;
-            std::memcpy(pt.x.data(), src, 48);
-            std::memcpy(pt.y.data(), src + 6, 48);
-            std::memcpy(pt.z.data(), src + 12, 48);
+            const uint64_t* src = h + ((size_t)w * nout + j) * 3 * fw;
+            J pt;
+            zkhost::get_fe(pt.x, src);
+            zkhost::get_fe(pt.y, src + fw);
+            zkhost::get_fe(pt.z, src + 2 * fw);
             if (zkhost::is_zero(pt.z)) continue;
             const size_t p = (size_t)L.bit_offset(w0 + w) + (pair ? 2 * (size_t)j : (j == c - 1 ? 0 : (size_t)j)) - p_lo;
             pos[p] = zkhost::jac_add(pos[p], pt);
@@ -948,7 +1043,10 @@ static int quantised_window(int c) {
     return c <= 5 ? 5 : (c > 17 ? 19 : std::min(17, 5 + step * ((c - 5 + step - 1) / step)));
 }
 
-int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) {
+template <class Cv>
+static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) {
+    typedef typename Cv::HostF HF;
+    constexpr size_t kOutWords = 3 * zkhost::fe_words<HF>();  // 18 (G1) / 36 (G2) u64 per result
     if (!h_out && count) return fail(ctx, ZK_ERR_INVALID, "null argument");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
@@ -962,15 +1060,16 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     for (size_t k = 0; k < count; k++) {
         const MsmItem& it = items[k];
         if (!it.srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
+        if (it.srs->g2 != !Cv::kEndo) return fail(ctx, ZK_ERR_INVALID, "msm: the SRS belongs to the other group (G1 / G2)");
         if (it.offset + it.n > it.srs->n)
             return fail(ctx, ZK_ERR_LENGTH, "msm: %zu scalars but only %zu bases from offset %zu", it.n,
                         it.srs->n - std::min(it.offset, it.srs->n), it.offset);
         if (it.n >= ((size_t)1 << 30)) return fail(ctx, ZK_ERR_INVALID, "msm: n too large");  // 2n row entries, 31-bit indices
         if (it.n == 0) {
-            zkhost::write_normalised(zkhost::jac_inf(), h_out + 18 * k);
+            zkhost::write_normalised(zkhost::jac_inf_t<HF>(), h_out + kOutWords * k);
             continue;
         }
-        const bool shared = it.srs->d_table != nullptr && ctx->msm_window_override <= 0;
+        const bool shared = Cv::kEndo && it.srs->d_table != nullptr && ctx->msm_window_override <= 0;
         int c = ctx->msm_window_override > 0 ? ctx->msm_window_override : msm_pick_window(it.n);
         if (count > 1 && ctx->msm_window_override <= 0) c = quantised_window(c);
         if (shared) c = it.srs->table_c;
@@ -982,7 +1081,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
             cl = &classes.back();
             cl->key_c = c;
             cl->shared = shared;
-            cl->L = msm_layout(c, shared ? kFullBits : kEndoBits);
+            cl->L = msm_layout(c, (shared || !Cv::kEndo) ? kFullBits : kEndoBits);
             // the balanced layout may end up narrower than asked: buckets and planes follow the WIDEST window;
             // windows one bit narrower (index >= L.rem) use only the lower half of their bucket row
             cl->c = cl->L.base + (cl->L.rem ? 1 : 0);
@@ -1034,7 +1133,7 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         const int W = cl.wc;
         const size_t nitems = cl.idx.size();
         cl.rpi = cl.shared ? 1 : W;
-        cl.copies = cl.shared ? W : 2;
+        cl.copies = cl.shared ? W : (Cv::kEndo ? 2 : 1);
         cl.row_len = (size_t)cl.copies * cl.ns;
         cl.rows = nitems * cl.rpi;
         cl.total = cl.rows * cl.nb;
@@ -1084,15 +1183,15 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         cl.cc_elems = cl.rows * (size_t)cl.np * cl.nchunks + 2 * cl.rows * (size_t)cl.np + cl.rows;  // hist, total, base, rowtot
         // classes run concurrently on separate streams: each gets its own region of every arena
         const size_t total64 = (cl.total + 63) & ~(size_t)63, tiles64 = (cl.total_tiles + 63) & ~(size_t)63;  // XYZZ arrays: blocks of 64
-        const size_t want_b[10] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4, total64 * 192, total64 * 192,
-                                   2 * tiles64 * 192, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
+        const size_t want_b[10] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4, total64 * Cv::kXyzzBytes, total64 * Cv::kXyzzBytes,
+                                   2 * tiles64 * Cv::kXyzzBytes, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
                                    cl.cc_elems * 4, cl.rows * cl.row_len * 2};
         for (int i = 0; i < 10; i++) {
             cl.off[i] = need[i];
             need[i] += (want_b[i] + 255) & ~(size_t)255;
         }
         cl.pinned_off = pinned_bytes;
-        pinned_bytes += ((cl.rows * (size_t)cl.npair * 144 + 255) & ~(size_t)255) + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
+        pinned_bytes += ((cl.rows * (size_t)cl.npair * Cv::kJacBytes + 255) & ~(size_t)255) + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
     }
     // allocate every arena once, before anything is enqueued (no reallocation between classes)
     static const int slot[10] = {0, 1, 2, 3, 4, 5, 6, 9, 8, 11};
@@ -1136,24 +1235,24 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         void* bufA = (char*)buf[3] + cl.off[3];
         void* bufB = (char*)buf[4] + cl.off[4];
         void* heads = (char*)buf[5] + cl.off[5];
-        void* tails = (char*)heads + ((cl.total_tiles + 63) & ~(size_t)63) * 192;
+        void* tails = (char*)heads + ((cl.total_tiles + 63) & ~(size_t)63) * Cv::kXyzzBytes;
         u32* longs = (u32*)((char*)buf[6] + cl.off[6]);
         ItemDesc* d_items = (ItemDesc*)((char*)buf[7] + cl.off[7]);
         u32* cc = (u32*)((char*)buf[8] + cl.off[8]);
         uint64_t* h_pts = (uint64_t*)(hpin + cl.pinned_off);
-        ItemDesc* h_items = (ItemDesc*)(hpin + cl.pinned_off + ((cl.rows * (size_t)cl.npair * 144 + 255) & ~(size_t)255));
+        ItemDesc* h_items = (ItemDesc*)(hpin + cl.pinned_off + ((cl.rows * (size_t)cl.npair * Cv::kJacBytes + 255) & ~(size_t)255));
         for (size_t j = 0; j < nitems; j++) {
             const MsmItem& it = items[cl.idx[j]];
             h_items[j].scalars = it.d_scalars;
-            h_items[j].bases = (const char*)(cl.shared ? it.srs->d_table : it.srs->d_bases) + it.offset * 96;
+            h_items[j].bases = (const char*)(cl.shared ? it.srs->d_table : it.srs->d_bases) + it.offset * Cv::kAffBytes;
             h_items[j].n = (u32)it.n;
-            h_items[j].pstride = cl.shared ? (u32)it.srs->table_stride : (u32)it.srs->n;  // phi(P_i) sits n points after P_i
+            h_items[j].pstride = cl.shared ? (u32)it.srs->table_stride : (Cv::kEndo ? (u32)it.srs->n : 0u);  // phi(P_i) sits n points after P_i
         }
         if (t_first) hipEventRecord(ctx->ev[0], st);
         ZK_HIP_INFLIGHT(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
         ZK_HIP_INFLIGHT(ctx, hipMemsetAsync(longs, 0, 4, st));
         hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
-                           (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, cl.shared ? 0 : 1, digits);
+                           (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, (cl.shared || !Cv::kEndo) ? 0 : 1, digits);
         {
             u32* hist = cc;
             u32* ptotal = hist + cl.rows * (size_t)cl.np * cl.nchunks;
@@ -1178,21 +1277,21 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         }
         if (t_first) hipEventRecord(ctx->ev[1], st);
         if (cl.part > 0) hipStreamWaitEvent(st, ctx->ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
-        hipLaunchKernelGGL(k_accum_tiles, dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
+        hipLaunchKernelGGL((k_accum_tiles<Cv>), dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const u32*)offsets, (const u32*)counts, cl.row_len,
                            (u32)ns, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
         if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(ctx->ev_part[cl.part % zk_ctx::kParts], st);
         if (t_last) hipEventRecord(ctx->ev[4], st);
         const NarrowRows nrw{cl.rpi, cl.w0, cl.narrow_from};
-        if (total <= fixq_max)
+        if (Cv::kQuad && total <= fixq_max)
             hipLaunchKernelGGL(k_fixup_quad, dim3((unsigned)((4 * total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
                                (const u32*)counts, nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                                longs + 1);
         else
-            hipLaunchKernelGGL(k_fixup, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
+            hipLaunchKernelGGL((k_fixup<Cv>), dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
                                (const u32*)counts, nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                                longs + 1);
-        hipLaunchKernelGGL(k_fixup_long, dim3(512), dim3(kBlk), 0, st, (const u32*)offsets, (const u32*)counts, nb, cl.T,
+        hipLaunchKernelGGL((k_fixup_long<Cv>), dim3(512), dim3(Cv::kXyzzBytes == 192 ? kBlk : kBlk / 2), (size_t)48 * 1024, st, (const u32*)offsets, (const u32*)counts, nb, cl.T,
                            cl.tiles_per_w, bufA, (const void*)heads, (const void*)tails, (const u32*)longs, (const u32*)(longs + 1));
         if (t_last) hipEventRecord(ctx->ev[2], st);
         void* in = bufA;
@@ -1201,11 +1300,11 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         size_t len = nb;
         while (len > 1) {
             size_t threads = cl.rows * (size_t)(rows + 1) * (len >> 1);
-            if (threads <= quad_max)  // too few additions to fill the chip: spend four lanes on each
+            if (Cv::kQuad && threads <= quad_max)  // too few additions to fill the chip: spend four lanes on each
                 hipLaunchKernelGGL(k_halve_quad, dim3((unsigned)((4 * threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
                                    (int)cl.rows, rows, len, nrw);
             else
-                hipLaunchKernelGGL(k_halve, dim3((unsigned)((threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
+                hipLaunchKernelGGL((k_halve<Cv>), dim3((unsigned)((threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
                                    (int)cl.rows, rows, len, nrw);
             std::swap(in, out);
             rows++;
@@ -1214,10 +1313,10 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
         // rows == c reduced points per window row -> Jacobian points in the reference form
         {
             const size_t threads = cl.rows * (size_t)cl.npair;
-            hipLaunchKernelGGL(k_finish, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, (const void*)in, out, cl.rows, cl.c, cl.npair, cl.pair ? 1 : 0);
+            hipLaunchKernelGGL((k_finish<Cv>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, (const void*)in, out, cl.rows, cl.c, cl.npair, cl.pair ? 1 : 0);
         }
         ZK_HIP_INFLIGHT(ctx, hipGetLastError());
-        ZK_HIP_INFLIGHT(ctx, hipMemcpyAsync(h_pts, out, cl.rows * (size_t)cl.npair * 144, hipMemcpyDeviceToHost, st));
+        ZK_HIP_INFLIGHT(ctx, hipMemcpyAsync(h_pts, out, cl.rows * (size_t)cl.npair * Cv::kJacBytes, hipMemcpyDeviceToHost, st));
         if (t_last) hipEventRecord(ctx->ev[3], st);
         while (ctx->ev_cls.size() <= cls_i) {  // one completion event per class: the host starts on a class as soon as it lands
             hipEvent_t e;
@@ -1238,13 +1337,13 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     // are taken in the order they finish on the device (least work first; the parts of a staggered class
     // in window order): while the big class is still running, the items of the small ones are already
     // being combined.  Only the last class's chains are exposed. ----
-    std::vector<zkhost::Jac> chain(count, zkhost::jac_inf());
+    std::vector<zkhost::JacT<HF>> chain(count, zkhost::jac_inf_t<HF>());
     auto run_item = [&chain, hpin, h_out](const MsmClass& cl, size_t j) {
         WinLayout one{1, 0, 0};  // shared buckets: a single row, the window factors live in the table
-        const uint64_t* h = (const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.rpi * cl.npair * 18;
-        if (cl.shared) combine_windows(chain[cl.idx[j]], h, one, 0, 1, cl.c, cl.npair, cl.pair);
-        else combine_windows(chain[cl.idx[j]], h, cl.L, cl.w0, cl.wc, cl.c, cl.npair, cl.pair);
-        if (cl.part + 1 == cl.nparts) zkhost::write_normalised(chain[cl.idx[j]], h_out + 18 * cl.idx[j]);
+        const uint64_t* h = (const uint64_t*)(hpin + cl.pinned_off) + j * (size_t)cl.rpi * cl.npair * kOutWords;
+        if (cl.shared) combine_windows<HF>(chain[cl.idx[j]], h, one, 0, 1, cl.c, cl.npair, cl.pair);
+        else combine_windows<HF>(chain[cl.idx[j]], h, cl.L, cl.w0, cl.wc, cl.c, cl.npair, cl.pair);
+        if (cl.part + 1 == cl.nparts) zkhost::write_normalised(chain[cl.idx[j]], h_out + kOutWords * cl.idx[j]);
     };
     std::vector<size_t> order(classes.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
@@ -1289,6 +1388,9 @@ int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
     ctx->msm_ms[5] = ctx->msm_ms[0] + ctx->msm_ms[1] + ctx->msm_ms[2] + ctx->msm_ms[3] + ctx->msm_ms[4];
     return ZK_OK;
 }
+
+int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) { return msm_batch<CvG1>(ctx, items, count, h_out); }
+int msm_g2_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) { return msm_batch<CvG2>(ctx, items, count, h_out); }
 
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out) {
     if (!srs || !h_out) return fail(ctx, ZK_ERR_INVALID, "null argument");
@@ -1357,6 +1459,39 @@ int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs**
     return ZK_OK;
 }
 
+// G2 base vector (powers_of_g2 and friends, dpoly_comm.rs:27): ark G2Affine = { x: Fq2, y: Fq2, infinity } -> 192-byte
+// records x.c0 | x.c1 | y.c0 | y.c1 (stride 192, or the Rust struct's stride with the flag byte at offset 192)
+int srs_pack_g2(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out) {
+    if (!out || (n && !h_bases)) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    if (stride != 192 && stride < 193) return fail(ctx, ZK_ERR_INVALID, "stride must be 192 or >= 193 (x, y, infinity flag)");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    SrsGuard guard;
+    zk_srs* s = guard.s = new zk_srs();
+    s->n = n;
+    s->owned = true;
+    s->g2 = true;
+    if (n) {
+        ZK_HIP(ctx, device_alloc(ctx, &s->d_bases, n * 192));
+        std::vector<char> packed;
+        const void* src = h_bases;
+        if (stride != 192) {
+            packed.resize(n * 192);
+            const char* p = (const char*)h_bases;
+            for (size_t i = 0; i < n; i++) {
+                if (p[i * stride + 192]) std::memset(&packed[i * 192], 0, 192);
+                else std::memcpy(&packed[i * 192], p + i * stride, 192);
+            }
+            src = packed.data();
+        }
+        ZK_HIP(ctx, hipMemcpy(s->d_bases, src, n * 192, hipMemcpyHostToDevice));
+        srs_convert(ctx, s->d_bases, s->d_bases, 2 * n, true);  // four coordinates per point
+        ZK_HIP(ctx, hipGetLastError());
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *out = guard.release();
+    return ZK_OK;
+}
+
 int srs_from_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out) {
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     SrsGuard guard;
@@ -1378,11 +1513,12 @@ int srs_download(zk_ctx* ctx, const zk_srs* srs, void* h_out96) {
     if (!srs || (srs->n && !h_out96)) return fail(ctx, ZK_ERR_INVALID, "null argument");
     if (!srs->n) return ZK_OK;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    void* tmp = scratch(ctx, 0, srs->n * 96);
+    const size_t rec = srs->g2 ? 192 : 96;  // G2: x.c0 | x.c1 | y.c0 | y.c1
+    void* tmp = scratch(ctx, 0, srs->n * rec);
     if (!tmp) return ZK_ERR_OOM;
-    srs_convert(ctx, srs->d_bases, tmp, srs->n, false);
+    srs_convert(ctx, srs->d_bases, tmp, srs->n * (rec / 96), false);
     ZK_HIP(ctx, hipGetLastError());
-    ZK_HIP(ctx, hipMemcpyAsync(h_out96, tmp, srs->n * 96, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(h_out96, tmp, srs->n * rec, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }
@@ -1398,6 +1534,7 @@ int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t 
 
 int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     if (!srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
+    if (srs->g2) return fail(ctx, ZK_ERR_INVALID, "zk_srs_precompute: G1 only");
     if (c == 0) c = msm_pick_window_full(srs->n ? srs->n : 1);
     if (c < 2 || c > 20) return fail(ctx, ZK_ERR_INVALID, "window bits out of range");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
@@ -1587,6 +1724,26 @@ int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, 
     ZK_HIP(ctx, hipMemcpyAsync(h.data(), d, n * 192, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < n; i++) zkhost::write_normalised(load_xyzz_host(&h[i * 24]), (uint64_t*)h_out + 18 * i);
+    return ZK_OK;
+}
+
+int dbg_g2_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n) {
+    if (n == 0) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    void* d = scratch(ctx, 3, n * 288);
+    if (!d) return ZK_ERR_OOM;
+    hipLaunchKernelGGL(k_dbg_g2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, p, q, d, n, mode);
+    ZK_HIP(ctx, hipGetLastError());
+    std::vector<uint64_t> h(n * 36);
+    ZK_HIP(ctx, hipMemcpyAsync(h.data(), d, n * 288, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; i++) {
+        zkhost::Jac2 j;
+        zkhost::get_fe(j.x, &h[i * 36]);
+        zkhost::get_fe(j.y, &h[i * 36 + 12]);
+        zkhost::get_fe(j.z, &h[i * 36 + 24]);
+        zkhost::write_normalised(j, (uint64_t*)h_out + 36 * i);
+    }
     return ZK_OK;
 }
 

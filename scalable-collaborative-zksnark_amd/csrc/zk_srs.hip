@@ -441,6 +441,7 @@ int srs_powers(zk_ctx* ctx, const void* h_g96, const uint64_t* h_s, size_t nvars
 // shorter than l is zero-extended to one chunk (:177-181)
 int srs_to_packed(zk_ctx* ctx, const zk_srs* level, const uint64_t* h_row, size_t l, zk_srs** out) {
     if (!level || !h_row || !out || l == 0) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    if (level->g2) return fail(ctx, ZK_ERR_INVALID, "zk_srs_to_packed: G1 levels only");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = level->n;
     const size_t cols = std::min(l, n), k = n < l ? (n ? 1 : 0) : n / l;

@@ -57,6 +57,9 @@ SYMBOLS = [
     ("zk_srs_download", _i, [_vp, _vp, _vp]),
     ("zk_msm_g1", _i, [_vp, _vp, _sz, _vp, _sz, _vp]),
     ("zk_msm_g1_batch", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    ("zk_srs_register_g2", _i, [_vp, _vp, _sz, _sz, _pp]),
+    ("zk_msm_g2", _i, [_vp, _vp, _sz, _vp, _sz, _vp]),
+    ("zk_msm_g2_batch", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zk_msm_g1_host", _i, [_vp, _vp, _sz, _sz, _vp, _sz, _vp, ctypes.POINTER(ctypes.c_size_t)]),
     ("zk_g1_lincomb", _i, [_vp, _vp, _vp, _sz, _vp]),
     ("zk_g1_lincomb_batch", _i, [_vp, _vp, _vp, _sz, _sz, _vp]),
@@ -79,6 +82,7 @@ SYMBOLS = [
     ("zk_dbg_fq_sub", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_fq_mul2add", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_g1_op", _i, [_vp, _i, _vp, _vp, _vp, _sz]),
+    ("zk_dbg_g2_op", _i, [_vp, _i, _vp, _vp, _vp, _sz]),
 ]
 
 ZK_OK, ZK_ERR_INVALID, ZK_ERR_LENGTH, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_DIV_ZERO, ZK_ERR_OOM, ZK_ERR_COMM = 0, -1, -2, -3, -4, -5, -6, -7

@@ -100,7 +100,7 @@ class Srs:
 
     def download(self) -> np.ndarray:
         n = len(self)
-        out = np.empty((n, 12), dtype=np.uint64)
+        out = np.empty((n, 24 if getattr(self, "g2", False) else 12), dtype=np.uint64)
         if n:
             self.ctx._check(self.ctx.lib.zk_srs_download(self.ctx.h, self.h, _h(out)))
         return out
@@ -361,6 +361,38 @@ class Ctx:
             print("zkhip-msm", [int(x) for x in lens], [round(float(x), 3) for x in self.msm_last_timing()], file=sys.stderr)
         return out
 
+    # ---- G2 (same pipeline over Fq2) ----
+    def srs_register_g2(self, bases: np.ndarray, stride: int = 192) -> Srs:
+        """bases: affine G2 points x.c0|x.c1|y.c0|y.c1, [n, 24] uint64 Montgomery limbs (zeros = infinity)"""
+        b = np.ascontiguousarray(bases)
+        n = b.nbytes // stride
+        h = ctypes.c_void_p()
+        self._check(self.lib.zk_srs_register_g2(self.h, _h(b), stride, n, ctypes.byref(h)))
+        s = Srs(self, h.value)
+        s.g2 = True
+        return s
+
+    def msm_g2(self, srs: Srs, scalars, n: int, offset: int = 0) -> np.ndarray:
+        """-> normalised Jacobian over Fq2, [36] uint64 (x.c0 x.c1 y.c0 y.c1 z.c0 z.c1)"""
+        out = np.zeros(36, dtype=np.uint64)
+        rc = self.lib.zk_msm_g2(self.h, srs.h, offset, _ptr(scalars), n, _h(out))
+        if rc == ZK_ERR_LENGTH:
+            raise MsmLengthError(rc, (self.lib.zk_last_error(self.h) or b"").decode(), min(n, max(len(srs) - offset, 0)))
+        self._check(rc)
+        return out
+
+    def msm_g2_batch(self, srs_list, scalars_list, lens, offsets=None) -> np.ndarray:
+        count = len(lens)
+        out = np.zeros((count, 36), dtype=np.uint64)
+        if count == 0:
+            return out
+        h = (ctypes.c_void_p * count)(*[s.h for s in srs_list])
+        sp = (ctypes.c_void_p * count)(*[_ptr(s) for s in scalars_list])
+        nn = (ctypes.c_size_t * count)(*[int(x) for x in lens])
+        off = (ctypes.c_size_t * count)(*[int(x) for x in (offsets or [0] * count)])
+        self._check(self.lib.zk_msm_g2_batch(self.h, count, h, off, sp, nn, _h(out)))
+        return out
+
     def msm_g1_host(self, bases: np.ndarray, scalars: np.ndarray, stride: int = 96) -> np.ndarray:
         """drop-in for G::msm(&[Affine], &[Fr]) on host arrays"""
         b = np.ascontiguousarray(bases)
@@ -471,6 +503,11 @@ class Ctx:
         fn = {"add": self.lib.zk_dbg_fq_add, "sub": self.lib.zk_dbg_fq_sub, "mul": self.lib.zk_dbg_fq_mul, "mul2add": self.lib.zk_dbg_fq_mul2add}[op]
         out = out or self.alloc(max(48 * n, 1))
         self._check(fn(self.h, _ptr(a), _ptr(b), _ptr(out), n))
+        return out
+
+    def dbg_g2_op(self, mode: int, p, q, n) -> np.ndarray:
+        out = np.zeros((n, 36), dtype=np.uint64)
+        self._check(self.lib.zk_dbg_g2_op(self.h, mode, _ptr(p), _ptr(q), _h(out), n))
         return out
 
     def dbg_g1_op(self, mode: int, p, q, n) -> np.ndarray:

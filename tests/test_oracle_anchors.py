@@ -82,3 +82,15 @@ def test_compressed_encoding_shape():
     assert b.hex().startswith("97f1d3a73197d7942695638c4fa9ac0f")  # generator, well-known encoding
     assert po.g1_compress(None)[0] == 0xC0
     assert len(po.fr_serialize(5)) == 32 and po.fr_serialize(5)[0] == 5
+
+
+def test_g2_generator_anchor():
+    """the G2 generator of the oracle: on the twist y^2 = x^3 + 4(1 + u) and of order r"""
+    import pyoracle as po
+
+    assert po.g2_is_on_curve(po.G2_GEN)
+    assert po.g2_mul(po.G2_GEN, po.R_MOD - 1) == po.g2_neg(po.G2_GEN)
+    assert po.g2_add(po.g2_mul(po.G2_GEN, po.R_MOD - 1), po.G2_GEN) is None
+    P = po.g2_mul(po.G2_GEN, 123456789)
+    assert po.g2_is_on_curve(P) and po.g2_add(P, po.g2_neg(P)) is None
+    assert po.g2_add(po.g2_mul(po.G2_GEN, 5), po.g2_mul(po.G2_GEN, 7)) == po.g2_mul(po.G2_GEN, 12)
