@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
@@ -1193,6 +1194,14 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
         cl.pinned_off = pinned_bytes;
         pinned_bytes += ((cl.rows * (size_t)cl.npair * Cv::kJacBytes + 255) & ~(size_t)255) + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
     }
+    static const bool dbg_classes = getenv("ZK_MSM_DEBUG") != nullptr;
+    if (dbg_classes)
+        for (auto& cl : classes) {
+            size_t nmin = ~(size_t)0, nmax2 = 0, tot = 0;
+            for (size_t k : cl.idx) nmin = std::min(nmin, items[k].n), nmax2 = std::max(nmax2, items[k].n), tot += items[k].n;
+            fprintf(stderr, "zk-class key_c=%d c=%d W=%d items=%zu n=[%zu..%zu] sum=%zu ns=%zu rows=%zu nb=%zu buckets=%zu T=%u tiles=%zu np=%u\n", cl.key_c, cl.c, cl.wc,
+                    cl.idx.size(), nmin, nmax2, tot, cl.ns, cl.rows, cl.nb, cl.total, cl.T, cl.total_tiles, cl.np);
+        }
     // allocate every arena once, before anything is enqueued (no reallocation between classes)
     static const int slot[10] = {0, 1, 2, 3, 4, 5, 6, 9, 8, 11};
     void* buf[10];

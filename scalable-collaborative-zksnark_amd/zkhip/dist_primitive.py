@@ -65,7 +65,7 @@ def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: Packe
         c_shares = be.msm_g1_batch(list(bases), list(scalars), list(lens))  # one pipeline pass for the whole batch
         gathered = net.all_gather(c_shares)  # [party][batch,18]
         coeff = np.array([int_to_limbs(c, 4) for c in pp.dmsm_coeffs(p)], dtype=np.uint64)
-        return be.g1_lincomb_batch(np.stack([np.stack([gathered[q][k] for q in range(n)]) for k in range(len(lens))]), coeff)
+        return be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in gathered], axis=1), coeff)
     lam = sum(pp.unpack2_matrix[j][p] for j in range(pp.l)) % R_MOD
     c_p = sum(pp.pack_matrix[p][j] for j in range(pp.l)) % R_MOD
     lam_m = fr_mont(lam)
@@ -78,7 +78,7 @@ def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: Packe
     c_shares = be.msm_g1_batch(list(bases), scaled, list(lens))
     gathered = net.all_gather(c_shares)
     ones = np.tile(int_to_limbs(1, 4), (n, 1))
-    sums = be.g1_lincomb_batch(np.stack([np.stack([gathered[q][k] for q in range(n)]) for k in range(len(lens))]), ones)
+    sums = be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in gathered], axis=1), ones)
     return be.g1_lincomb_batch(sums.reshape(len(lens), 1, 18), np.array([int_to_limbs(c_p, 4)], dtype=np.uint64))
 
 
@@ -310,7 +310,7 @@ def d_commit_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], net: N
     local = be.msm_g1_batch(srs, list(pevals), list(lens))  # [k, 18]
     got = net.all_gather(local)  # [party][k, 18]
     ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
-    return be.g1_lincomb_batch(np.stack([np.stack([got[p][i] for p in range(net.n_parties)]) for i in range(k)]), ones)
+    return be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in got], axis=1), ones)  # [k][party][18]
 
 
 def d_commit(be, powers_of_g, peval, length: int, net: Net) -> np.ndarray:
@@ -349,9 +349,9 @@ def d_open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: 
         return [(ZERO.copy(), np.zeros((0, 18), dtype=np.uint64)) for _ in range(k)]
     ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
     total = cuts[-1]
-    pi = be.g1_lincomb_batch(np.stack([np.stack([prfs[p][i] for p in range(net.n_parties)]) for i in range(total)]), ones) if total else np.zeros((0, 18), dtype=np.uint64)
+    pi = be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in prfs], axis=1), ones) if total else np.zeros((0, 18), dtype=np.uint64)
     # the k root tables (one value per party each) go up in ONE copy
-    root_tab = be.to_device(np.ascontiguousarray(np.stack([np.stack([vals[p][i] for p in range(net.n_parties)]) for i in range(k)])))
+    root_tab = be.to_device(np.ascontiguousarray(np.stack([np.asarray(v).reshape(-1, 4) for v in vals], axis=1)))  # [k][party][4]
     roots = open_many(be, powers_of_g, [root_tab.at(32 * net.n_parties * i) for i in range(k)], [net.n_parties] * k, [p[:plog] for p in pts])
     out = []
     for i in range(k):

@@ -106,3 +106,16 @@ def check_dhyperplonk_transcripts(n: int, res, pk, n_parties: int, leader: bool,
                 bad.append(f"wiring[{k}] (top tree)")
             k += 1
     return bad
+
+
+def open_equation_terms(value, point, s) -> list:
+    """
+    The verifier equation of the multilinear commitment (PolynomialCommitment::verify, dpoly_comm.rs:466-484):
+        e(C - value * g1, g2) == sum_i e(proof_i, s_i * g2 - point_i * g2).
+    With the trapdoor s known (it is in every test of the reference, which builds the SRS from s, :502-531), both
+    sides pull back to G1 through the non-degenerate pairing:  C - value * g1 == sum_i (s_i - point_i) * proof_i.
+    Returns the canonical coefficients [(s_i - point_i) mod r]; the caller combines the points (zk_g1_lincomb) and
+    compares group elements.  A pairing-free statement of the SAME equation, not a replacement for `verify`.
+    """
+    sv, pt = _ints(s), _ints(point)
+    return [(a - b) % R_MOD for a, b in zip(sv, pt)]

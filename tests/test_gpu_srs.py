@@ -135,3 +135,35 @@ def test_packed_commitment_shares_recombine(ctx):
     # every party's output is its share of the packed result [C; l]: unpack recovers C in every slot
     got = opp.unpack_g1([pt_ints(jac_norm_to_affine(o)) for o in outs])
     assert got == [pt_ints(jac_norm_to_affine(plain))] * l
+
+
+@pytest.mark.parametrize("n", [4, 10])
+def test_commit_open_pairs_satisfy_the_verifier_equation(ctx, n):
+    """
+    should_commit_and_open (dpoly_comm.rs:502-531): commit + open against the structured SRS must satisfy
+    verify's pairing equation (:466-484); checked pulled back to G1 through the known trapdoor, with the
+    ORACLE's group law: C - v g == sum_i (s_i - u_i) pi_i.
+    """
+    from zkhip import dist_primitive as dp
+    from zkhip.verify import open_equation_terms
+
+    rng = po.SplitMix64(4242 + n)
+    s, u, poly = rng.fr_vec(n), rng.fr_vec(n), rng.fr_vec(1 << n)
+    cub = dp.PolynomialCommitmentCub.new(ctx, _mont(s))
+    d_poly = ctx.to_device(_mont(poly))
+    C = pt_ints(jac_norm_to_affine(dp.commit(ctx, cub.mature(), d_poly, 1 << n)))
+    value, proofs = dp.open_(ctx, cub.mature(), d_poly, 1 << n, _mont(u))
+    v = po.fr_from_mont_limbs(value)
+    # the opened value is the multilinear extension at u (variable 0 = the top index bit, folded first)
+    tab = list(poly)
+    for r in u:
+        tab = po.fold(tab, r)
+    assert tab == [v]
+    coeffs = open_equation_terms(value, _mont(u), _mont(s))
+    rhs = None
+    for c, pi in zip(coeffs, proofs):
+        rhs = po.g1_add(rhs, po.g1_mul(pt_ints(jac_norm_to_affine(pi)), c))
+    lhs = po.g1_add(C, po.g1_neg(po.g1_mul(po.G1_GEN, v)))
+    assert lhs == rhs
+    # a wrong value must break it
+    assert po.g1_add(C, po.g1_neg(po.g1_mul(po.G1_GEN, (v + 1) % po.R_MOD))) != rhs
