@@ -43,6 +43,65 @@ def pss2ss(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
 # ---------------------------------------------------------------------------------------
 # d_msm (dmsm.rs:9-43)
 # ---------------------------------------------------------------------------------------
+class MsmQueue:
+    """
+    Collects the local MSMs of SEVERAL protocol calls and runs them in ONE pipeline pass (zk_msm_g1_batch).
+    Nothing on the path consumes an MSM result on the device (challenges are pre-sampled), so every
+    commit / open of a protocol step can queue its MSMs, run them together and finish (exchange + public map)
+    afterwards: a batch costs ~1 ms of latency chain whatever its size, a step of the driver had 2-9 of them.
+    The `*_q` functions below queue their work and return a closure that produces the reference's return value
+    once `run()` has been called; every party must call them, `run()` and the closures in the same order.
+    """
+
+    def __init__(self, be):
+        self.be, self.srs, self.bufs, self.lens, self.keep, self.res = be, [], [], [], [], None
+
+    def add(self, srs_list, bufs, lens, keep=()):
+        a = len(self.lens)
+        self.srs += list(srs_list)
+        self.bufs += list(bufs)
+        self.lens += [int(x) for x in lens]
+        self.keep += list(keep)  # buffers that must outlive the batched pass
+        return slice(a, len(self.lens))
+
+    def run(self):
+        self.res = self.be.msm_g1_batch(self.srs, self.bufs, self.lens) if self.lens else np.zeros((0, 18), dtype=np.uint64)
+        self.keep = []
+        return self.res
+
+
+def d_msm_q(be, q: MsmQueue, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net, prescale: bool = True):
+    """d_msm (dmsm.rs:9-43) with its local MSMs queued; -> closure returning [batch, 18]"""
+    assert len(bases) == len(scalars) == len(lens)  # dmsm.rs:16
+    p, n = net.party_id, net.n_parties
+    if not len(lens):
+        return lambda: np.zeros((0, 18), dtype=np.uint64)
+    # the no-`comm` echo net fabricates the other parties' messages from the local one, so the map must
+    # be applied exactly where the reference applies it
+    if not prescale or getattr(net, "echo", False):
+        sl = q.add(bases, scalars, lens)
+
+        def fin_plain():
+            gathered = net.all_gather(q.res[sl])  # [party][batch,18]
+            coeff = np.array([int_to_limbs(c, 4) for c in pp.dmsm_coeffs(p)], dtype=np.uint64)
+            return be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in gathered], axis=1), coeff)
+
+        return fin_plain
+    lam = sum(pp.unpack2_matrix[j][p] for j in range(pp.l)) % R_MOD
+    c_p = sum(pp.pack_matrix[p][j] for j in range(pp.l)) % R_MOD
+    lam_m = fr_mont(lam)
+    scaled = [be.fr_scale(s, lam_m, m) for s, m in zip(scalars, lens)]
+    sl = q.add(bases, scaled, lens, keep=scaled)
+
+    def fin():
+        gathered = net.all_gather(q.res[sl])
+        ones = np.tile(int_to_limbs(1, 4), (n, 1))
+        sums = be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in gathered], axis=1), ones)
+        return be.g1_lincomb_batch(sums.reshape(len(lens), 1, 18), np.array([int_to_limbs(c_p, 4)], dtype=np.uint64))
+
+    return fin
+
+
 def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net, prescale: bool = True) -> np.ndarray:
     """
     bases[k]: Srs (device-resident level), scalars[k]: device buffer of lens[k] Fr shares.
@@ -55,31 +114,17 @@ def d_msm(be, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: Packe
     all-gather, 7 point additions and ONE scalar multiplication by c_p instead of an 8-term
     255-bit combination on the host.  Same group element, hence the same output bits.
     """
-    assert len(bases) == len(scalars) == len(lens)  # dmsm.rs:16
-    if not len(lens):
-        return np.zeros((0, 18), dtype=np.uint64)
-    p, n = net.party_id, net.n_parties
-    # the no-`comm` echo net fabricates the other parties' messages from the local one, so the map must
-    # be applied exactly where the reference applies it
-    if not prescale or getattr(net, "echo", False):
-        c_shares = be.msm_g1_batch(list(bases), list(scalars), list(lens))  # one pipeline pass for the whole batch
-        gathered = net.all_gather(c_shares)  # [party][batch,18]
-        coeff = np.array([int_to_limbs(c, 4) for c in pp.dmsm_coeffs(p)], dtype=np.uint64)
-        return be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in gathered], axis=1), coeff)
-    lam = sum(pp.unpack2_matrix[j][p] for j in range(pp.l)) % R_MOD
-    c_p = sum(pp.pack_matrix[p][j] for j in range(pp.l)) % R_MOD
-    lam_m = fr_mont(lam)
-    if getattr(net, "ctx", None) is be and hasattr(be, "d_msm"):
+    if len(lens) and prescale and not getattr(net, "echo", False) and getattr(net, "ctx", None) is be and hasattr(be, "d_msm"):
         # the communicator lives in the same ctx: the whole of d_msm is ONE C-ABI call (zk_d_msm)
+        p, n = net.party_id, net.n_parties
+        lam = sum(pp.unpack2_matrix[j][p] for j in range(pp.l)) % R_MOD
+        c_p = sum(pp.pack_matrix[p][j] for j in range(pp.l)) % R_MOD
         net._count(144 * len(lens))
-        return be.d_msm(list(bases), list(scalars), list(lens), np.tile(int_to_limbs(c_p, 4), (n, 1)), lam_mont=lam_m)
-    scaled = [be.fr_scale(s, lam_m, m, out=be.temp(32 * m, ("d_msm", k)) if hasattr(be, "temp") else None)
-              for k, (s, m) in enumerate(zip(scalars, lens))]
-    c_shares = be.msm_g1_batch(list(bases), scaled, list(lens))
-    gathered = net.all_gather(c_shares)
-    ones = np.tile(int_to_limbs(1, 4), (n, 1))
-    sums = be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in gathered], axis=1), ones)
-    return be.g1_lincomb_batch(sums.reshape(len(lens), 1, 18), np.array([int_to_limbs(c_p, 4)], dtype=np.uint64))
+        return be.d_msm(list(bases), list(scalars), list(lens), np.tile(int_to_limbs(c_p, 4), (n, 1)), lam_mont=fr_mont(lam))
+    q = MsmQueue(be)
+    fin = d_msm_q(be, q, bases, scalars, lens, pp, net, prescale)
+    q.run()
+    return fin()
 
 
 # ---------------------------------------------------------------------------------------
@@ -251,6 +296,13 @@ class PolynomialCommitmentCub:
         return self.powers_of_g
 
 
+def commit_q(q: MsmQueue, powers_of_g, peval, length: int):
+    level = length.bit_length() - 1
+    assert level < len(powers_of_g) and length == 1 << level
+    sl = q.add([powers_of_g[level]], [peval], [length])
+    return lambda: q.res[sl][0]
+
+
 def commit(be, powers_of_g, peval, length: int) -> np.ndarray:
     """dpoly_comm.rs:237-243 (= d_local_commit :269-275)"""
     level = length.bit_length() - 1
@@ -273,22 +325,29 @@ def _open_items(be, powers_of_g, peval, length: int, point: np.ndarray):
     return value, q, srs, bufs, lens
 
 
+def open_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray]):
+    """several independent opens: the fold rounds run now, the commitments of all q_i are queued; -> closure"""
+    vals, cuts = [], []
+    for pe, length, pt in zip(pevals, lens, points):
+        v, qb, s_, b_, l_ = _open_items(be, powers_of_g, pe, length, np.asarray(pt, dtype=np.uint64).reshape(-1, 4))
+        vals.append(v)
+        cuts.append(q.add(s_, b_, l_, keep=[qb]))  # the q buffers must outlive the batched MSM
+    def fin():
+        return [(vals[k], q.res[cuts[k]]) for k in range(len(vals))]
+
+    fin.values = vals  # known as soon as the fold rounds ran (before the MSMs)
+    return fin
+
+
 def open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray]):
     """
     several independent opens (dpoly_comm.rs:299-325 each) with ALL their commitments in one batched MSM
     pass: -> list of (value [4], proofs [n_k, 18]).  Same outputs as calling open_ once per polynomial.
     """
-    vals, keep, srs, bufs, ms, cuts = [], [], [], [], [], [0]
-    for pe, length, pt in zip(pevals, lens, points):
-        v, q, s_, b_, l_ = _open_items(be, powers_of_g, pe, length, np.asarray(pt, dtype=np.uint64).reshape(-1, 4))
-        vals.append(v)
-        keep.append(q)  # the q buffers must outlive the batched MSM
-        srs += s_
-        bufs += b_
-        ms += l_
-        cuts.append(len(ms))
-    proofs = be.msm_g1_batch(srs, bufs, ms) if ms else np.zeros((0, 18), dtype=np.uint64)
-    return [(vals[k], proofs[cuts[k] : cuts[k + 1]]) for k in range(len(vals))]
+    q = MsmQueue(be)
+    fin = open_many_q(be, q, powers_of_g, pevals, lens, points)
+    q.run()
+    return fin()
 
 
 def open_(be, powers_of_g, peval, length: int, point: np.ndarray):
@@ -297,20 +356,31 @@ def open_(be, powers_of_g, peval, length: int, point: np.ndarray):
     return open_many(be, powers_of_g, [peval], [length], [point])[0]
 
 
-def d_commit_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], net: Net) -> np.ndarray:
-    """several d_commit (dpoly_comm.rs:276-297) in one MSM pass and one exchange -> [k, 18]"""
+def d_commit_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], net: Net):
     k = len(lens)
     if not k:
-        return np.zeros((0, 18), dtype=np.uint64)
+        return lambda: np.zeros((0, 18), dtype=np.uint64)
     srs = []
     for length in lens:
         level = length.bit_length() - 1
         assert level < len(powers_of_g) and length == 1 << level
         srs.append(powers_of_g[level])
-    local = be.msm_g1_batch(srs, list(pevals), list(lens))  # [k, 18]
-    got = net.all_gather(local)  # [party][k, 18]
-    ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
-    return be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in got], axis=1), ones)  # [k][party][18]
+    sl = q.add(srs, pevals, lens)
+
+    def fin():
+        got = net.all_gather(q.res[sl])  # [party][k, 18]
+        ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
+        return be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in got], axis=1), ones)  # [k][party][18]
+
+    return fin
+
+
+def d_commit_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], net: Net) -> np.ndarray:
+    """several d_commit (dpoly_comm.rs:276-297) in one MSM pass and one exchange -> [k, 18]"""
+    q = MsmQueue(be)
+    fin = d_commit_many_q(be, q, powers_of_g, pevals, lens, net)
+    q.run()
+    return fin()
 
 
 def d_commit(be, powers_of_g, peval, length: int, net: Net) -> np.ndarray:
@@ -318,47 +388,76 @@ def d_commit(be, powers_of_g, peval, length: int, net: Net) -> np.ndarray:
     return d_commit_many(be, powers_of_g, [peval], [length], net)[0]
 
 
-def c_commit(be, powers_of_g, pevals: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net) -> np.ndarray:
-    """dpoly_comm.rs:244-267: d_msm with bases_k = powers_of_g[log2(len_k * l)] -> [batch, 18]"""
+def _c_commit_bases(powers_of_g, lens, pp):
     bases = []
     for n in lens:
         level = (n * pp.l).bit_length() - 1
         assert level < len(powers_of_g) and n * pp.l == 1 << level  # :256-257
         bases.append(powers_of_g[level])
-    return d_msm(be, bases, pevals, lens, pp, net)
+    return bases
+
+
+def c_commit_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net):
+    return d_msm_q(be, q, _c_commit_bases(powers_of_g, lens, pp), pevals, lens, pp, net)
+
+
+def c_commit(be, powers_of_g, pevals: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net) -> np.ndarray:
+    """dpoly_comm.rs:244-267: d_msm with bases_k = powers_of_g[log2(len_k * l)] -> [batch, 18]"""
+    return d_msm(be, _c_commit_bases(powers_of_g, lens, pp), pevals, lens, pp, net)
+
+
+def d_open_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], net: Net):
+    """
+    several d_open (dpoly_comm.rs:355-398): local fold rounds and the exchange of the local VALUES happen now; the
+    commitments of the local opens and (leader) of the root opens on the gathered values are queued; -> closure
+    """
+    k = len(lens)
+    if not k:
+        return lambda: []
+    plog = net.n_parties.bit_length() - 1
+    pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
+    f_local = open_many_q(be, q, powers_of_g, pevals, lens, [p[plog:] for p in pts])
+    # the local values are known once the fold rounds ran: gather them now, queue the root opens with them
+    vals_mine = np.stack([np.asarray(v, dtype=np.uint64).reshape(4) for v in f_local.values])
+    vals = net.all_gather(vals_mine)  # [party][k, 4]
+    f_root = None
+    if net.is_leader:
+        root_tab = be.to_device(np.ascontiguousarray(np.stack([np.asarray(v).reshape(-1, 4) for v in vals], axis=1)))  # [k][party][4]
+        f_root = open_many_q(be, q, powers_of_g, [root_tab.at(32 * net.n_parties * i) for i in range(k)], [net.n_parties] * k, [p[:plog] for p in pts])
+        q.keep.append(root_tab)
+
+    def fin():
+        local = f_local()
+        cuts = [0]
+        for _, prf in local:
+            cuts.append(cuts[-1] + len(prf))
+        prfs = net.all_gather(np.concatenate([prf for _, prf in local]) if cuts[-1] else np.zeros((0, 18), dtype=np.uint64))
+        if not net.is_leader:
+            return [(ZERO.copy(), np.zeros((0, 18), dtype=np.uint64)) for _ in range(k)]
+        ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
+        total = cuts[-1]
+        pi = be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in prfs], axis=1), ones) if total else np.zeros((0, 18), dtype=np.uint64)
+        roots = f_root()
+        out = []
+        for i in range(k):
+            root_val, root_proofs = roots[i]
+            allp = list(root_proofs) + list(pi[cuts[i] : cuts[i + 1]])  # root proofs FIRST (:379-384)
+            out.append((root_val, np.stack(allp) if allp else np.zeros((0, 18), dtype=np.uint64)))
+        return out
+
+    return fin
 
 
 def d_open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], net: Net):
     """
-    several d_open (dpoly_comm.rs:355-398) at once: the local opens share one batched MSM pass, the
-    values and proofs travel in one exchange each, the leader's root opens share another MSM pass.
+    several d_open (dpoly_comm.rs:355-398) at once: the local opens and the leader's root opens share one batched
+    MSM pass, the values and proofs travel in one exchange each.
     -> list of (root value [4], root proofs ++ summed local proofs) for the leader, (0, []) for workers.
     """
-    k = len(lens)
-    if not k:
-        return []
-    plog = net.n_parties.bit_length() - 1
-    pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
-    local = open_many(be, powers_of_g, pevals, lens, [p[plog:] for p in pts])
-    cuts = [0]
-    for _, prf in local:
-        cuts.append(cuts[-1] + len(prf))
-    vals = net.all_gather(np.stack([np.asarray(v, dtype=np.uint64).reshape(4) for v, _ in local]))  # [party][k, 4]
-    prfs = net.all_gather(np.concatenate([prf for _, prf in local]) if cuts[-1] else np.zeros((0, 18), dtype=np.uint64))
-    if not net.is_leader:
-        return [(ZERO.copy(), np.zeros((0, 18), dtype=np.uint64)) for _ in range(k)]
-    ones = np.tile(int_to_limbs(1, 4), (net.n_parties, 1))
-    total = cuts[-1]
-    pi = be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in prfs], axis=1), ones) if total else np.zeros((0, 18), dtype=np.uint64)
-    # the k root tables (one value per party each) go up in ONE copy
-    root_tab = be.to_device(np.ascontiguousarray(np.stack([np.asarray(v).reshape(-1, 4) for v in vals], axis=1)))  # [k][party][4]
-    roots = open_many(be, powers_of_g, [root_tab.at(32 * net.n_parties * i) for i in range(k)], [net.n_parties] * k, [p[:plog] for p in pts])
-    out = []
-    for i in range(k):
-        root_val, root_proofs = roots[i]
-        allp = list(root_proofs) + list(pi[cuts[i] : cuts[i + 1]])  # root proofs FIRST (:379-384)
-        out.append((root_val, np.stack(allp) if allp else np.zeros((0, 18), dtype=np.uint64)))
-    return out
+    q = MsmQueue(be)
+    fin = d_open_many_q(be, q, powers_of_g, pevals, lens, points, net)
+    q.run()
+    return fin()
 
 
 def d_open(be, powers_of_g, peval, length: int, point: np.ndarray, net: Net):
@@ -369,38 +468,58 @@ def d_open(be, powers_of_g, peval, length: int, point: np.ndarray, net: Net):
     return d_open_many(be, powers_of_g, [peval], [length], [point], net)[0]
 
 
-def c_open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], pp: PackedSharingParams, net: Net):
-    """several c_open (dpoly_comm.rs:401-464) whose q_i commitments share ONE d_msm -> list of (value, proofs)"""
+def c_open_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], pp: PackedSharingParams, net: Net):
+    """several c_open (dpoly_comm.rs:401-464) whose q_i commitments share ONE queued d_msm; -> closure"""
     k = len(lens)
     pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
-    vals, keep, bufs, ms, cuts = [], [], [], [], [0]
+    vals, bufs, ms, cuts = [], [], [], [0]
     for pe, length, pt in zip(pevals, lens, pts):
         n = length.bit_length() - 1
-        q, value = be.open_rounds(pe, length, pt[:n])
-        keep.append(q)
+        qb, value = be.open_rounds(pe, length, pt[:n])
+        q.keep.append(qb)
         vals.append(value)
         off, m = 0, length
         for _ in range(n):
             h = m // 2
-            bufs.append(q.at(32 * off))
+            bufs.append(qb.at(32 * off))
             ms.append(h)
             off += h
             m = h
         cuts.append(len(ms))
-    com = c_commit(be, powers_of_g, bufs, ms, pp, net) if ms else np.zeros((0, 18), dtype=np.uint64)
-    out = []
+    f_com = c_commit_q(be, q, powers_of_g, bufs, ms, pp, net) if ms else (lambda: np.zeros((0, 18), dtype=np.uint64))
+    # phase 2 (:440-462): pss2ss of the last value, log2(l) more rounds on the l-vector; its MSMs are queued too
+    tails = []
     for i in range(k):
-        res = list(com[cuts[i] : cuts[i + 1]])
         cur = _fr_vec_to_ints(pss2ss(vals[i], pp, net))
         pt = _fr_vec_to_ints(pts[i])
+        fins = []
         for r in range(pp.l.bit_length() - 1):
             h = len(cur) // 2
             qi = [(cur[j + h] - cur[j]) % R_MOD for j in range(h)]
             level = (len(qi) * pp.l).bit_length() - 1
-            res.append(be.msm_g1(powers_of_g[level], be.to_device(_ints_to_fr(qi)), len(qi)))
+            d_qi = be.to_device(_ints_to_fr(qi))
+            sl = q.add([powers_of_g[level]], [d_qi], [len(qi)], keep=[d_qi])
+            fins.append(sl)
             cur = [(cur[j] * (1 - pt[r]) + cur[j + h] * pt[r]) % R_MOD for j in range(h)]
-        out.append((fr_mont(cur[0]), np.stack(res) if res else np.zeros((0, 18), dtype=np.uint64)))
-    return out
+        tails.append((fr_mont(cur[0]), fins))
+
+    def fin():
+        com = f_com()
+        out = []
+        for i in range(k):
+            res = list(com[cuts[i] : cuts[i + 1]]) + [q.res[sl][0] for sl in tails[i][1]]
+            out.append((tails[i][0], np.stack(res) if res else np.zeros((0, 18), dtype=np.uint64)))
+        return out
+
+    return fin
+
+
+def c_open_many(be, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], pp: PackedSharingParams, net: Net):
+    """several c_open (dpoly_comm.rs:401-464) whose q_i commitments share ONE d_msm -> list of (value, proofs)"""
+    q = MsmQueue(be)
+    fin = c_open_many_q(be, q, powers_of_g, pevals, lens, points, pp, net)
+    q.run()
+    return fin()
 
 
 def c_open(be, powers_of_g, peval, length: int, point: np.ndarray, pp: PackedSharingParams, net: Net):

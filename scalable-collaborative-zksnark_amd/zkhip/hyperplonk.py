@@ -122,9 +122,12 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
         s_dev = be.to_device(np.concatenate(net.all_gather(local_s_l.download((4 * M // npar // l, 4)))))
     # 2.b (commit of local_s) and the d_open of local_s in 2.d are independent of everything below: they ride
     # in the batched passes of :363-407 (same positions in the output lists as in the reference)
+    # every MSM of the step is queued and runs in ONE batched pass at its end (dp.MsmQueue); the closures below put
+    # the results at the reference's positions.  Exchanges keep the reference's order on every party.
+    q = dp.MsmQueue(be)
     wiring_proofs.append(dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net))  # 2.c
     # 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
-    wiring_opens += dp.c_open_many(be, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net)
+    f_copen = dp.c_open_many_q(be, q, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net)
     # 2.e (:322-340)
     hlen = 4 * M // npar
     num = be.fr_axpb(local_s_p, T["sid_p"], pk.alpha, pk.beta, hlen)
@@ -133,9 +136,9 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     subtree, top = dp.d_acc_product(be, h_p, hlen, net)  # :342
     v1x = _at(subtree, 32 * hlen)  # tree[N..]
     vx0, vx1 = be.fr_deinterleave(subtree, hlen)  # tree[0::2], tree[1::2]  :344-359
-    # :363-380 / :383-407: independent commits / opens -> one MSM pass and one exchange each
+    # :363-380 / :383-407: independent commits / opens
     tabs8 = [T["ssigma_p"], T["sid_p"], h_p, num, den, v1x, vx0, vx1]
-    wiring_commits += list(dp.d_commit_many(be, dc, [local_s_p] + tabs8, [4 * M // npar] + [hlen] * 8, net))  # 2.b, then :363-380
+    f_dcommit = dp.d_commit_many_q(be, q, dc, [local_s_p] + tabs8, [4 * M // npar] + [hlen] * 8, net)  # 2.b, then :363-380
     lay_tabs, lay_lens, lay_pts = [local_s_p] + tabs8[:5], [4 * M // npar] + [hlen] * 5, [pk.challenge_r2] * 6  # 2.d, then :383-407
     dsp = lambda f, g, length, ch: dp.d_sumcheck_product(be, f, g, length, ch, net)
     wiring_proofs.append(dsp(den, T["eq_r2_p"], hlen, pk.challenge_r2))  # 2.e.1 :411-413
@@ -157,22 +160,31 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
         for k in cur:  # current = current[len/2..]
             cur[k] = _at(cur[k], 32 * (clen // 2))
         clen //= 2
-    # the opens of local_s, of the five tables and of all layers are independent of each other: one batched
-    # pass, results in the reference's order
-    wiring_opens += dp.d_open_many(be, dc, lay_tabs, lay_lens, lay_pts, net)
+    # the opens of local_s, of the five tables and of all layers are independent of each other
+    f_dopen = dp.d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net)
+    f_top_commits, f_top_opens, top_proofs = [], None, []
     if top is not None:  # leader-only tail on the N_p-leaf top tree (:480-511)
         tt = np.asarray(top, dtype=np.uint64).reshape(-1, 4)
         half = len(tt) // 2
         lv1x, lvx0, lvx1 = tt[half:], tt[0::2], tt[1::2]
         chs = pk.challenge_r2[:sbits]
-        for v in (lvx0, lvx1, lv1x):
-            d = be.to_device(np.ascontiguousarray(v))
-            wiring_commits.append(dp.commit(be, dc, d, len(v)))
-            wiring_opens.append(dp.open_(be, dc, d, len(v), chs))
-        d1, d0, dd1 = be.to_device(np.ascontiguousarray(lv1x)), be.to_device(np.ascontiguousarray(lvx0)), be.to_device(np.ascontiguousarray(lvx1))
-        wiring_proofs.append(dp.sumcheck_product(be, eq_top, d1, len(lv1x), chs))
-        wiring_proofs.append(dp.sumcheck_product(be, eq_top, d0, len(lvx0), chs))
-        wiring_proofs.append(dp.sumcheck_product(be, d0, dd1, len(lvx0), chs))
+        dv = [be.to_device(np.ascontiguousarray(v)) for v in (lvx0, lvx1, lv1x)]
+        f_top_commits = [dp.commit_q(q, dc, d, len(v)) for d, v in zip(dv, (lvx0, lvx1, lv1x))]
+        f_top_opens = dp.open_many_q(be, q, dc, dv, [len(lvx0), len(lvx1), len(lv1x)], [chs] * 3)
+        q.keep += dv
+        d0, dd1, d1 = dv
+        top_proofs.append(dp.sumcheck_product(be, eq_top, d1, len(lv1x), chs))
+        top_proofs.append(dp.sumcheck_product(be, eq_top, d0, len(lvx0), chs))
+        top_proofs.append(dp.sumcheck_product(be, d0, dd1, len(lvx0), chs))
+    q.run()
+    wiring_opens += f_copen()                 # 2.d
+    wiring_commits += list(f_dcommit())       # 2.b, then :363-380
+    wiring_opens += f_dopen()
+    if top is not None:
+        for fc, fo in zip(f_top_commits, f_top_opens()):  # (commit, open) per table, in the reference's order
+            wiring_commits.append(fc())
+            wiring_opens.append(fo)
+        wiring_proofs += top_proofs
     return wiring_proofs, wiring_commits, wiring_opens
 
 
@@ -198,9 +210,13 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     cc, dc = pk.c_commitment, pk.d_commitment
     com = {}
     names_c, names_d = ("a_evals", "b_evals", "c_evals"), ("I_p", "S1_p", "S2_p")
-    for name, cm in zip(names_c, dp.c_commit(be, cc, [T[x] for x in names_c], [L[x] for x in names_c], pp, net)):
+    q = dp.MsmQueue(be)  # both commit families in one batched MSM pass
+    f_c = dp.c_commit_q(be, q, cc, [T[x] for x in names_c], [L[x] for x in names_c], pp, net)
+    f_d = dp.d_commit_many_q(be, q, dc, [T[x] for x in names_d], [L[x] for x in names_d], net)
+    q.run()
+    for name, cm in zip(names_c, f_c()):
         com[name] = cm
-    for name, cm in zip(names_d, dp.d_commit_many(be, dc, [T[x] for x in names_d], [L[x] for x in names_d], net)):
+    for name, cm in zip(names_d, f_d()):
         com[name] = cm
     tm.end()
 
@@ -227,9 +243,13 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     # Open (:517-553)
     tm.start("Open")
     gate_commitments = []
-    for name, op in zip(names_c, dp.c_open_many(be, cc, [T[x] for x in names_c], [L[x] for x in names_c], [pk.challenge] * 3, pp, net)):
+    q = dp.MsmQueue(be)
+    f_c = dp.c_open_many_q(be, q, cc, [T[x] for x in names_c], [L[x] for x in names_c], [pk.challenge] * 3, pp, net)
+    f_d = dp.d_open_many_q(be, q, dc, [T[x] for x in names_d], [L[x] for x in names_d], [pk.challenge] * 3, net)
+    q.run()
+    for name, op in zip(names_c, f_c()):
         gate_commitments.append((com[name], op))
-    for name, op in zip(names_d, dp.d_open_many(be, dc, [T[x] for x in names_d], [L[x] for x in names_d], [pk.challenge] * 3, net)):
+    for name, op in zip(names_d, f_d()):
         gate_commitments.append((com[name], op))
     tm.end()
     tm.end()
