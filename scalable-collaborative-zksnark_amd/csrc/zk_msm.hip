@@ -488,7 +488,8 @@ __global__ void __launch_bounds__(kSortThreads) k_part_scatter_staged(const u32*
 __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restrict__ part_idx, const unsigned short* __restrict__ part_low,
                                                               size_t row_len, u32 np, int low_bits, int idx_bits, size_t nb,
                                                               const u32* __restrict__ base, const u32* __restrict__ rowtot,
-                                                              u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ sorted) {
+                                                              uint2* __restrict__ oc, u32 T, size_t tiles_per_w, u32* __restrict__ tile_b,
+                                                              u32* __restrict__ sorted) {
     __shared__ u32 cnt[kMaxLow];
     __shared__ u32 sh[kSortThreads];
     const u32 nthr = blockDim.x;
@@ -512,13 +513,16 @@ __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restric
     u32 sum = 0;
     for (u32 i = lo; i < hi; i++) sum += cnt[i];
     u32 run = s + block_exclusive_scan(sum, sh, nullptr);
-    u32* cnt_out = counts + (size_t)row * nb + (size_t)p * nlow;
-    u32* off_out = offsets + (size_t)row * nb + (size_t)p * nlow;
+    // (offset, count) of every bucket as one 8-byte record, and for every tile of the accumulation the bucket
+    // its first entry falls into (tile t starts at entry t * T): the accumulation starts without a search
+    uint2* oc_out = oc + (size_t)row * nb + (size_t)p * nlow;
+    u32* tile_out = tile_b + (size_t)row * tiles_per_w;
     for (u32 i = lo; i < hi; i++) {
         const u32 v = cnt[i];
-        cnt_out[i] = v;
-        off_out[i] = run;
+        oc_out[i] = make_uint2(run, v);
         cnt[i] = run;  // becomes the cursor of bucket i
+        if (v)
+            for (u32 t = (run + T - 1) / T; t <= (run + v - 1) / T; t++) tile_out[t] = p * nlow + i;
         run += v;
     }
     __syncthreads();
@@ -540,8 +544,8 @@ __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restric
 // ---------------------------------------------------------------------------------------
 template <class Cv>
 __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict__ items, int rows_per_item,
-                                                    const u32* __restrict__ sorted, const u32* __restrict__ offsets,
-                                                    const u32* __restrict__ counts, size_t ns, u32 nsi, size_t nb, u32 T,
+                                                    const u32* __restrict__ sorted, const uint2* __restrict__ oc_all,
+                                                    const u32* __restrict__ tile_b, size_t ns, u32 nsi, size_t nb, u32 T,
                                                     size_t tiles_per_w, size_t total_tiles, void* __restrict__ buckets,
                                                     void* __restrict__ heads, void* __restrict__ tails) {
     const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
@@ -557,21 +561,15 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
         u32 win = v / nsi;
         return (size_t)win * it.pstride + (v - win * nsi);
     };
-    const u32* off = offsets + w * nb;
-    const u32* cnt = counts + w * nb;
-    const u32 nw = off[nb - 1] + cnt[nb - 1];  // entries of this window (zero digits are skipped)
+    const uint2* oc = oc_all + w * nb;
+    const uint2 last = oc[nb - 1];
+    const u32 nw = last.x + last.y;  // entries of this window (zero digits are skipped)
     const u32 e0 = (u32)t * T;
     if (e0 >= nw) return;
     const u32 e1 = (e0 + T < nw) ? e0 + T : nw;
-    // bucket holding entry e0: the largest b with off[b] <= e0 (ties = empty buckets, skipped)
-    u32 lo = 0, hi = (u32)nb - 1;
-    while (lo < hi) {
-        u32 mid = (lo + hi + 1) >> 1;
-        if (off[mid] <= e0) lo = mid;
-        else hi = mid - 1;
-    }
-    u32 b = lo;
-    u32 bstart = off[b], bend = bstart + cnt[b];
+    u32 b = tile_b[g];  // the bucket holding entry e0 (written by k_part_sort)
+    uint2 cur_b = oc[b];
+    u32 bstart = cur_b.x, bend = cur_b.x + cur_b.y;
     u32 ps = e0;  // start of the current run
     const u32* run = sorted + w * ns;
     typename Cv::Xyzz acc;
@@ -584,8 +582,9 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
             else Cv::store(heads, g, acc);                            // started before this tile
             do {
                 b++;
-                bstart = off[b];
-                bend = bstart + cnt[b];
+                cur_b = oc[b];
+                bstart = cur_b.x;
+                bend = cur_b.x + cur_b.y;
             } while (bend == bstart);
             ps = e;
             Cv::set_inf(acc);
@@ -616,7 +615,7 @@ struct NarrowRows {
 // span more than kLongSpan tiles (skewed scalars: many equal digits) are queued for k_fixup_long.
 static constexpr u32 kLongSpan = 24;
 template <class Cv>
-__global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, NarrowRows nr, u32 T,
+__global__ void __launch_bounds__(kBlk) k_fixup(const uint2* __restrict__ oc, size_t nb, NarrowRows nr, u32 T,
                                               size_t tiles_per_w, size_t total, void* __restrict__ buckets,
                                               const void* __restrict__ heads, const void* __restrict__ tails,
                                               u32* __restrict__ long_count, u32* __restrict__ long_list) {
@@ -624,7 +623,8 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets,
     if (g >= total) return;
     const size_t w = g / nb;
     if (nr.narrow(w) && (g % nb) >= nb / 2) return;  // never populated, never read by the reduction
-    const u32 s = offsets[g], c = counts[g];
+    const uint2 ocg = oc[g];
+    const u32 s = ocg.x, c = ocg.y;
     if (c == 0) {
         typename Cv::Xyzz z;
         Cv::set_inf(z);
@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const u32* __restrict__ offsets,
 
 // the same with one bucket per QUAD of lanes (small and mid-size MSMs: the chain of dependent additions
 // is pure latency, a quad runs each in 4 multiplication rounds instead of 13)
-__global__ void __launch_bounds__(kBlk) k_fixup_quad(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, NarrowRows nr, u32 T,
+__global__ void __launch_bounds__(kBlk) k_fixup_quad(const uint2* __restrict__ oc, size_t nb, NarrowRows nr, u32 T,
                                                    size_t tiles_per_w, size_t total, void* __restrict__ buckets,
                                                    const void* __restrict__ heads, const void* __restrict__ tails,
                                                    u32* __restrict__ long_count, u32* __restrict__ long_list) {
@@ -656,7 +656,8 @@ __global__ void __launch_bounds__(kBlk) k_fixup_quad(const u32* __restrict__ off
     if (g >= total) return;
     const size_t w = g / nb;
     if (nr.narrow(w) && (g % nb) >= nb / 2) return;  // never populated, never read by the reduction
-    const u32 s = offsets[g], c = counts[g];
+    const uint2 ocg = oc[g];
+    const u32 s = ocg.x, c = ocg.y;
     if (c == 0) {
         f30_store_chunks(buckets, g, 3 * role, f30_zero());
         return;
@@ -676,7 +677,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup_quad(const u32* __restrict__ off
 
 // one workgroup per long bucket: strided partial sums per lane, then an LDS tree
 template <class Cv>
-__global__ void __launch_bounds__(kBlk) k_fixup_long(const u32* __restrict__ offsets, const u32* __restrict__ counts, size_t nb, u32 T,
+__global__ void __launch_bounds__(kBlk) k_fixup_long(const uint2* __restrict__ oc, size_t nb, u32 T,
                                                    size_t tiles_per_w, void* __restrict__ buckets, const void* __restrict__ heads,
                                                    const void* __restrict__ tails, const u32* __restrict__ long_count,
                                                    const u32* __restrict__ long_list) {
@@ -685,7 +686,8 @@ __global__ void __launch_bounds__(kBlk) k_fixup_long(const u32* __restrict__ off
     for (u32 i = blockIdx.x; i < nlong; i += gridDim.x) {
         const size_t g = long_list[i];
         const size_t w = g / nb;
-        const u32 s = offsets[g], e = s + counts[g];
+        const uint2 ocg = oc[g];
+        const u32 s = ocg.x, e = s + ocg.y;
         const u32 t0 = s / T, t1 = (e - 1) / T;
         const size_t base = w * tiles_per_w;
         typename Cv::Xyzz acc;
@@ -1184,7 +1186,7 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
         cl.cc_elems = cl.rows * (size_t)cl.np * cl.nchunks + 2 * cl.rows * (size_t)cl.np + cl.rows;  // hist, total, base, rowtot
         // classes run concurrently on separate streams: each gets its own region of every arena
         const size_t total64 = (cl.total + 63) & ~(size_t)63, tiles64 = (cl.total_tiles + 63) & ~(size_t)63;  // XYZZ arrays: blocks of 64
-        const size_t want_b[10] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4, total64 * Cv::kXyzzBytes, total64 * Cv::kXyzzBytes,
+        const size_t want_b[10] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4 + cl.total_tiles * 4, total64 * Cv::kXyzzBytes, total64 * Cv::kXyzzBytes,
                                    2 * tiles64 * Cv::kXyzzBytes, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
                                    cl.cc_elems * 4, cl.rows * cl.row_len * 2};
         for (int i = 0; i < 10; i++) {
@@ -1215,7 +1217,8 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
     // streams (the small ones are pure launch/latency chains and overlap with the big one).
     // Phase timers: sort of the first class, accumulation from the first part's launch to the last
     // part's end, then fix-up / reduction of the last part -- i.e. the exposed time of each phase. ----
-    const bool multi = classes.size() > 1;
+    static const bool serial_env = getenv("ZK_MSM_SERIAL") != nullptr;  // diagnostics: all classes on the ctx stream (per-kernel times = work)
+    const bool multi = classes.size() > 1 && !serial_env;
     if (multi) {
         hipEventRecord(ctx->ev_fork, ctx->stream);
         for (int k = 0; k < zk_ctx::kAux; k++) hipStreamWaitEvent(ctx->aux[k], ctx->ev_fork, 0);
@@ -1239,8 +1242,8 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
         u32* sorted = digits;  // the digits are dead once partitioned: the sorted entries take their place
         u32* part_idx = (u32*)((char*)buf[1] + cl.off[1]);
         unsigned short* part_low = (unsigned short*)((char*)buf[9] + cl.off[9]);
-        u32* counts = (u32*)((char*)buf[2] + cl.off[2]);
-        u32* offsets = counts + total;
+        uint2* oc = (uint2*)((char*)buf[2] + cl.off[2]);  // (offset, count) per bucket
+        u32* tile_b = (u32*)(oc + total);                // first bucket of every tile
         void* bufA = (char*)buf[3] + cl.off[3];
         void* bufB = (char*)buf[4] + cl.off[4];
         void* heads = (char*)buf[5] + cl.off[5];
@@ -1282,25 +1285,25 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
                                    cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low);
             }
             hipLaunchKernelGGL(k_part_sort, g_parts, dim3(cl.row_len / cl.np >= 4096 ? kSortThreads : 256), 0, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len,
-                               cl.np, cl.low_bits, cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, counts, offsets, sorted);
+                               cl.np, cl.low_bits, cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, oc, cl.T, cl.tiles_per_w, tile_b, sorted);
         }
         if (t_first) hipEventRecord(ctx->ev[1], st);
         if (cl.part > 0) hipStreamWaitEvent(st, ctx->ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
         hipLaunchKernelGGL((k_accum_tiles<Cv>), dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
-                           (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const u32*)offsets, (const u32*)counts, cl.row_len,
+                           (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const uint2*)oc, (const u32*)tile_b, cl.row_len,
                            (u32)ns, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
         if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(ctx->ev_part[cl.part % zk_ctx::kParts], st);
         if (t_last) hipEventRecord(ctx->ev[4], st);
         const NarrowRows nrw{cl.rpi, cl.w0, cl.narrow_from};
         if (Cv::kQuad && total <= fixq_max)
-            hipLaunchKernelGGL(k_fixup_quad, dim3((unsigned)((4 * total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
-                               (const u32*)counts, nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
+            hipLaunchKernelGGL(k_fixup_quad, dim3((unsigned)((4 * total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const uint2*)oc,
+                               nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                                longs + 1);
         else
-            hipLaunchKernelGGL((k_fixup<Cv>), dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const u32*)offsets,
-                               (const u32*)counts, nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
+            hipLaunchKernelGGL((k_fixup<Cv>), dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const uint2*)oc,
+                               nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                                longs + 1);
-        hipLaunchKernelGGL((k_fixup_long<Cv>), dim3(512), dim3(Cv::kXyzzBytes == 192 ? kBlk : kBlk / 2), (size_t)48 * 1024, st, (const u32*)offsets, (const u32*)counts, nb, cl.T,
+        hipLaunchKernelGGL((k_fixup_long<Cv>), dim3(512), dim3(Cv::kXyzzBytes == 192 ? kBlk : kBlk / 2), (size_t)48 * 1024, st, (const uint2*)oc, nb, cl.T,
                            cl.tiles_per_w, bufA, (const void*)heads, (const void*)tails, (const u32*)longs, (const u32*)(longs + 1));
         if (t_last) hipEventRecord(ctx->ev[2], st);
         void* in = bufA;
