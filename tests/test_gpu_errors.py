@@ -66,3 +66,28 @@ def test_single_element_tables(ctx):
     assert tr.shape[0] == 0 and (lf == t[0]).all() and (lg == t[0]).all()
     q, v = ctx.open_rounds(ctx.to_device(t), 1, np.zeros((0, 4), dtype=np.uint64))
     assert (v == t[0]).all()
+
+
+def test_ctx_on_every_visible_gpu_in_one_process(co):
+    """
+    one process, one ctx per GPU (the reference's task-per-party model): every kernel attribute the library sets
+    (dynamic LDS of the sumcheck stages, of the staged scatter) must hold on EVERY device, not only the first one
+    that launched.  Runs the LDS-heavy paths on each visible GPU (one on a 1-GPU box).
+    """
+    import zkhip
+    from helpers import rand_fr
+
+    ndev = zkhip.lib().zk_device_count()
+    assert ndev >= 1
+    f, g, ch = rand_fr(1 << 12, 1), rand_fr(1 << 12, 2), rand_fr(12, 3)
+    etr, elf, elg = co.sumcheck_product_rounds(f, g, ch)
+    ctxs = [zkhip.Ctx(d) for d in range(ndev)]
+    try:
+        for c in ctxs:
+            tr, lf, lg = c.sumcheck_product(c.to_device(f), c.to_device(g), 1 << 12, ch)
+            assert (tr == etr).all() and (lf == elf).all() and (lg == elg).all()
+            pairs, last = c.sumcheck(c.to_device(f), 1 << 12, ch)
+            assert (pairs == co.sumcheck(f, ch)[:12]).all()
+    finally:
+        for c in ctxs:
+            c.close()
