@@ -531,6 +531,20 @@ def c_open(be, powers_of_g, peval, length: int, point: np.ndarray, pp: PackedSha
     return c_open_many(be, powers_of_g, [peval], [length], [point], pp, net)[0]
 
 
+def verify(powers_of_g2, commitment: np.ndarray, value: np.ndarray, proof: np.ndarray, point: np.ndarray, g1=None) -> bool:
+    """
+    PolynomialCommitment::verify (dpoly_comm.rs:466-484): e(C - value g1, g2) == sum_i e(proof_i, powers_of_g2[i+1] - point_i g2).
+    commitment [18] / proof [n, 18]: normalised Jacobian as the library returns them; value [4], point [n, 4]: Montgomery Fr;
+    powers_of_g2: affine G2 points as python ints (zkhip.pairing.powers_of_g2); g1 = powers_of_g[0][0] (default: the generator).
+    Host big-int pairing (zkhip/pairing.py): off the hot path, seconds per call.
+    """
+    from . import pairing as pr
+    from .field import jacobian_to_affine_ints
+
+    pts = [jacobian_to_affine_ints(p) for p in np.asarray(proof, dtype=np.uint64).reshape(-1, 18)]
+    return pr.verify(g1 or pr.G1_GEN, powers_of_g2, jacobian_to_affine_ints(commitment), fr_from_mont(value), pts, _fr_vec_to_ints(point))
+
+
 def fix_variable(be, evaluations, length: int, points: np.ndarray):
     """mle.rs:88-105 -> device buffer of length >> min(n, len(points))"""
     return be.fold(evaluations, length, points)
