@@ -61,7 +61,7 @@ __device__ __forceinline__ void block_reduce_store(Fr (&acc)[NS], uint4* lds, vo
 // one sumcheck / fold / open round on the register-resident slice e[0 .. 2*half)
 // MODE 0: plain sums (2), 1: product sums (3), 2: fold only, 3: open (q written by caller)
 template <int MODE>
-__device__ __forceinline__ void round_pair(Fr& flo, const Fr& fhi, Fr& glo, const Fr& ghi, const Fr& r, Fr* acc, Fr& q_out) {
+__device__ __forceinline__ void round_pair(Fr& flo, const Fr& fhi, Fr& glo, const Fr& ghi, const Fr& r, Fr* acc, Fr& q_out, bool with_t1) {
     Fr df = fr_sub(fhi, flo);
     if (MODE == 0) {
         acc[0] = fr_add(acc[0], flo);
@@ -70,7 +70,9 @@ __device__ __forceinline__ void round_pair(Fr& flo, const Fr& fhi, Fr& glo, cons
     if (MODE == 1) {
         Fr dg = fr_sub(ghi, glo);
         acc[0] = fr_add(acc[0], fr_mul(flo, glo));
-        acc[1] = fr_add(acc[1], fr_mul(fhi, ghi));
+        // t1 = sum f_hi g_hi is only computed in the very first round of a call: afterwards t0 + t1 of a round equals the
+        // previous round polynomial at its challenge (dsumcheck.rs:558-588 read backwards), the host fills it in
+        if (with_t1) acc[1] = fr_add(acc[1], fr_mul(fhi, ghi));
         // (2 f_hi - f_lo)(2 g_hi - g_lo) = (f_hi + df)(g_hi + dg)      dsumcheck.rs:55-72
         acc[2] = fr_add(acc[2], fr_mul(fr_add(fhi, df), fr_add(ghi, dg)));
         glo = fr_add(glo, fr_mul(r, dg));
@@ -94,7 +96,7 @@ struct ModeTraits {
 template <int K, int MODE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, (K == 3 && MODE == 1) ? 1 : 2))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
                                                void* __restrict__ go, size_t m, ChalArgs ch, void* __restrict__ partials,
-                                               void* __restrict__ qbase) {
+                                               void* __restrict__ qbase, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     constexpr int E = 1 << K;
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
                 if (s < half) {
                     Fr qv;
                     round_pair<MODE>(ef[s], ef[s + half], eg[TWO ? s : 0], eg[TWO ? s + half : 0], ch.c[rd],
-                                     &acc[(W == 0) ? 0 : rd * W], qv);
+                                     &acc[(W == 0) ? 0 : rd * W], qv, t1mode == 2 || (t1mode == 1 && rd == 0));
                     if (MODE == 3) fr_store(qbase, qoff + j + (size_t)s * q, qv);
                 }
             }
@@ -209,7 +211,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict__ f, const void* __restrict__ g, unsigned G, unsigned E,
                                                        int elog, int rounds, TailChal chal, void* __restrict__ sums,
                                                        void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go,
-                                                       ReducePlan plan, void* __restrict__ red_out) {
+                                                       ReducePlan plan, void* __restrict__ red_out, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     extern __shared__ uint4 lds[];
@@ -268,6 +270,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
             const unsigned u = E - p;  // in (E/2^(k+1), E/2^k]
             const int k = elog - (32 - __clz(u - 1));
             const unsigned hk = E >> (k + 1), t = p - (E - (E >> k)), off = lvl_off(E, k);
+            if (ws == 1 && !(t1mode == 2 || (t1mode == 1 && k == 0))) continue;  // t1 is derived on the host (see round_pair)
             Fr a, b;
             if (ws == 0) {
                 a = fr_load(tf, off + t);
@@ -287,6 +290,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
     const int grp = tid >> 5, l32 = tid & 31;
     for (int vid = grp; vid < rounds * W; vid += kLocalThreads / 32) {
         const int k = vid / W, ws = vid - k * W;
+        if (MODE == 1 && ws == 1 && !(t1mode == 2 || (t1mode == 1 && k == 0))) continue;
         const unsigned cnt = E >> (k + 1);
         const uint4* src = (MODE == 1) ? park : tf;
         const unsigned base = (MODE == 1) ? ws * P + (E - (E >> k)) : lvl_off(E, k) + ws * cnt;  // mode 0: lo half | hi half of level k
@@ -315,7 +319,7 @@ static size_t pass_blocks(zk_ctx* ctx, size_t m, int k) {
 }
 template <int K, int MODE>
 static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void* go, size_t m, const uint64_t* chal, void* partials,
-                       void* qbase) {
+                       void* qbase, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
     const size_t blocks = pass_blocks(ctx, m, K);
     ChalArgs ch;
@@ -324,7 +328,7 @@ static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void
     const size_t lds = (W != 0) ? (size_t)K * W * kBlock * 32 : 0;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_pass<K, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
-                       qbase);
+                       qbase, t1mode);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -340,9 +344,134 @@ static int sc_pass_k(int mode) {
     return mode == 1 ? kp : k0;
 }
 
+// ---- host Fr arithmetic on Montgomery-form values (4 x u64): the product sumcheck's t1 = sum f_hi g_hi of every round
+// after the first is NOT computed on the device: t0 + t1 of round k equals the round polynomial of round k-1 -- the
+// parabola through (0, t0), (1, t1), (2, t2) -- at the challenge of round k-1 (the verifier's check, dsumcheck.rs:558-588,
+// read as an identity: sum_j f'_j g'_j with f' = f_lo + r (f_hi - f_lo)).  Exact field arithmetic: the same bits. ----
+namespace hfr {
+typedef unsigned __int128 u128;
+static const uint64_t RM[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+static const uint64_t INV = 0xfffffffeffffffffULL;  // -r^-1 mod 2^64
+struct F {
+    uint64_t l[4];
+};
+static inline bool geq_r(const uint64_t* a) {
+    for (int i = 3; i >= 0; i--) {
+        if (a[i] > RM[i]) return true;
+        if (a[i] < RM[i]) return false;
+    }
+    return true;
+}
+static inline F add(const F& a, const F& b) {
+    F r;
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (u128)a.l[i] + b.l[i];
+        r.l[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (c || geq_r(r.l)) {
+        u128 bw = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 t = (u128)r.l[i] - RM[i] - (uint64_t)bw;
+            r.l[i] = (uint64_t)t;
+            bw = (t >> 64) & 1;
+        }
+    }
+    return r;
+}
+static inline F sub(const F& a, const F& b) {
+    F r;
+    u128 bw = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 t = (u128)a.l[i] - b.l[i] - (uint64_t)bw;
+        r.l[i] = (uint64_t)t;
+        bw = (t >> 64) & 1;
+    }
+    if (bw) {
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)r.l[i] + RM[i];
+            r.l[i] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    return r;
+}
+static inline F mul(const F& a, const F& b) {  // CIOS Montgomery multiplication, R = 2^256
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a.l[j] * b.l[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * INV;
+        c = ((u128)m * RM[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * RM[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    F r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || geq_r(r.l)) {
+        u128 bw = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 d = (u128)r.l[i] - RM[i] - (uint64_t)bw;
+            r.l[i] = (uint64_t)d;
+            bw = (d >> 64) & 1;
+        }
+    }
+    return r;
+}
+static inline F half(const F& a) {  // a / 2: (a + r) / 2 when a is odd
+    uint64_t t[5] = {a.l[0], a.l[1], a.l[2], a.l[3], 0};
+    if (t[0] & 1) {
+        u128 c = 0;
+        for (int i = 0; i < 4; i++) {
+            c += (u128)t[i] + RM[i];
+            t[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        t[4] = (uint64_t)c;
+    }
+    F r;
+    for (int i = 0; i < 4; i++) r.l[i] = (t[i] >> 1) | (t[i + 1] << 63);
+    return r;
+}
+}  // namespace hfr
+
+// sums: rounds x (t0, t1, t2) Montgomery Fr on the host; t1 of round 0 is the device's, every later one is derived
+static void derive_t1(uint64_t* sums, const uint64_t* chal, size_t rounds) {
+    using namespace hfr;
+    for (size_t rd = 1; rd < rounds; rd++) {
+        F a, b, c, x, t0;
+        std::memcpy(&a, sums + (rd - 1) * 12, 32);
+        std::memcpy(&b, sums + (rd - 1) * 12 + 4, 32);
+        std::memcpy(&c, sums + (rd - 1) * 12 + 8, 32);
+        std::memcpy(&x, chal + (rd - 1) * 4, 32);
+        std::memcpy(&t0, sums + rd * 12, 32);
+        // p(X) = a + X (B + X A),  A = (c - 2b + a) / 2,  B = (-c + 4b - 3a) / 2        dsumcheck.rs:562-575
+        const F b2 = add(b, b);
+        const F A = half(add(sub(c, b2), a));
+        const F B = half(sub(sub(add(b2, b2), c), add(add(a, a), a)));
+        const F px = add(a, mul(x, add(B, mul(x, A))));
+        const F t1 = sub(px, t0);
+        std::memcpy(sums + rd * 12 + 4, &t1, 32);
+    }
+}
+
 template <int MODE>
 static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, unsigned E, int rl, const uint64_t* chal, void* sums,
-                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out) {
+                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     TailChal tc;
@@ -360,7 +489,7 @@ static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, u
     // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_local<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(kLocalThreads), lds, ctx->stream, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
-                       rp ? *rp : none, red_out);
+                       rp ? *rp : none, red_out, t1mode);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -431,6 +560,9 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     const void* cg = d_g;
     size_t m = len, done = 0;
     int flip = 0;
+    // product sumcheck on tables from 2^18: t1 of every round after the first is derived on the host (derive_t1); below
+    // that size the host arithmetic (~0.2 us per round) costs more than the multiplications it saves
+    const bool derive = MODE == 1 && len >= ((size_t)1 << 18);
     ReducePlan rp;
     std::memset(&rp, 0, sizeof(rp));
     for (const Stage& st : plan) {
@@ -441,10 +573,11 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
         void* part = d_part ? d_part + st.part_off : nullptr;
         int rc;
-        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, k, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr);
-        else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
-        else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
-        else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb);
+        const int t1mode = !derive ? 2 : (done == 0 ? 1 : 0);  // t1 on the device: 2 every round, 1 the stage's first round only, 0 never
+        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, k, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, t1mode);
+        else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
+        else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
+        else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         if (rc) return rc;
         if (W != 0) {  // outputs of this stage: sums of rounds done .. done+k-1, consecutive in d_res
             rp.partials[rp.n] = part;
@@ -467,7 +600,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         void* fo = (MODE == 2) ? d_out : d_last_f;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
         int rc = launch_local<MODE>(ctx, cf, cg, 1u, (unsigned)m, rl, h_chal + 4 * done, (void*)(d_res + done * W * fr), qb, fo, d_last_g,
-                                    (W != 0 && rp.n) ? &rp : nullptr, (void*)d_res);
+                                    (W != 0 && rp.n) ? &rp : nullptr, (void*)d_res, !derive ? 2 : (done == 0 ? 1 : 0));
         if (rc) return rc;
     } else if (rounds == 0) {
         ZK_HIP(ctx, hipMemcpyAsync(d_out, d_f, len * fr, hipMemcpyDeviceToDevice, ctx->stream));
@@ -477,6 +610,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         if (!h) return ZK_ERR_OOM;
         ZK_HIP(ctx, hipMemcpyAsync(h, d_res, res_elems * fr, hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (derive) derive_t1((uint64_t*)h, h_chal, rounds);
         if (h_sums && rounds * W) std::memcpy(h_sums, h, rounds * W * fr);
         if (h_last_f) std::memcpy(h_last_f, h + rounds * W * fr, fr);
         if (TWO && h_last_g) std::memcpy(h_last_g, h + (rounds * W + 1) * fr, fr);

@@ -19,7 +19,7 @@ def test_sumcheck(ctx, co, length):
     assert (last == exp[n, 1]).all() and not exp[n, 0].any()
 
 
-@pytest.mark.parametrize("length", SIZES)
+@pytest.mark.parametrize("length", SIZES + [1 << 18, 1 << 19])  # from 2^18 the host derives t1 of the later rounds
 def test_sumcheck_product(ctx, co, length):
     n = length.bit_length() - 1
     f, g, chal = rand_fr(length, 300 + n), rand_fr(length, 400 + n), rand_fr(max(n, 1), 500 + n)
