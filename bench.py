@@ -56,7 +56,7 @@ def pmc_traffic(kernel: str):
         return None, None
     best = {}  # counter -> (dispatches, KB): the launch geometry with the most dispatches is the headline loop's
     for row in csv.reader(open(files[-1])):
-        if len(row) >= 4 and row[1] == kernel and row[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if len(row) >= 4 and kernel in row[1] and row[0] in ("FETCH_SIZE", "WRITE_SIZE"):
             disp, kb = int(row[-2]), float(row[-1])
             if row[0] not in best or disp > best[row[0]][0]:
                 best[row[0]] = (disp, kb)
@@ -201,7 +201,7 @@ def main():
         c = ctx.lib.zk_msm_window(n)
         windows = (129 + c - 1) // c  # scalars are split into two 128-bit halves (k = k1 + k2*lambda): 2n entries per window
         madds = 2.0 * n * windows  # one XYZZ mixed addition per entry per window
-        traffic, traffic_src = pmc_traffic("zk::k_accum_tiles") if args.log2n == 20 else (None, None)
+        traffic, traffic_src = pmc_traffic("k_accum_tiles") if args.log2n == 20 else (None, None)
         out = {
             "metric": "G1 scalar-muls/sec (d_msm) + Fr field-ops/sec (d_sumcheck), 2^20 shares, 1/2/4/8 GPU",
             "value": value,
