@@ -179,3 +179,38 @@ def test_permchecks_gpu_match_oracle_backed_run():
         exp = _run_perm(OracleBackend, n, which)
         got = _run_perm(lambda: zkhip.Ctx(0), n, which)
         assert _digest(got[0]) == _digest(exp[0]) and _digest(got[3]) == _digest(exp[3]), which
+
+
+def _run_l2(make_backend, n, fn_name):
+    from zkhip import hyperplonk as hp
+
+    pp = PackedSharingParams(2)  # l = 2: 16 parties, the packed maps are no longer the l = 1 closed forms
+
+    def party(net):
+        be = make_backend()
+        pk = PackedProvingParameters.new(n, pp, be, seed=700 + net.party_id, chal_seed=4711)
+        return getattr(hp, fn_name)(n, pk, pp, be, net, seed=800 + net.party_id)[0]
+
+    return LocalTestNet.simulate_network_round(pp.n, party)
+
+
+def test_dhyperplonk_l2_structure_cpu():
+    """packing factor 2 (16 parties): c_sumcheck_product gains log2(l) rounds, d_* leader rounds grow to log2(16)"""
+    n = 6  # the 16-leaf top tree needs d_commitment level 4 = n + 2 - log2(16) (dhyperplonk.rs:101)
+    res = _run_l2(OracleBackend, n, "dhyperplonk")
+    (gate_proofs, gate_comms), (w_proofs, w_commits, w_opens) = res[0]
+    assert all(p.shape == ((n - 1) + 1 + 1, 3, 4) for p in gate_proofs)  # log2(M / l) + log2(l) + 1
+    assert w_proofs[1].shape == ((n - 2) + 4, 3, 4)                      # log2(4M / 16) local + log2(16) leader rounds
+    assert w_opens[0][1].shape == ((n + 1) + 1, 18)                      # c_open(V): log2(4M / l) + log2(l) proofs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fn_name", ["dhyperplonk", "cpermcheck"])
+def test_l2_sixteen_parties_gpu_matches_oracle_backed_run(fn_name):
+    import zkhip
+
+    n = 6
+    exp = _run_l2(OracleBackend, n, fn_name)
+    got = _run_l2(lambda: zkhip.Ctx(0), n, fn_name)
+    for p in (0, 1, 15):
+        assert _digest(got[p]) == _digest(exp[p]), f"{fn_name}: party {p}"
