@@ -308,6 +308,12 @@ __device__ __forceinline__ void fp_store(void* base, size_t idx, const Fp<C>& a)
 // convenient aliases
 __device__ __forceinline__ Fr fr_load(const void* b, size_t i) { return fp_load<FrCfg>(b, i); }
 __device__ __forceinline__ void fr_store(void* b, size_t i, const Fr& a) { fp_store<FrCfg>(b, i, a); }
+__device__ __forceinline__ Fr fr_from_u4(const uint4& lo, const uint4& hi) {  // the two 16-byte halves of an element
+    Fr r;
+    r.l[0] = lo.x, r.l[1] = lo.y, r.l[2] = lo.z, r.l[3] = lo.w;
+    r.l[4] = hi.x, r.l[5] = hi.y, r.l[6] = hi.z, r.l[7] = hi.w;
+    return r;
+}
 __device__ __forceinline__ Fr fr_add(const Fr& a, const Fr& b) { return fp_add<FrCfg>(a, b); }
 __device__ __forceinline__ Fr fr_sub(const Fr& a, const Fr& b) { return fp_sub<FrCfg>(a, b); }
 __device__ __forceinline__ Fr fr_mul(const Fr& a, const Fr& b) { return fp_mul<FrCfg>(a, b); }

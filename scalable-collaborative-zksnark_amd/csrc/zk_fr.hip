@@ -16,6 +16,7 @@
 #include "zk_ctx.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -82,6 +83,64 @@ __device__ __forceinline__ void round_pair(Fr& flo, const Fr& fhi, Fr& glo, cons
     flo = fr_add(flo, fr_mul(r, df));
 }
 
+// ---------------------------------------------------------------------------------------
+// Lazily reduced sums of the product sumcheck: t0 = sum f_lo g_lo and t2 = sum (2 f_hi - f_lo)(2 g_hi - g_lo) of a round
+// are sums of PRODUCTS, so the HBM passes add the 512-bit integer products into a 544-bit integer (fp_mac_wide: the
+// multiplication half of a Montgomery multiplication, no reduction half, no modular addition) and the one Montgomery
+// reduction per sum happens on the host when the call ends: W0 + W1 R + W2 R^2 -> W0 R^-1 + W1 + W2 R (mod r), the same
+// canonical element the reference's reduce-every-product order gives.  2^25 products of factors < 2r fit 544 bits.
+// ---------------------------------------------------------------------------------------
+struct Wide {
+    u32 l[17];
+};
+static constexpr int kWideBytes = 80;  // 17 limbs + 3 words of padding: five 16-byte accesses per value
+__device__ __forceinline__ void wide_add(Wide& a, const Wide& b) {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 17; i++) a.l[i] = addc(a.l[i], b.l[i], c);
+}
+__device__ __forceinline__ Wide wide_shfl_down(const Wide& v, int off, int width) {
+    Wide o;
+#pragma unroll
+    for (int i = 0; i < 17; i++) o.l[i] = __shfl_down(v.l[i], off, width);
+    return o;
+}
+__device__ __forceinline__ void wide_store(void* base, size_t idx, const Wide& v) {
+    uint4* p = reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + idx * kWideBytes);
+#pragma unroll
+    for (int i = 0; i < 4; i++) p[i] = make_uint4(v.l[4 * i], v.l[4 * i + 1], v.l[4 * i + 2], v.l[4 * i + 3]);
+    p[4] = make_uint4(v.l[16], 0, 0, 0);
+}
+__device__ __forceinline__ Wide wide_load(const void* base, size_t idx) {
+    const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + idx * kWideBytes);
+    Wide v;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint4 x = p[i];
+        v.l[4 * i] = x.x, v.l[4 * i + 1] = x.y, v.l[4 * i + 2] = x.z, v.l[4 * i + 3] = x.w;
+    }
+    v.l[16] = p[4].x;
+    return v;
+}
+// a + b as 256-bit integers (both < r: no wrap), NOT reduced: a factor of a lazily reduced product
+__device__ __forceinline__ Fr fr_add_nored(const Fr& a, const Fr& b) {
+    Fr r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = addc(a.l[i], b.l[i], c);
+    return r;
+}
+// the product-sumcheck round on one pair with lazily reduced sums (see round_pair<1>)
+__device__ __forceinline__ void round_pair_lazy(Fr& flo, const Fr& fhi, Fr& glo, const Fr& ghi, const Fr& r, Wide& w0, Wide& w1, Wide& w2,
+                                                bool with_t1) {
+    const Fr df = fr_sub(fhi, flo), dg = fr_sub(ghi, glo);
+    fp_mac_wide(w0.l, flo, glo);
+    if (with_t1) fp_mac_wide(w1.l, fhi, ghi);
+    fp_mac_wide(w2.l, fr_add_nored(fhi, df), fr_add_nored(ghi, dg));  // (2 f_hi - f_lo)(2 g_hi - g_lo), factors < 2r   dsumcheck.rs:55-72
+    glo = fr_add(glo, fr_mul(r, dg));
+    flo = fr_add(flo, fr_mul(r, df));
+}
+
 template <int MODE>
 struct ModeTraits {
     static constexpr int W = (MODE == 0) ? 2 : (MODE == 1 ? 3 : 0);
@@ -101,11 +160,20 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     constexpr int E = 1 << K;
     constexpr int NS = (W == 0) ? 1 : K * W;
+    constexpr bool LAZY = (MODE == 1);      // lazily reduced sums: t0, t2 of each round + t1 of the first
+    constexpr int NW = LAZY ? 2 * K + 1 : 1;
     extern __shared__ uint4 lds[];
     const size_t q = m >> K;
-    Fr acc[NS];
+    Fr acc[LAZY ? 1 : NS];
+    Wide wacc[NW];
 #pragma unroll
-    for (int s = 0; s < NS; s++) acc[s] = fp_zero<FrCfg>();
+    for (int s = 0; s < (LAZY ? 1 : NS); s++) acc[s] = fp_zero<FrCfg>();
+    if (LAZY) {
+#pragma unroll
+        for (int a = 0; a < NW; a++)
+#pragma unroll
+            for (int i = 0; i < 17; i++) wacc[a].l[i] = 0;
+    }
 
     for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += (size_t)gridDim.x * kBlock) {
         Fr ef[E], eg[TWO ? E : 1];
@@ -125,8 +193,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
             for (int s = 0; s < E / 2; s++) {
                 if (s < half) {
                     Fr qv;
-                    round_pair<MODE>(ef[s], ef[s + half], eg[TWO ? s : 0], eg[TWO ? s + half : 0], ch.c[rd],
-                                     &acc[(W == 0) ? 0 : rd * W], qv, t1mode == 2 || (t1mode == 1 && rd == 0));
+                    if (LAZY)
+                        round_pair_lazy(ef[s], ef[s + half], eg[TWO ? s : 0], eg[TWO ? s + half : 0], ch.c[rd], wacc[LAZY ? 2 * rd : 0],
+                                        wacc[LAZY ? 2 * K : 0], wacc[LAZY ? 2 * rd + 1 : 0], t1mode != 0 && rd == 0);
+                    else
+                        round_pair<MODE>(ef[s], ef[s + half], eg[TWO ? s : 0], eg[TWO ? s + half : 0], ch.c[rd],
+                                         &acc[(W == 0) ? 0 : rd * W], qv, t1mode == 2 || (t1mode == 1 && rd == 0));
                     if (MODE == 3) fr_store(qbase, qoff + j + (size_t)s * q, qv);
                 }
             }
@@ -136,7 +208,20 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
         fr_store(fo, j, ef[0]);
         if (TWO) fr_store(go, j, eg[0]);
     }
-    if (W != 0) block_reduce_store<NS>(acc, lds, partials, blockIdx.x, gridDim.x);
+    if constexpr (LAZY) {
+        // one 544-bit partial per wave and sum: [(round * 3 + kind) * 4 gridDim + 4 block + wave], 80-byte slots
+        const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const size_t nbw = (size_t)gridDim.x * (kBlock / 64);
+#pragma unroll
+        for (int a = 0; a < NW; a++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wide_add(wacc[a], wide_shfl_down(wacc[a], off, 64));
+            const int slot = (a == 2 * K) ? 1 : (a >> 1) * 3 + ((a & 1) ? 2 : 0);
+            if (lane == 0) wide_store(partials, (size_t)slot * nbw + (size_t)blockIdx.x * (kBlock / 64) + wave, wacc[a]);
+        }
+    } else if constexpr (W != 0) {
+        block_reduce_store<NS>(acc, lds, partials, blockIdx.x, gridDim.x);
+    }
 }
 
 // the per-block partial sums of ALL passes of one call, reduced in a single launch after the last
@@ -146,6 +231,7 @@ struct ReducePlan {
     const void* partials[kMax];  // [nsums][nb] Fr
     unsigned nb[kMax];
     unsigned first[kMax + 1];    // first output index of pass p (prefix sums of nsums); outputs are consecutive in `out`
+    unsigned char wide[kMax];    // the partials (and the output) of pass p are 544-bit integers in 80-byte slots
     int n;
 };
 // the challenges of a local stage travel as kernel arguments (at most log2(kLocalMaxE) = 10 rounds)
@@ -188,11 +274,29 @@ __device__ __forceinline__ Fr fr_shfl_down32(const Fr& v, int off) {
 }
 
 // one output sum of an earlier stage: block `ob` of the reduce part of the launch (1024 threads)
-__device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __restrict__ out, unsigned ob, uint4* lds) {
+__device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __restrict__ out, void* __restrict__ wout, unsigned ob,
+                                                uint4* lds) {
     int p = 0;
     while (p + 1 < plan.n && ob >= plan.first[p + 1]) p++;
     const size_t s = ob - plan.first[p], nb = plan.nb[p];
     const int tid = threadIdx.x, grp = tid >> 5, l32 = tid & 31;
+    if (plan.wide[p]) {
+        Wide v;
+#pragma unroll
+        for (int i = 0; i < 17; i++) v.l[i] = 0;
+        for (size_t i = tid; i < nb; i += kLocalThreads) wide_add(v, wide_load(plan.partials[p], s * nb + i));
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) wide_add(v, wide_shfl_down(v, o, 32));
+        if (l32 == 0) wide_store(lds, grp, v);
+        __syncthreads();
+        if (grp == 0) {
+            v = wide_load(lds, l32);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) wide_add(v, wide_shfl_down(v, o, 32));
+            if (l32 == 0) wide_store(wout, ob, v);
+        }
+        return;
+    }
     Fr v = fp_zero<FrCfg>();
     for (size_t i = tid; i < nb; i += kLocalThreads) v = fr_add(v, fr_load(plan.partials[p], s * nb + i));
 #pragma unroll
@@ -211,15 +315,30 @@ template <int MODE>
 __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict__ f, const void* __restrict__ g, unsigned G, unsigned E,
                                                        int elog, int rounds, TailChal chal, void* __restrict__ sums,
                                                        void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go,
-                                                       ReducePlan plan, void* __restrict__ red_out, int t1mode) {
+                                                       ReducePlan plan, void* __restrict__ red_out, void* __restrict__ red_wide,
+                                                       int t1mode, int xcd_map, unsigned long long* __restrict__ ts) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     extern __shared__ uint4 lds[];
     if (blockIdx.x >= G) {
-        reduce_all_body(plan, red_out, blockIdx.x - G, lds);
+        reduce_all_body(plan, red_out, red_wide, blockIdx.x - G, lds);
         return;
     }
-    const unsigned w = blockIdx.x, tid = threadIdx.x;
+    // slice of this workgroup.  The four slices that share a 128-byte line of the table (32-byte elements) go to the
+    // same XCD, so the line crosses the fabric once instead of once per XCD L2 (block b runs on XCD b % 8: observed
+    // placement, a speed matter only -- any bijection is correct)
+    unsigned w = blockIdx.x;
+    if (xcd_map && (G & 31) == 0) {
+        const unsigned x = w & 7, y = w >> 3;  // XCD, slot on it
+        w = 4 * (x + 8 * (y >> 2)) + (y & 3);
+    }
+    const unsigned tid = threadIdx.x;
+    int tsn = 0;
+#define ZK_TS()                                                            \
+    do {                                                                   \
+        if (ts && blockIdx.x == 0 && tid == 0) ts[tsn++] = wall_clock64(); \
+    } while (0)
+    ZK_TS();
     uint4* tf = lds;                          // 2E Fr (2 uint4 each)
     uint4* tg = lds + 4 * (size_t)E;          // 2E Fr
     uint4* park = lds + (TWO ? 8 : 4) * (size_t)E;
@@ -228,7 +347,11 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         if (TWO) fr_store(tg, t, fr_load(g, w + (size_t)G * t));
     }
     __syncthreads();
+    ZK_TS();
     // ---- phase A: the fold chain ----
+    // (two rounds per barrier -- four independent multiplications per output on the lanes of a quad, DPP exchange -- was
+    // built and measured: a field addition costs 0.08 us at one wave per SIMD, and the double round needs 8 of them against
+    // 2 per single round: 2.0 us per double round against 2 x 1.08 us.  Not kept.)
     {
         unsigned L = E;
         size_t qoff = 0, mcur = (size_t)G * E;
@@ -250,12 +373,14 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
             }
             if (solo) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             else __syncthreads();
+            ZK_TS();
             qoff += mcur >> 1;
             mcur >>= 1;
             L = h;
         }
         __syncthreads();
     }
+    ZK_TS();
     const unsigned Lf = E >> rounds;
     for (unsigned t = tid; t < Lf; t += kLocalThreads) {
         fr_store(fo, w + (size_t)G * t, fr_load(tf, lvl_off(E, rounds) + t));
@@ -287,6 +412,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         }
         __syncthreads();
     }
+    ZK_TS();
     const int grp = tid >> 5, l32 = tid & 31;
     for (int vid = grp; vid < rounds * W; vid += kLocalThreads / 32) {
         const int k = vid / W, ws = vid - k * W;
@@ -300,6 +426,9 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
         if (l32 == 0) fr_store(sums, (size_t)vid * G + w, v);
     }
+    ZK_TS();
+    if (ts && blockIdx.x == 0 && tid == 0) ts[31] = tsn;
+#undef ZK_TS
 }
 
 // ---------------------------------------------------------------------------------------
@@ -314,7 +443,8 @@ static int ilog2(size_t x) {
 static size_t pass_blocks(zk_ctx* ctx, size_t m, int k) {
     const size_t q = m >> k;
     size_t blocks = (q + kBlock - 1) / kBlock;
-    const size_t maxb = std::max<size_t>((size_t)ctx->cu_count * 4, (q + (size_t)kBlock * 32 - 1) / ((size_t)kBlock * 32));  // <= 32 grid-stride iterations per lane
+    static const size_t per_cu = getenv("ZK_SC_PASS_WG") ? (size_t)atoi(getenv("ZK_SC_PASS_WG")) : 4;
+    const size_t maxb = std::max<size_t>((size_t)ctx->cu_count * per_cu, (q + (size_t)kBlock * 32 - 1) / ((size_t)kBlock * 32));  // <= 32 grid-stride iterations per lane
     return blocks > maxb ? maxb : blocks;
 }
 template <int K, int MODE>
@@ -325,7 +455,7 @@ static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void
     ChalArgs ch;
     std::memset(&ch, 0, sizeof(ch));
     std::memcpy(&ch, chal, (size_t)K * 32);
-    const size_t lds = (W != 0) ? (size_t)K * W * kBlock * 32 : 0;
+    const size_t lds = (W != 0 && MODE != 1) ? (size_t)K * W * kBlock * 32 : 0;  // (the lazily reduced sums leave through shuffles)
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_pass<K, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
                        qbase, t1mode);
@@ -336,6 +466,30 @@ static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void
 // stage geometry knobs (A/B runs): workgroups of a local stage, rounds fused per HBM pass
 static unsigned sc_local_g() {
     static const unsigned v = getenv("ZK_SC_LOCAL_G") ? (unsigned)atoi(getenv("ZK_SC_LOCAL_G")) : 256u;
+    return v;
+}
+// ZK_SC_TS=1: 100 MHz timestamps of the stages of workgroup 0 of every local launch of a call, printed on stderr
+static unsigned long long* g_ts = nullptr;
+static int g_ts_n = 0;
+static unsigned long long* sc_ts_next() {
+    static const bool on = getenv("ZK_SC_TS") && atoi(getenv("ZK_SC_TS"));
+    if (!on) return nullptr;
+    if (!g_ts && hipMalloc((void**)&g_ts, 8 * 32 * 8) != hipSuccess) return nullptr;
+    return g_ts_n < 8 ? g_ts + 32 * g_ts_n++ : nullptr;
+}
+static void sc_ts_print() {
+    if (!g_ts_n) return;
+    unsigned long long h[8 * 32];
+    if (hipMemcpy(h, g_ts, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int i = 0; i < g_ts_n; i++) {
+        fprintf(stderr, "[sc ts] local launch %d:", i);
+        for (int j = 1; j < (int)h[32 * i + 31] && j < 31; j++) fprintf(stderr, " %.2f", (double)(h[32 * i + j] - h[32 * i + j - 1]) / 100.0);
+        fprintf(stderr, " us\n");
+    }
+    g_ts_n = 0;
+}
+static int sc_xcd_map() {
+    static const int v = getenv("ZK_SC_XCD") ? atoi(getenv("ZK_SC_XCD")) : 1;
     return v;
 }
 static int sc_pass_k(int mode) {
@@ -447,6 +601,29 @@ static inline F half(const F& a) {  // a / 2: (a + r) / 2 when a is odd
     for (int i = 0; i < 4; i++) r.l[i] = (t[i] >> 1) | (t[i + 1] << 63);
     return r;
 }
+static const uint64_t R2M[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};  // R^2 mod r
+static inline F red(F a) {  // a < 2^256 -> a mod r (2^256 < 3 r)
+    while (geq_r(a.l)) {
+        u128 bw = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 t = (u128)a.l[i] - RM[i] - (uint64_t)bw;
+            a.l[i] = (uint64_t)t;
+            bw = (t >> 64) & 1;
+        }
+    }
+    return a;
+}
+// 17 x u32 limbs W0 + W1 R + W2 R^2 (a sum of integer products of Montgomery forms) -> its Montgomery reduction
+// W0 R^-1 + W1 + W2 R mod r, canonical
+static inline F from_wide(const uint32_t* w) {
+    F w0, w1, w2 = {{w[16], 0, 0, 0}}, one = {{1, 0, 0, 0}}, r2;
+    for (int i = 0; i < 4; i++) {
+        w0.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+        w1.l[i] = (uint64_t)w[8 + 2 * i] | ((uint64_t)w[8 + 2 * i + 1] << 32);
+        r2.l[i] = R2M[i];
+    }
+    return add(add(mul(red(w0), one), red(w1)), mul(w2, r2));
+}
 }  // namespace hfr
 
 // sums: rounds x (t0, t1, t2) Montgomery Fr on the host; t1 of round 0 is the device's, every later one is derived
@@ -471,7 +648,7 @@ static void derive_t1(uint64_t* sums, const uint64_t* chal, size_t rounds) {
 
 template <int MODE>
 static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, unsigned E, int rl, const uint64_t* chal, void* sums,
-                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out, int t1mode) {
+                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out, void* red_wide, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     TailChal tc;
@@ -489,7 +666,7 @@ static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, u
     // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_local<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(kLocalThreads), lds, ctx->stream, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
-                       rp ? *rp : none, red_out, t1mode);
+                       rp ? *rp : none, red_out, red_wide, t1mode, sc_xcd_map(), sc_ts_next());
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -503,11 +680,17 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     const size_t local_max = emax * sc_local_g();           // longest table handed to a local stage
     const size_t fr = 32;
     // result block on device: [sums rounds*W][last_f][last_g]
+    // (written by the last kernel straight into pinned host memory: a few dozen 32-byte stores over the link instead of
+    // a copy kernel and one more kernel boundary: the same kernel time, 1-4 us less per call)
+    // product sumcheck: + one 80-byte slot per sum for the lazily reduced sums of the HBM passes (see struct Wide)
     const size_t res_elems = rounds * W + 2;
-    char* d_res = (char*)scratch(ctx, 5, res_elems * fr);
+    const size_t res_bytes = res_elems * fr + (MODE == 1 ? rounds * W * kWideBytes : 0);
+    static const bool pinned_out = !(getenv("ZK_SC_PINNED_OUT") && atoi(getenv("ZK_SC_PINNED_OUT")) == 0);
+    char* d_res = (MODE != 2 && pinned_out) ? (char*)pinned(ctx, res_bytes) : (char*)scratch(ctx, 5, res_bytes);
     if (!d_res) return ZK_ERR_OOM;
     void* d_last_f = d_res + rounds * W * fr;
     void* d_last_g = d_res + (rounds * W + 1) * fr;
+    char* d_wide = d_res + res_elems * fr;
 
     // ---- plan: HBM passes (K rounds fused in registers) down to local_max, one multi-workgroup local
     // stage down to <= 256 elements, one single-workgroup local stage for the rest ----
@@ -534,7 +717,8 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
             st.blocks = st.G;
         }
         st.part_off = part_bytes;
-        part_bytes += (size_t)st.k * W * st.blocks * fr;
+        if (MODE == 1 && st.kind == 0) part_bytes += (size_t)st.k * W * st.blocks * (kBlock / 64) * kWideBytes;  // one 544-bit partial per wave
+        else part_bytes += (size_t)st.k * W * st.blocks * fr;
         plan.push_back(st);
         mm = st.kind == 0 ? mm >> st.k : (size_t)st.G * (st.E >> st.k);
         dd += st.k;
@@ -562,7 +746,9 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     int flip = 0;
     // product sumcheck on tables from 2^18: t1 of every round after the first is derived on the host (derive_t1); below
     // that size the host arithmetic (~0.2 us per round) costs more than the multiplications it saves
-    const bool derive = MODE == 1 && len >= ((size_t)1 << 18);
+    // (the passes keep t1 for their very first round only: a call with passes always derives)
+    const bool derive = MODE == 1 && (len >= ((size_t)1 << 18) || !plan.empty() && plan[0].kind == 0);
+    size_t wide_rounds = 0;  // rounds whose sums come back as 544-bit integers
     ReducePlan rp;
     std::memset(&rp, 0, sizeof(rp));
     for (const Stage& st : plan) {
@@ -574,14 +760,17 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         void* part = d_part ? d_part + st.part_off : nullptr;
         int rc;
         const int t1mode = !derive ? 2 : (done == 0 ? 1 : 0);  // t1 on the device: 2 every round, 1 the stage's first round only, 0 never
-        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, k, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, t1mode);
+        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, k, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode);
         else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         if (rc) return rc;
         if (W != 0) {  // outputs of this stage: sums of rounds done .. done+k-1, consecutive in d_res
+            const bool wide = MODE == 1 && st.kind == 0;
             rp.partials[rp.n] = part;
-            rp.nb[rp.n] = (unsigned)st.blocks;
+            rp.nb[rp.n] = (unsigned)(wide ? st.blocks * (kBlock / 64) : st.blocks);
+            rp.wide[rp.n] = wide;
+            if (wide) wide_rounds = done + k;
             rp.first[rp.n] = (unsigned)(done * W);
             rp.n++;
             rp.first[rp.n] = (unsigned)((done + k) * W);
@@ -600,16 +789,29 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         void* fo = (MODE == 2) ? d_out : d_last_f;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
         int rc = launch_local<MODE>(ctx, cf, cg, 1u, (unsigned)m, rl, h_chal + 4 * done, (void*)(d_res + done * W * fr), qb, fo, d_last_g,
-                                    (W != 0 && rp.n) ? &rp : nullptr, (void*)d_res, !derive ? 2 : (done == 0 ? 1 : 0));
+                                    (W != 0 && rp.n) ? &rp : nullptr, (void*)d_res, (void*)d_wide, !derive ? 2 : (done == 0 ? 1 : 0));
         if (rc) return rc;
     } else if (rounds == 0) {
         ZK_HIP(ctx, hipMemcpyAsync(d_out, d_f, len * fr, hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (MODE != 2) {
-        char* h = (char*)pinned(ctx, res_elems * fr);
-        if (!h) return ZK_ERR_OOM;
-        ZK_HIP(ctx, hipMemcpyAsync(h, d_res, res_elems * fr, hipMemcpyDeviceToHost, ctx->stream));
+        char* h = d_res;
+        if (!pinned_out) {
+            h = (char*)pinned(ctx, res_bytes);
+            if (!h) return ZK_ERR_OOM;
+            ZK_HIP(ctx, hipMemcpyAsync(h, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        sc_ts_print();
+        if (MODE == 1) {  // the one Montgomery reduction of every lazily reduced sum
+            const char* hw = h + res_elems * fr;
+            for (size_t rd = 0; rd < wide_rounds; rd++)
+                for (int ws = 0; ws < 3; ws++) {
+                    if (ws == 1 && rd != 0) continue;  // (derived below)
+                    const hfr::F v = hfr::from_wide((const uint32_t*)(hw + (rd * 3 + ws) * kWideBytes));
+                    std::memcpy(h + (rd * 3 + ws) * fr, &v, fr);
+                }
+        }
         if (derive) derive_t1((uint64_t*)h, h_chal, rounds);
         if (h_sums && rounds * W) std::memcpy(h_sums, h, rounds * W * fr);
         if (h_last_f) std::memcpy(h_last_f, h + rounds * W * fr, fr);

@@ -81,7 +81,34 @@ def gen(cfg, N):
     return "".join(out)
 
 
+def gen_mac_wide(cfg, N):
+    """acc (2N + 1 limbs) += a * b as integers, no reduction: the lazily reduced running sums of the product sumcheck
+    (sum of f_lo g_lo over many pairs, reduced once per call).  Column k starts from acc[k] plus the carry of column k-1
+    (one more mad with the constant 1: it cannot carry), runs the same 96-bit accumulate as fp_mul and leaves its low
+    word in acc[k]."""
+    out = []
+    out.append(f"__device__ __forceinline__ void fp_mac_wide(u32 (&acc)[{2 * N + 1}], const Fp<{cfg}>& a, const Fp<{cfg}>& b) {{\n")
+    out.append("    u64 lo = 0, c0, c1, c2;\n    u32 hi = 0;\n")
+    for k in range(2 * N - 1):
+        js = [j for j in range(N) if 0 <= k - j < N]
+        pairs = [(f"%[a{j}]", f"%[b{k - j}]") for j in js]
+        ins = {"acc": ("v", f"acc[{k}]")}
+        for j in js:
+            ins[f"a{j}"] = ("v", f"a.l[{j}]")
+        for j in js:
+            ins[f"b{k - j}"] = ("v", f"b.l[{k - j}]")
+        body = "\\n\\t".join(["v_mad_u64_u32 %[lo], %[c2], %[acc], 1, %[lo]"] + run(pairs))
+        in_ops = ", ".join(f'[{kk}] "{c}"({e})' for kk, (c, e) in ins.items())
+        out.append(f"    // column {k}\n")
+        out.append(f'    asm("{body}"\n        : [lo] "+v"(lo), [hi] "+v"(hi), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)\n'
+                   f'        : {in_ops}\n        : "vcc");\n')
+        out.append(f"    acc[{k}] = (u32)lo;\n    lo = (lo >> 32) | ((u64)hi << 32);\n    hi = 0;\n")
+    out.append(f"    lo += acc[{2 * N - 1}];\n    acc[{2 * N - 1}] = (u32)lo;\n    acc[{2 * N}] += (u32)(lo >> 32);\n}}\n\n")
+    return "".join(out)
+
+
 print("// GENERATED by tools/gen_fp_mul.py -- do not edit.  See that file for the rationale.")
 print("#pragma once\n// included from fp.cuh (inside namespace zk), after the generic fp_mul template\n")
 print(gen("FrCfg", 8))
 print(gen("FqCfg", 12))
+print(gen_mac_wide("FrCfg", 8))
