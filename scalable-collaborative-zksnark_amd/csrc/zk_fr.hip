@@ -16,6 +16,7 @@
 #include "zk_ctx.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
                                                        int elog, int rounds, TailChal chal, void* __restrict__ sums,
                                                        void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go,
                                                        ReducePlan plan, void* __restrict__ red_out, void* __restrict__ red_wide,
-                                                       int t1mode, int xcd_map, unsigned long long* __restrict__ ts) {
+                                                       int t1mode, int xcd_map, int pre, unsigned long long* __restrict__ ts) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     extern __shared__ uint4 lds[];
@@ -342,25 +343,82 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
     uint4* tf = lds;                          // 2E Fr (2 uint4 each)
     uint4* tg = lds + 4 * (size_t)E;          // 2E Fr
     uint4* park = lds + (TWO ? 8 : 4) * (size_t)E;
-    for (unsigned t = tid; t < E; t += kLocalThreads) {
-        fr_store(tf, t, fr_load(f, w + (size_t)G * t));
-        if (TWO) fr_store(tg, t, fr_load(g, w + (size_t)G * t));
+    // `pre`: the slice has 2E elements and the first round of the stage runs straight out of the table -- pairs (t, t + E),
+    // one per lane, the folded pair goes to LDS as level 0, the products of the round's sums leave through a shuffle
+    // reduction.  One round more per launch at no LDS: a 2^18 product table is ONE local stage + the final one (an HBM
+    // pass less per call from 2^18 on).  r0 = rounds of the stage before LDS level 0.
+    const int r0 = pre ? 1 : 0;
+    const int grp = tid >> 5, l32 = tid & 31;
+    uint4* presc = park + (MODE == 1 ? 6 * (size_t)(E - (E >> rounds)) : 0);  // 64 Fr: group partials of the pre-round
+    if (pre) {
+        const Fr r = fr_load(chal.c, 0);
+        Fr pa = fp_zero<FrCfg>(), pb = fp_zero<FrCfg>();
+        if (TWO) {
+            const unsigned role = tid >> elog, p = tid & (E - 1);  // role 0: f and t0 (t1), role 1: g and t2
+            if (role < 2) {
+                const Fr flo = fr_load(f, w + (size_t)G * p), fhi = fr_load(f, w + (size_t)G * (p + E));
+                const Fr glo = fr_load(g, w + (size_t)G * p), ghi = fr_load(g, w + (size_t)G * (p + E));
+                if (role == 0) {
+                    fr_store(tf, p, fr_add(flo, fr_mul(r, fr_sub(fhi, flo))));
+                    pa = fr_mul(flo, glo);
+                    if (t1mode != 0) pb = fr_mul(fhi, ghi);
+                } else {
+                    const Fr df = fr_sub(fhi, flo), dg = fr_sub(ghi, glo);
+                    fr_store(tg, p, fr_add(glo, fr_mul(r, dg)));
+                    pa = fr_mul(fr_add(fhi, df), fr_add(ghi, dg));  // (2 f_hi - f_lo)(2 g_hi - g_lo)      dsumcheck.rs:55-72
+                }
+            }
+        } else if (tid < E) {
+            const Fr lo = fr_load(f, w + (size_t)G * tid), hi = fr_load(f, w + (size_t)G * (tid + E));
+            const Fr d = fr_sub(hi, lo);
+            if (MODE == 3) fr_store(qbase, w + (size_t)G * tid, d);
+            fr_store(tf, tid, fr_add(lo, fr_mul(r, d)));
+            pa = lo, pb = hi;
+        }
+        if (W != 0) {
+            const bool need_b = MODE == 0 || t1mode != 0;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                pa = fr_add(pa, fr_shfl_down32(pa, o));
+                if (need_b) pb = fr_add(pb, fr_shfl_down32(pb, o));
+            }
+            if (l32 == 0) {
+                fr_store(presc, grp, pa);
+                if (need_b) fr_store(presc, 32 + grp, pb);
+            }
+        }
+    } else {
+        for (unsigned t = tid; t < E; t += kLocalThreads) {
+            fr_store(tf, t, fr_load(f, w + (size_t)G * t));
+            if (TWO) fr_store(tg, t, fr_load(g, w + (size_t)G * t));
+        }
     }
     __syncthreads();
     ZK_TS();
+    if (pre && W != 0 && grp >= 29) {  // the sums of the pre-round, on the last wave (the fold chain below runs on the first)
+        const unsigned ng = E >> 5;    // groups per role
+        const int ws = 31 - grp;       // 0: t0 | plain lo, 1: t1 | plain hi, 2: t2
+        if (ws < W && !(MODE == 1 && ws == 1 && t1mode == 0)) {
+            const unsigned src = (ws == 1) ? 32 : (ws == 2 ? ng : 0);
+            Fr v = (unsigned)l32 < ng ? fr_load(presc, src + l32) : fp_zero<FrCfg>();
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
+            if (l32 == 0) fr_store(sums, (size_t)ws * G + w, v);
+        }
+    }
     // ---- phase A: the fold chain ----
     // (two rounds per barrier -- four independent multiplications per output on the lanes of a quad, DPP exchange -- was
     // built and measured: a field addition costs 0.08 us at one wave per SIMD, and the double round needs 8 of them against
     // 2 per single round: 2.0 us per double round against 2 x 1.08 us.  Not kept.)
     {
         unsigned L = E;
-        size_t qoff = 0, mcur = (size_t)G * E;
+        size_t qoff = pre ? (size_t)G * E : 0, mcur = (size_t)G * E;
         for (int k = 0; k < rounds; k++) {
             const unsigned h = L >> 1, cur = lvl_off(E, k), nxt = lvl_off(E, k + 1);
             const unsigned items = TWO ? 2 * h : h;
             const bool solo = items <= 64;  // this round and every later one fit the first wave
             if (!solo || tid < 64) {
-                const Fr r = fr_load(chal.c, k);
+                const Fr r = fr_load(chal.c, r0 + k);
                 for (unsigned it = tid; it < items; it += kLocalThreads) {
                     const bool isg = TWO && it >= h;
                     const unsigned t = isg ? it - h : it;
@@ -395,7 +453,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
             const unsigned u = E - p;  // in (E/2^(k+1), E/2^k]
             const int k = elog - (32 - __clz(u - 1));
             const unsigned hk = E >> (k + 1), t = p - (E - (E >> k)), off = lvl_off(E, k);
-            if (ws == 1 && !(t1mode == 2 || (t1mode == 1 && k == 0))) continue;  // t1 is derived on the host (see round_pair)
+            if (ws == 1 && !(t1mode == 2 || (t1mode == 1 && r0 + k == 0))) continue;  // t1 is derived on the host (see round_pair)
             Fr a, b;
             if (ws == 0) {
                 a = fr_load(tf, off + t);
@@ -413,10 +471,9 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         __syncthreads();
     }
     ZK_TS();
-    const int grp = tid >> 5, l32 = tid & 31;
     for (int vid = grp; vid < rounds * W; vid += kLocalThreads / 32) {
         const int k = vid / W, ws = vid - k * W;
-        if (MODE == 1 && ws == 1 && !(t1mode == 2 || (t1mode == 1 && k == 0))) continue;
+        if (MODE == 1 && ws == 1 && !(t1mode == 2 || (t1mode == 1 && r0 + k == 0))) continue;
         const unsigned cnt = E >> (k + 1);
         const uint4* src = (MODE == 1) ? park : tf;
         const unsigned base = (MODE == 1) ? ws * P + (E - (E >> k)) : lvl_off(E, k) + ws * cnt;  // mode 0: lo half | hi half of level k
@@ -424,7 +481,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         for (unsigned t = l32; t < cnt; t += 32) v = fr_add(v, fr_load(src, base + t));
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
-        if (l32 == 0) fr_store(sums, (size_t)vid * G + w, v);
+        if (l32 == 0) fr_store(sums, (size_t)(r0 * W + vid) * G + w, v);
     }
     ZK_TS();
     if (ts && blockIdx.x == 0 && tid == 0) ts[31] = tsn;
@@ -440,10 +497,13 @@ static int ilog2(size_t x) {
     return l;
 }
 
-static size_t pass_blocks(zk_ctx* ctx, size_t m, int k) {
+static size_t pass_blocks(zk_ctx* ctx, size_t m, int k, int mode) {
     const size_t q = m >> k;
     size_t blocks = (q + kBlock - 1) / kBlock;
-    static const size_t per_cu = getenv("ZK_SC_PASS_WG") ? (size_t)atoi(getenv("ZK_SC_PASS_WG")) : 4;
+    // product passes: the resident set only (2 workgroups per CU at 2 waves/SIMD) -- every lane then runs >= 2 iterations from
+    // 2^18 outputs on and the 544-bit shuffle reduction at the end of a lane's life is paid half as often (2^20: -7 us)
+    static const size_t env_cu = getenv("ZK_SC_PASS_WG") ? (size_t)atoi(getenv("ZK_SC_PASS_WG")) : 0;
+    const size_t per_cu = env_cu ? env_cu : (mode == 1 ? 2 : 4);
     const size_t maxb = std::max<size_t>((size_t)ctx->cu_count * per_cu, (q + (size_t)kBlock * 32 - 1) / ((size_t)kBlock * 32));  // <= 32 grid-stride iterations per lane
     return blocks > maxb ? maxb : blocks;
 }
@@ -451,7 +511,7 @@ template <int K, int MODE>
 static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void* go, size_t m, const uint64_t* chal, void* partials,
                        void* qbase, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
-    const size_t blocks = pass_blocks(ctx, m, K);
+    const size_t blocks = pass_blocks(ctx, m, K, MODE);
     ChalArgs ch;
     std::memset(&ch, 0, sizeof(ch));
     std::memcpy(&ch, chal, (size_t)K * 32);
@@ -647,26 +707,27 @@ static void derive_t1(uint64_t* sums, const uint64_t* chal, size_t rounds) {
 }
 
 template <int MODE>
-static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, unsigned E, int rl, const uint64_t* chal, void* sums,
+static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, unsigned E, int pre, int rl, const uint64_t* chal, void* sums,
                         void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out, void* red_wide, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     TailChal tc;
     std::memset(&tc, 0, sizeof(tc));
+    // rl = rounds on the LDS levels; pre = 1: one more round before them, straight from the 2E-element slices
     if (rl > 10) return fail(ctx, ZK_ERR_INVALID, "internal: local rounds");
-    if (rl) std::memcpy(tc.c, chal, (size_t)rl * 32);
+    if (rl + pre) std::memcpy(tc.c, chal, (size_t)(rl + pre) * 32);
     ReducePlan none;
     std::memset(&none, 0, sizeof(none));
     const unsigned extra = rp ? rp->first[rp->n] : 0u;
     const unsigned Lf = E >> rl;
     size_t lds = (size_t)(TWO ? 4 : 2) * E * 32 + (MODE == 1 ? (size_t)3 * (E - Lf) * 32 : 0);
-    lds = std::max<size_t>(lds, 32 * 32);
+    lds = std::max<size_t>(lds + 64 * 32, 32 * 32);  // + the group partials of the pre-round
     int elog = 0;
     while ((1u << elog) < E) elog++;
     // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_local<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(kLocalThreads), lds, ctx->stream, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
-                       rp ? *rp : none, red_out, red_wide, t1mode, sc_xcd_map(), sc_ts_next());
+                       rp ? *rp : none, red_out, red_wide, t1mode, sc_xcd_map(), pre, sc_ts_next());
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -676,8 +737,18 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
                     uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
+    static const bool host_ts = getenv("ZK_SC_TS") && atoi(getenv("ZK_SC_TS")) == 2;  // host-side phases of a call on stderr
+    const auto hts0 = std::chrono::steady_clock::now();
+    double hts_us[6];
+    int hts_n = 0;
+    auto hts = [&](bool last) {
+        if (!host_ts) return;
+        hts_us[hts_n++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hts0).count();
+        if (last) fprintf(stderr, "[sc host] launched %.2f synced %.2f copied %.2f reduced %.2f derived %.2f us\n", hts_us[0], hts_us[1], hts_us[2], hts_us[3], hts_us[4]);
+    };
     const size_t emax = TWO ? kLocalMaxE / 2 : kLocalMaxE;  // table elements a workgroup holds in LDS
-    const size_t local_max = emax * sc_local_g();           // longest table handed to a local stage
+    static const int use_pre = getenv("ZK_SC_PRE") ? atoi(getenv("ZK_SC_PRE")) : 1;
+    const size_t local_max = emax * sc_local_g() * (use_pre ? 2 : 1);  // longest table handed to a local stage (x2: its pre-round)
     const size_t fr = 32;
     // result block on device: [sums rounds*W][last_f][last_g]
     // (written by the last kernel straight into pinned host memory: a few dozen 32-byte stores over the link instead of
@@ -699,6 +770,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         int k;     // rounds
         size_t m, blocks, part_off;
         unsigned G, E;
+        int pre;
     };
     std::vector<Stage> plan;
     size_t part_bytes = 0, mm = len, dd = 0;
@@ -708,19 +780,20 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         if (mm > local_max) {
             st.kind = 0;
             st.k = (int)std::min<size_t>({(size_t)sc_pass_k(MODE), rounds - dd, (size_t)(ilog2(mm) - ilog2(local_max))});
-            st.blocks = pass_blocks(ctx, mm, st.k);
+            st.blocks = pass_blocks(ctx, mm, st.k, MODE);
         } else {
             st.kind = 1;
+            st.pre = mm > emax * sc_local_g();  // (= 2 emax G: the first round runs out of the table)
             st.E = (unsigned)emax;
-            st.G = (unsigned)(mm / emax);
-            st.k = (int)std::min<size_t>((size_t)ilog2(emax), rounds - dd);
+            st.G = (unsigned)(mm / emax) >> st.pre;
+            st.k = (int)std::min<size_t>((size_t)ilog2(emax) + st.pre, rounds - dd);
             st.blocks = st.G;
         }
         st.part_off = part_bytes;
         if (MODE == 1 && st.kind == 0) part_bytes += (size_t)st.k * W * st.blocks * (kBlock / 64) * kWideBytes;  // one 544-bit partial per wave
         else part_bytes += (size_t)st.k * W * st.blocks * fr;
         plan.push_back(st);
-        mm = st.kind == 0 ? mm >> st.k : (size_t)st.G * (st.E >> st.k);
+        mm = st.kind == 0 ? mm >> st.k : (size_t)st.G * (st.E >> (st.k - st.pre));
         dd += st.k;
     }
     if ((int)plan.size() > ReducePlan::kMax) return fail(ctx, ZK_ERR_INVALID, "internal: too many passes");
@@ -760,7 +833,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         void* part = d_part ? d_part + st.part_off : nullptr;
         int rc;
         const int t1mode = !derive ? 2 : (done == 0 ? 1 : 0);  // t1 on the device: 2 every round, 1 the stage's first round only, 0 never
-        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, k, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode);
+        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, st.pre, k - st.pre, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode);
         else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
@@ -777,7 +850,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         }
         cf = fo;
         cg = go;
-        m = st.kind == 0 ? m >> k : (size_t)st.G * (st.E >> k);
+        m = st.kind == 0 ? m >> k : (size_t)st.G * (st.E >> (k - st.pre));
         done += k;
         flip ^= 1;
     }
@@ -788,7 +861,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         if (m > emax) return fail(ctx, ZK_ERR_INVALID, "internal: last stage too large");
         void* fo = (MODE == 2) ? d_out : d_last_f;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
-        int rc = launch_local<MODE>(ctx, cf, cg, 1u, (unsigned)m, rl, h_chal + 4 * done, (void*)(d_res + done * W * fr), qb, fo, d_last_g,
+        int rc = launch_local<MODE>(ctx, cf, cg, 1u, (unsigned)m, 0, rl, h_chal + 4 * done, (void*)(d_res + done * W * fr), qb, fo, d_last_g,
                                     (W != 0 && rp.n) ? &rp : nullptr, (void*)d_res, (void*)d_wide, !derive ? 2 : (done == 0 ? 1 : 0));
         if (rc) return rc;
     } else if (rounds == 0) {
@@ -801,8 +874,11 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
             if (!h) return ZK_ERR_OOM;
             ZK_HIP(ctx, hipMemcpyAsync(h, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
         }
+        hts(false);
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hts(false);
         sc_ts_print();
+        hts(false);
         if (MODE == 1) {  // the one Montgomery reduction of every lazily reduced sum
             const char* hw = h + res_elems * fr;
             for (size_t rd = 0; rd < wide_rounds; rd++)
@@ -812,7 +888,9 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
                     std::memcpy(h + (rd * 3 + ws) * fr, &v, fr);
                 }
         }
+        hts(false);
         if (derive) derive_t1((uint64_t*)h, h_chal, rounds);
+        hts(true);
         if (h_sums && rounds * W) std::memcpy(h_sums, h, rounds * W * fr);
         if (h_last_f) std::memcpy(h_last_f, h + rounds * W * fr, fr);
         if (TWO && h_last_g) std::memcpy(h_last_g, h + (rounds * W + 1) * fr, fr);
