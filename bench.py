@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--cpu-log2n", type=int, default=20, help="size of the bounded CPU-baseline MSM sample")
     ap.add_argument("--cpu-e2e-n", type=int, default=13, help="log2 constraints of the CPU end-to-end sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-precompute", action="store_true", help="time the MSM without the SRS window table (zk_srs_precompute)")
     ap.add_argument("--no-extra", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (counter-collection runs)")
     ap.add_argument("--big", type=int, default=24, help="log2 size of the large strong-scaling / sumcheck legs")
@@ -171,6 +172,29 @@ def main():
             return d_msm(ctx, [srs], [scalars], [n], pp, net)
         return sh.sharded_msm(ctx, srs, scalars, n, net)  # one MSM of world * 2^20 points, a chunk per GPU
 
+    # The SRS is fixed for the life of a prover (PolynomialCommitmentCub::new, dpoly_comm.rs:37-67): like uploading it, the
+    # window table 2^{o_w} P_i (zk_srs_precompute) is built once, outside the timed region.  With it every digit of a scalar
+    # lands in ONE bucket set, so the window can be 19 bits wide at 2^20 points: 14 bucket additions per scalar instead of
+    # 16, one bucket reduction instead of 8.  The table-less path is timed first (a few steps) and reported beside it.
+    default_path = None
+    if not args.no_precompute:
+        for _ in range(2):
+            step()
+        ph0 = np.zeros(6)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+            ph0 += ctx.msm_last_timing()
+        barrier()
+        dt0 = (time.perf_counter() - t0) / 10
+        c0 = ctx.lib.zk_msm_window(n)
+        default_path = {"scalar_muls_per_s": world * n / dt0, "ms_per_step": dt0 * 1e3, "steps": 10, "pippenger_window_bits": c0, "windows": (129 + c0 - 1) // c0,
+                        "k_accum_tiles_ms": float(ph0[1]) / 10, "note": "no window table: endomorphism split, 2n entries per window, one bucket set per window"}
+        t0 = time.perf_counter()
+        srs.precompute(0)
+        ctx.sync()
+        precompute_s = time.perf_counter() - t0
     for _ in range(args.warmup):
         step()
     phase = np.zeros(6)
@@ -198,9 +222,13 @@ def main():
         accum_ms = float(phase[1])
         alg_bytes = 128.0 * n  # 96-B affine point + 32-B scalar per scalar-mul, read once
         achieved = alg_bytes / (accum_ms * 1e-3) / 1e9 if accum_ms > 0 else 0.0
-        c = ctx.lib.zk_msm_window(n)
-        windows = (129 + c - 1) // c  # scalars are split into two 128-bit halves (k = k1 + k2*lambda): 2n entries per window
-        madds = 2.0 * n * windows  # one XYZZ mixed addition per entry per window
+        tc = srs.table_window
+        if tc:
+            c, windows, per_window = tc, (256 + tc - 1) // tc, n  # table mode: ceil(256 / c) digits per scalar, one bucket set
+        else:
+            c = ctx.lib.zk_msm_window(n)
+            windows, per_window = (129 + c - 1) // c, 2 * n  # scalars are split into two 128-bit halves (k = k1 + k2*lambda): 2n entries per window
+        madds = float(per_window) * windows  # one XYZZ mixed addition per entry per window
         traffic, traffic_src = pmc_traffic("k_accum_tiles") if args.log2n == 20 else (None, None)
         out = {
             "metric": "G1 scalar-muls/sec (d_msm) + Fr field-ops/sec (d_sumcheck), 2^20 shares, 1/2/4/8 GPU",
@@ -223,8 +251,11 @@ def main():
                                                       else "one MSM over N x 2^20 points, a contiguous chunk per GPU: RCCL all-gather of N partial points + additions"),
                 "pippenger_window_bits": c,
                 "windows": windows,
-                "entries_per_window": 2 * n,
+                "entries_per_window": per_window,
+                "srs_window_table": ({"window_bits": tc, "copies": windows, "bytes": windows * ((n + 3) & ~3) * 96, "build_s": precompute_s,
+                                      "built": "once per SRS level, outside the timed region (zk_srs_precompute)"} if tc else None),
             },
+            "msm_without_window_table": default_path,
             "msm_phase_ms": {"digits_sort": float(phase[0]), "k_accum_tiles": accum_ms, "fixup": float(phase[2]), "bucket_reduce": float(phase[3]), "host_combine": float(phase[4])},
             "roofline": {
                 "kernel": "zk::k_accum_tiles (bucket accumulation)",

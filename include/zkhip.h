@@ -167,6 +167,8 @@ int zk_g1_apply_matrix(zk_ctx *ctx, const uint64_t *h_matrix, size_t rows, size_
  * length).  MSMs on this SRS then use ONE bucket set for all windows: 1/W of the bucket-reduction
  * and fix-up work and no cross-window doubling chain.  Costs W x the level's memory (W ~ 16). */
 int zk_srs_precompute(zk_ctx *ctx, zk_srs *srs, int window_bits);
+/* window bits of the level's table (0: none built) -- the MSMs on it insert ceil(256 / bits) digits per scalar */
+int zk_srs_table_window(const zk_srs *srs);
 int zk_srs_free(zk_ctx *ctx, zk_srs *srs);
 size_t zk_srs_len(const zk_srs *srs);
 /* the library's device copy (INTERNAL Montgomery form, radix 2^390): for diagnostics only */

@@ -357,6 +357,7 @@ int zk_srs_free(zk_ctx* ctx, zk_srs* srs) {
     delete srs;
     return ZK_OK;
 }
+int zk_srs_table_window(const zk_srs* srs) { return (srs && srs->d_table) ? srs->table_c : 0; }
 size_t zk_srs_len(const zk_srs* srs) { return srs ? srs->n : 0; }
 const void* zk_srs_device_ptr(const zk_srs* srs) { return srs ? srs->d_bases : nullptr; }
 

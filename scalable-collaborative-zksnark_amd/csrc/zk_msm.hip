@@ -123,12 +123,15 @@ int msm_pick_window(size_t n) {
     if (c > 17) c = 17;
     return c;
 }
-static int msm_pick_window_full(size_t n) {  // 256-bit layout of the precomputed-table mode
+// 256-bit layout of the precomputed-table mode: ONE bucket set for all ceil(256 / c) digits of a scalar, so the window
+// can be as wide as the bucket reduction of 2^(c-1) buckets allows.  Measured optimum (tools/sweep_pre.py, MI355X):
+// log2 n + 2 up to 2^15 points, 17 bits for 2^16..2^18 (one more bit doubles the narrow-row fix-up), log2 n - 1 from 2^19.
+static int msm_pick_window_full(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg - 4;
+    int c = lg <= 15 ? lg + 2 : (lg <= 18 ? 17 : lg - 1);
     if (c < 4) c = 4;
-    if (c > 16) c = 16;
+    if (c > 20) c = 20;
     return c;
 }
 

@@ -98,6 +98,11 @@ class Srs:
         self.ctx._check(self.ctx.lib.zk_srs_precompute(self.ctx.h, self.h, window_bits))
         return self
 
+    @property
+    def table_window(self) -> int:
+        """window bits of the precomputed table, 0 if none"""
+        return self.ctx.lib.zk_srs_table_window(self.h)
+
     def download(self) -> np.ndarray:
         n = len(self)
         out = np.empty((n, 24 if getattr(self, "g2", False) else 12), dtype=np.uint64)

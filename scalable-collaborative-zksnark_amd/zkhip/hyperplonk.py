@@ -50,11 +50,13 @@ class PackedProvingParameters:
     d_commitment: List = None  # levels 0..n-1          (new_random, dpoly_comm.rs:220-233)
 
     @staticmethod
-    def new(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = None) -> "PackedProvingParameters":
+    def new(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = None, window_tables: bool = True) -> "PackedProvingParameters":
         """
         dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy().  chal_seed: the
         challenges are public values every party shares (the reference's local mode clones ONE parameter set
         for all parties, mpc-net/src/multi.rs:344); pass the same chal_seed to parties with different table seeds.
+        window_tables: build the MSM window table of every SRS level up to 2^22 points (zk_srs_precompute: setup work like
+        generating the level, 14-16 x its memory; results are bit-identical with and without).
         """
         l, npar = pp.l, pp.n
         M = 1 << n
@@ -85,6 +87,10 @@ class PackedProvingParameters:
         # synthetic SRS (random points in the reference as well)
         pk.c_commitment = [be.srs_generate(seed * 7919 + 2 * i + 1, seed * 104729 + 2 * i + 3, max(1, (1 << i) // l)) for i in range(n + 3)]
         pk.d_commitment = [be.srs_generate(seed * 6007 + 2 * i + 5, seed * 15485863 + 2 * i + 7, 1 << i) for i in range(n - (npar.bit_length() - 1) + 3)]
+        if window_tables:
+            for lv in pk.c_commitment + pk.d_commitment:
+                if hasattr(lv, "precompute") and 64 <= len(lv) <= (1 << 22):
+                    lv.precompute(0)
         return pk
 
 
