@@ -130,6 +130,8 @@ static int msm_pick_window_full(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     int c = lg <= 15 ? lg + 2 : (lg <= 18 ? 17 : lg - 1);
+    static const int delta = getenv("ZK_MSM_TABLE_DC") ? atoi(getenv("ZK_MSM_TABLE_DC")) : 0;  // (sweeps)
+    c += delta;
     if (c < 4) c = 4;
     if (c > 20) c = 20;
     return c;

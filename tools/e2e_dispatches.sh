@@ -3,7 +3,7 @@
 N=${1:-20}
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pd
-rocprofv3 --kernel-trace -f csv -d /tmp/pd -o e -- python $REPO/tools/hyperplonk_bench.py --n $N --reps 0 --no-check > /dev/null 2>&1
+rocprofv3 --kernel-trace -f csv -d /tmp/pd -o e -- python $REPO/tools/hyperplonk_bench.py --n $N --reps 1 --no-check > /dev/null 2>&1
 python - <<'PY'
 import csv, glob
 from collections import defaultdict
