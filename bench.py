@@ -178,19 +178,20 @@ def main():
     # 16, one bucket reduction instead of 8.  The table-less path is timed first (a few steps) and reported beside it.
     default_path = None
     if not args.no_precompute:
-        for _ in range(2):
-            step()
-        ph0 = np.zeros(6)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            step()
-            ph0 += ctx.msm_last_timing()
-        barrier()
-        dt0 = (time.perf_counter() - t0) / 10
-        c0 = ctx.lib.zk_msm_window(n)
-        default_path = {"scalar_muls_per_s": world * n / dt0, "ms_per_step": dt0 * 1e3, "steps": 10, "pippenger_window_bits": c0, "windows": (129 + c0 - 1) // c0,
-                        "k_accum_tiles_ms": float(ph0[1]) / 10, "note": "no window table: endomorphism split, 2n entries per window, one bucket set per window"}
+        if not args.no_extra:  # (profiling runs time the headline geometry only)
+            for _ in range(2):
+                step()
+            ph0 = np.zeros(6)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+                ph0 += ctx.msm_last_timing()
+            barrier()
+            dt0 = (time.perf_counter() - t0) / 10
+            c0 = ctx.lib.zk_msm_window(n)
+            default_path = {"scalar_muls_per_s": world * n / dt0, "ms_per_step": dt0 * 1e3, "steps": 10, "pippenger_window_bits": c0, "windows": (129 + c0 - 1) // c0,
+                            "k_accum_tiles_ms": float(ph0[1]) / 10, "note": "no window table: endomorphism split, 2n entries per window, one bucket set per window"}
         t0 = time.perf_counter()
         srs.precompute(0)
         ctx.sync()
