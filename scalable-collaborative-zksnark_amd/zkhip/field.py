@@ -25,18 +25,24 @@ def limbs_to_int(a) -> int:
 def fr_sum_mont(parts) -> np.ndarray:
     """
     sum over axis 0 of Montgomery-form Fr arrays [P, ..., 4] -> [..., 4].  The Montgomery map is
-    linear, so the raw values are added mod r without leaving Montgomery form.
+    linear, so the raw values are added mod r without leaving Montgomery form.  Every party's array becomes ONE big
+    integer with a 320-bit slot per element (64 spare bits: no carry crosses a slot for P < 2^64), the parties are
+    added with P - 1 big-int additions, and each slot is reduced mod r on the way out.
     """
-    a = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.uint64) for x in parts]), dtype="<u8")
+    a = np.stack([np.asarray(x, dtype=np.uint64) for x in parts])
     shape = a.shape[1:-1]
-    flat = a.reshape(a.shape[0], -1, 4)
-    out = np.empty((flat.shape[1], 4), dtype=np.uint64)
-    for j in range(flat.shape[1]):
-        t = 0
-        for p in range(flat.shape[0]):
-            t += int.from_bytes(flat[p, j].tobytes(), "little")
-        out[j] = int_to_limbs(t % R_MOD, 4)
-    return out.reshape(*shape, 4)
+    a = a.reshape(a.shape[0], -1, 4)
+    npart, m = a.shape[0], a.shape[1]
+    wide = np.zeros((npart, m, 5), dtype="<u8")
+    wide[:, :, :4] = a
+    tot = 0
+    for p in range(npart):
+        tot += int.from_bytes(wide[p].tobytes(), "little")
+    raw = tot.to_bytes(40 * m, "little")
+    out = bytearray(32 * m)
+    for j in range(m):
+        out[32 * j : 32 * j + 32] = (int.from_bytes(raw[40 * j : 40 * j + 40], "little") % R_MOD).to_bytes(32, "little")
+    return np.frombuffer(bytes(out), dtype="<u8").astype(np.uint64).reshape(*shape, 4)
 
 
 def fr_mont(x: int) -> np.ndarray:
