@@ -9,7 +9,11 @@ pytestmark = pytest.mark.gpu
 SIZES = [1, 2, 4, 64, 2048, 4096, 8192, 1 << 15, 1 << 17]
 
 
-@pytest.mark.parametrize("length", SIZES)
+# 2^18 / 2^19: the single-table local stage whose first round runs straight out of the table (2^19), with and without an HBM pass
+BIG1 = [1 << 18, 1 << 19]
+
+
+@pytest.mark.parametrize("length", SIZES + BIG1)
 def test_sumcheck(ctx, co, length):
     n = length.bit_length() - 1
     tab, chal = rand_fr(length, 100 + n), rand_fr(max(n, 1), 200 + n)
@@ -19,7 +23,7 @@ def test_sumcheck(ctx, co, length):
     assert (last == exp[n, 1]).all() and not exp[n, 0].any()
 
 
-@pytest.mark.parametrize("length", SIZES + [1 << 18, 1 << 19])  # from 2^18 the host derives t1 of the later rounds
+@pytest.mark.parametrize("length", SIZES + [1 << 18, 1 << 19, 1 << 21])  # from 2^18 the host derives t1 of the later rounds; 2^21: two passes with lazily reduced sums
 def test_sumcheck_product(ctx, co, length):
     n = length.bit_length() - 1
     f, g, chal = rand_fr(length, 300 + n), rand_fr(length, 400 + n), rand_fr(max(n, 1), 500 + n)
@@ -29,7 +33,8 @@ def test_sumcheck_product(ctx, co, length):
     assert (lf == elf).all() and (lg == elg).all()
 
 
-@pytest.mark.parametrize("length,npts", [(1, 0), (8, 0), (8, 2), (8, 3), (8, 5), (4096, 2), (1 << 14, 2), (1 << 14, 14), (1 << 16, 5), (1 << 16, 9)])
+@pytest.mark.parametrize("length,npts", [(1, 0), (8, 0), (8, 2), (8, 3), (8, 5), (4096, 2), (1 << 14, 2), (1 << 14, 14), (1 << 16, 5), (1 << 16, 9),
+                                         (1 << 18, 18), (1 << 19, 1), (1 << 19, 3), (1 << 19, 19), (1 << 20, 2), (1 << 21, 12)])
 def test_fold(ctx, co, length, npts):
     n = length.bit_length() - 1
     tab, pts = rand_fr(length, 600 + n), rand_fr(max(npts, 1), 700 + npts)[:npts]
@@ -41,7 +46,7 @@ def test_fold(ctx, co, length, npts):
     assert (got == cur).all()
 
 
-@pytest.mark.parametrize("length", SIZES)
+@pytest.mark.parametrize("length", SIZES + BIG1)
 def test_open_rounds(ctx, co, length):
     n = length.bit_length() - 1
     tab, pt = rand_fr(length, 800 + n), rand_fr(max(n, 1), 900 + n)
