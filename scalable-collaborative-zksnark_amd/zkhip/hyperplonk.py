@@ -88,9 +88,15 @@ class PackedProvingParameters:
         pk.c_commitment = [be.srs_generate(seed * 7919 + 2 * i + 1, seed * 104729 + 2 * i + 3, max(1, (1 << i) // l)) for i in range(n + 3)]
         pk.d_commitment = [be.srs_generate(seed * 6007 + 2 * i + 5, seed * 15485863 + 2 * i + 7, 1 << i) for i in range(n - (npar.bit_length() - 1) + 3)]
         if window_tables:
-            for lv in pk.c_commitment + pk.d_commitment:
+            # largest levels last: if the device runs out of memory the levels without a table simply use the table-less path
+            for lv in sorted(pk.c_commitment + pk.d_commitment, key=len):
                 if hasattr(lv, "precompute") and 64 <= len(lv) <= (1 << 22):
-                    lv.precompute(0)
+                    try:
+                        lv.precompute(0)
+                    except Exception as e:
+                        if getattr(e, "code", None) != -6:  # ZK_ERR_OOM: keep going without the remaining tables
+                            raise
+                        break
         return pk
 
 
