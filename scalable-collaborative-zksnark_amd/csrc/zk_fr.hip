@@ -151,7 +151,7 @@ struct ModeTraits {
 // ---------------------------------------------------------------------------------------
 // K fused rounds over a table of length m living in HBM.  Thread handles output index j
 // (grid-stride), reading f[j + s*(m>>K)], s < 2^K (each a coalesced 2-KiB wave read).
-// partials layout: [(rd*W + w) * gridDim.x + blockIdx.x]
+// partials layout: [(rd*W + w) * gridDim.x + blockIdx.x] Fr; product sumcheck: 544-bit integers, one per wave (see Wide)
 // ---------------------------------------------------------------------------------------
 template <int K, int MODE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, (K == 3 && MODE == 1) ? 1 : 2))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
@@ -187,8 +187,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
         size_t mcur = m;
 #pragma unroll
         for (int rd = 0; rd < K; rd++) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int half = E >> (rd + 1);
 #pragma unroll
             for (int s = 0; s < E / 2; s++) {
