@@ -154,7 +154,7 @@ struct ModeTraits {
 // partials layout: [(rd*W + w) * gridDim.x + blockIdx.x] Fr; product sumcheck: 544-bit integers, one per wave (see Wide)
 // ---------------------------------------------------------------------------------------
 template <int K, int MODE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, (K == 3 && MODE == 1) ? 1 : 2))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, (K == 3 && MODE == 1) ? 1 : ((K <= 2 && MODE != 1) ? 4 : 2)))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
                                                void* __restrict__ go, size_t m, ChalArgs ch, void* __restrict__ partials,
                                                void* __restrict__ qbase, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
