@@ -223,6 +223,55 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Fold-only passes (fix_variable, mle.rs:95-103) in FLAT form.  K rounds of f <- f_lo + r (f_hi - f_lo) are one linear
+// map of the 2^K elements a lane loads:  out[j] = sum_S w[S] f[j + S q],  w[S] = prod_i (bit_{K-1-i}(S) ? r_i : 1 - r_i)
+// (the eq-polynomial of the K challenges, 2^K products computed on the host).  No intermediate level is needed by
+// anyone, so a lane adds the 2^K integer products into ONE 544-bit sum (fp_mac_wide_s: the weights are wave-uniform
+// kernel arguments, i.e. SGPR operands) and reduces once: 2^K half-multiplications + one reduction per output instead
+// of 2^K - 1 full multiplications -- half the issue slots per element at K = 4 -- and 30 live registers instead of 250,
+// so the sweep runs at full occupancy and is bound by HBM, not by the multiplier.  Exact integer arithmetic: the
+// canonical result is the one the round-by-round order gives.
+// ---------------------------------------------------------------------------------------
+struct FlatW {
+    Fr w[16];
+};
+// v (9 limbs) -= 2^S r if v >= 2^S r
+template <int S>
+__device__ __forceinline__ void w9_csub(u32 (&v)[9]) {
+    u32 d[9], bw = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const u32 lo = i < 8 ? FrCfg::P(i) : 0u, below = i > 0 ? FrCfg::P(i - 1) : 0u;
+        const u32 c = S == 0 ? lo : ((lo << S) | (below >> (32 - S)));  // limb i of r << S
+        d[i] = subb(v[i], c, bw);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] = bw ? v[i] : d[i];
+}
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_fold_flat(const void* __restrict__ f, void* __restrict__ fo, size_t m, FlatW w) {
+    constexpr int E = 1 << K;
+    const size_t q = m >> K;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += (size_t)gridDim.x * kBlock) {
+        u32 acc[17];
+#pragma unroll
+        for (int i = 0; i < 17; i++) acc[i] = 0;
+#pragma unroll
+        for (int s = 0; s < E; s++) fp_mac_wide_s(acc, fr_load(f, j + (size_t)s * q), w.w[s]);
+        u32 v[9];
+        fp_redc_wide(v, acc);  // < (2^K r^2 / 2^256) + r < (0.4528 * 2^K + 1) r
+        if (K >= 4) w9_csub<3>(v);
+        if (K >= 3) w9_csub<2>(v);
+        if (K >= 2) w9_csub<1>(v);
+        w9_csub<0>(v);
+        Fr o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.l[i] = v[i];
+        fr_store(fo, j, o);
+    }
+}
+
 // the per-block partial sums of ALL passes of one call, reduced in a single launch after the last
 // pass (the sums of round i are not an input of round i+1): block b -> output b of pass p
 struct ReducePlan {
@@ -550,9 +599,14 @@ static int sc_xcd_map() {
     static const int v = getenv("ZK_SC_XCD") ? atoi(getenv("ZK_SC_XCD")) : 1;
     return v;
 }
+static int sc_flat_k() {  // rounds per flat fold pass (0: the round-by-round passes)
+    static const int kf = getenv("ZK_SC_KF") ? atoi(getenv("ZK_SC_KF")) : 4;
+    return kf < 0 ? 0 : (kf > 4 ? 4 : kf);
+}
 static int sc_pass_k(int mode) {
     static const int kp = getenv("ZK_SC_KP") ? atoi(getenv("ZK_SC_KP")) : 2;  // product passes
     static const int k0 = getenv("ZK_SC_K0") ? atoi(getenv("ZK_SC_K0")) : 3;  // single-table passes
+    if (mode == 2 && sc_flat_k()) return sc_flat_k();
     return mode == 1 ? kp : k0;
 }
 
@@ -659,6 +713,7 @@ static inline F half(const F& a) {  // a / 2: (a + r) / 2 when a is odd
     for (int i = 0; i < 4; i++) r.l[i] = (t[i] >> 1) | (t[i + 1] << 63);
     return r;
 }
+static const uint64_t ONEM[4] = {0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL};  // R mod r
 static const uint64_t R2M[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};  // R^2 mod r
 static inline F red(F a) {  // a < 2^256 -> a mod r (2^256 < 3 r)
     while (geq_r(a.l)) {
@@ -683,6 +738,40 @@ static inline F from_wide(const uint32_t* w) {
     return add(add(mul(red(w0), one), red(w1)), mul(w2, r2));
 }
 }  // namespace hfr
+
+// flat fold pass: weights w[S], S < 2^K, from the K challenges (Montgomery forms; MSB of S <-> the first challenge)
+static int launch_fold_flat(zk_ctx* ctx, const void* f, void* fo, size_t m, int K, const uint64_t* chal) {
+    using namespace hfr;
+    FlatW fw;
+    std::memset(&fw, 0, sizeof(fw));
+    F one;
+    std::memcpy(&one, hfr::ONEM, 32);
+    std::vector<F> w(1, one);
+    for (int i = 0; i < K; i++) {  // w_{i+1}[2S + t] = w_i[S] * (t ? r_i : 1 - r_i)
+        F r;
+        std::memcpy(&r, chal + 4 * i, 32);
+        std::vector<F> nx(w.size() * 2);
+        for (size_t S = 0; S < w.size(); S++) {
+            const F hi = mul(w[S], r);
+            nx[2 * S + 1] = hi;
+            nx[2 * S] = sub(w[S], hi);
+        }
+        w.swap(nx);
+    }
+    for (size_t S = 0; S < w.size(); S++) std::memcpy(&fw.w[S], &w[S], 32);
+    const size_t q = m >> K;
+    size_t blocks = (q + kBlock - 1) / kBlock;
+    static const size_t per_cu = getenv("ZK_SC_FLAT_WG") ? (size_t)atoi(getenv("ZK_SC_FLAT_WG")) : 64;  // (8 .. 4096 measured: 64 and up within noise, 8 is 5 % slower)
+    const size_t maxb = std::max<size_t>((size_t)ctx->cu_count * per_cu, (q + (size_t)kBlock * 32 - 1) / ((size_t)kBlock * 32));
+    if (blocks > maxb) blocks = maxb;
+    if (K == 4) hipLaunchKernelGGL((k_fold_flat<4>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
+    else if (K == 3) hipLaunchKernelGGL((k_fold_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
+    else if (K == 2) hipLaunchKernelGGL((k_fold_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
+    else hipLaunchKernelGGL((k_fold_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
 
 // sums: rounds x (t0, t1, t2) Montgomery Fr on the host; t1 of round 0 is the device's, every later one is derived
 static void derive_t1(uint64_t* sums, const uint64_t* chal, size_t rounds) {
@@ -832,6 +921,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         int rc;
         const int t1mode = !derive ? 2 : (done == 0 ? 1 : 0);  // t1 on the device: 2 every round, 1 the stage's first round only, 0 never
         if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, st.pre, k - st.pre, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode);
+        else if (MODE == 2 && sc_flat_k()) rc = launch_fold_flat(ctx, cf, fo, m, k, h_chal + 4 * done);
         else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);

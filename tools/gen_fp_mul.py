@@ -81,13 +81,14 @@ def gen(cfg, N):
     return "".join(out)
 
 
-def gen_mac_wide(cfg, N):
+def gen_mac_wide(cfg, N, uniform_b=False):
     """acc (2N + 1 limbs) += a * b as integers, no reduction: the lazily reduced running sums of the product sumcheck
     (sum of f_lo g_lo over many pairs, reduced once per call).  Column k starts from acc[k] plus the carry of column k-1
     (one more mad with the constant 1: it cannot carry), runs the same 96-bit accumulate as fp_mul and leaves its low
     word in acc[k]."""
     out = []
-    out.append(f"__device__ __forceinline__ void fp_mac_wide(u32 (&acc)[{2 * N + 1}], const Fp<{cfg}>& a, const Fp<{cfg}>& b) {{\n")
+    name = "fp_mac_wide_s" if uniform_b else "fp_mac_wide"  # _s: b is wave-uniform (a kernel argument): its limbs are SGPR operands
+    out.append(f"__device__ __forceinline__ void {name}(u32 (&acc)[{2 * N + 1}], const Fp<{cfg}>& a, const Fp<{cfg}>& b) {{\n")
     out.append("    u64 lo = 0, c0, c1, c2;\n    u32 hi = 0;\n")
     for k in range(2 * N - 1):
         js = [j for j in range(N) if 0 <= k - j < N]
@@ -96,7 +97,7 @@ def gen_mac_wide(cfg, N):
         for j in js:
             ins[f"a{j}"] = ("v", f"a.l[{j}]")
         for j in js:
-            ins[f"b{k - j}"] = ("v", f"b.l[{k - j}]")
+            ins[f"b{k - j}"] = ("s" if uniform_b else "v", f"b.l[{k - j}]")
         body = "\\n\\t".join(["v_mad_u64_u32 %[lo], %[c2], %[acc], 1, %[lo]"] + run(pairs))
         in_ops = ", ".join(f'[{kk}] "{c}"({e})' for kk, (c, e) in ins.items())
         out.append(f"    // column {k}\n")
@@ -107,8 +108,39 @@ def gen_mac_wide(cfg, N):
     return "".join(out)
 
 
+def gen_redc_wide(cfg, N):
+    """t (2N + 1 limbs, < 2^(32 N) * 2^4 * p) -> (t + m p) / 2^(32 N) as N + 1 limbs (< t / 2^(32 N) + p): the reduction half
+    of fp_mul on a running sum of products (fp_mac_wide).  The caller subtracts multiples of p."""
+    out = []
+    out.append(f"__device__ __forceinline__ void fp_redc_wide(u32 (&r)[{N + 1}], const u32 (&t)[{2 * N + 1}]) {{\n")
+    out.append(f"    u64 lo = 0, c0, c1, c2;\n    u32 hi = 0;\n    u32 m[{N}];\n")
+    for k in range(2 * N - 1):
+        jb = list(range(k)) if k < N else [j for j in range(N) if 0 <= k - j < N and k - j >= 1]
+        out.append(f"    // column {k}\n")
+        pairs = [(f"%[p{k - j}]", f"%[m{j}]") for j in jb]
+        ins = {"acc": ("v", f"t[{k}]")}
+        for j in jb:
+            ins[f"m{j}"] = ("v", f"m[{j}]")
+        for j in jb:
+            ins[f"p{k - j}"] = ("s", f"{cfg}::P({k - j})")
+        body = "\\n\\t".join(["v_mad_u64_u32 %[lo], %[c2], %[acc], 1, %[lo]"] + (run(pairs) if pairs else []))
+        in_ops = ", ".join(f'[{kk}] "{c}"({e})' for kk, (c, e) in ins.items())
+        out.append(f'    asm("{body}"\n        : [lo] "+v"(lo), [hi] "+v"(hi), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2)\n'
+                   f'        : {in_ops}\n        : "vcc");\n')
+        if k < N:
+            out.append(f"    m[{k}] = (u32)lo * {cfg}::INV;\n")
+            out.append(stmt([("%[p0]", "%[mk]")], {"mk": ("v", f"m[{k}]"), "p0": ("s", f"{cfg}::P(0)")}))
+        else:
+            out.append(f"    r[{k - N}] = (u32)lo;\n")
+        out.append("    lo = (lo >> 32) | ((u64)hi << 32);\n    hi = 0;\n")
+    out.append(f"    lo += t[{2 * N - 1}];\n    r[{N - 1}] = (u32)lo;\n    r[{N}] = (u32)(lo >> 32) + t[{2 * N}];\n}}\n\n")
+    return "".join(out)
+
+
 print("// GENERATED by tools/gen_fp_mul.py -- do not edit.  See that file for the rationale.")
 print("#pragma once\n// included from fp.cuh (inside namespace zk), after the generic fp_mul template\n")
 print(gen("FrCfg", 8))
 print(gen("FqCfg", 12))
 print(gen_mac_wide("FrCfg", 8))
+print(gen_mac_wide("FrCfg", 8, uniform_b=True))
+print(gen_redc_wide("FrCfg", 8))
