@@ -272,6 +272,67 @@ __global__ void __launch_bounds__(kBlock) k_fold_flat(const void* __restrict__ f
     }
 }
 
+// The plain sumcheck's passes in the same flat form.  Its round sums t0 = sum of the low half, t1 = sum of the high half of
+// every level are LINEAR in the table: with A_S = sum_j f[j + S q] (the 2^K column sums of the pass, plain additions)
+// the K rounds of the pass are the sumcheck of the 2^K-element table (A_S) itself -- 2^K field elements, run on the host.
+// So a lane keeps 2^K lazily reduced 288-bit column sums (one 9-limb integer addition per element) next to the wide
+// sum of the fold output: one multiply-accumulate + one addition per element instead of 7/8 multiplication + 3.5
+// modular additions, and no dependency between the rounds.
+static constexpr int kW9Bytes = 48;  // 9 limbs + 3 words of padding
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_plain_flat(const void* __restrict__ f, void* __restrict__ fo, size_t m, FlatW w,
+                                                      void* __restrict__ partials) {
+    constexpr int E = 1 << K;
+    const size_t q = m >> K;
+    u32 cs[E][9];
+#pragma unroll
+    for (int s = 0; s < E; s++)
+#pragma unroll
+        for (int i = 0; i < 9; i++) cs[s][i] = 0;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += (size_t)gridDim.x * kBlock) {
+        u32 acc[17];
+#pragma unroll
+        for (int i = 0; i < 17; i++) acc[i] = 0;
+#pragma unroll
+        for (int s = 0; s < E; s++) {
+            const Fr e = fr_load(f, j + (size_t)s * q);
+            fp_mac_wide_s(acc, e, w.w[s]);
+            u32 c = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) cs[s][i] = addc(cs[s][i], e.l[i], c);
+            cs[s][8] += c;
+        }
+        u32 v[9];
+        fp_redc_wide(v, acc);
+        if (K >= 4) w9_csub<3>(v);
+        if (K >= 3) w9_csub<2>(v);
+        if (K >= 2) w9_csub<1>(v);
+        w9_csub<0>(v);
+        Fr o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.l[i] = v[i];
+        fr_store(fo, j, o);
+    }
+    // one 288-bit partial per wave and column: [S * 4 gridDim + 4 block + wave], 48-byte slots
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t nbw = (size_t)gridDim.x * (kBlock / 64);
+#pragma unroll
+    for (int s = 0; s < E; s++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            u32 c = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) cs[s][i] = addc(cs[s][i], __shfl_down(cs[s][i], off, 64), c);
+        }
+        if (lane == 0) {
+            uint4* p = reinterpret_cast<uint4*>(reinterpret_cast<char*>(partials) + ((size_t)s * nbw + (size_t)blockIdx.x * (kBlock / 64) + wave) * kW9Bytes);
+            p[0] = make_uint4(cs[s][0], cs[s][1], cs[s][2], cs[s][3]);
+            p[1] = make_uint4(cs[s][4], cs[s][5], cs[s][6], cs[s][7]);
+            p[2] = make_uint4(cs[s][8], 0, 0, 0);
+        }
+    }
+}
+
 // the per-block partial sums of ALL passes of one call, reduced in a single launch after the last
 // pass (the sums of round i are not an input of round i+1): block b -> output b of pass p
 struct ReducePlan {
@@ -279,7 +340,8 @@ struct ReducePlan {
     const void* partials[kMax];  // [nsums][nb] Fr
     unsigned nb[kMax];
     unsigned first[kMax + 1];    // first output index of pass p (prefix sums of nsums); outputs are consecutive in `out`
-    unsigned char wide[kMax];    // the partials (and the output) of pass p are 544-bit integers in 80-byte slots
+    unsigned obase[kMax];        // first output slot of pass p in `out` (Fr) / `wout` (wide kinds)
+    unsigned char wide[kMax];    // 1: the partials (and the output) of pass p are 544-bit integers in 80-byte slots; 2: 288-bit partials in 48-byte slots, 544-bit output
     int n;
 };
 // the challenges of a local stage travel as kernel arguments (at most log2(kLocalMaxE) = 10 rounds)
@@ -332,7 +394,19 @@ __device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __
         Wide v;
 #pragma unroll
         for (int i = 0; i < 17; i++) v.l[i] = 0;
-        for (size_t i = tid; i < nb; i += kLocalThreads) wide_add(v, wide_load(plan.partials[p], s * nb + i));
+        if (plan.wide[p] == 2) {
+            for (size_t i = tid; i < nb; i += kLocalThreads) {
+                const uint4* q4 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(plan.partials[p]) + (s * nb + i) * kW9Bytes);
+                const uint4 a = q4[0], b = q4[1];
+                Wide t;
+#pragma unroll
+                for (int k = 0; k < 17; k++) t.l[k] = 0;
+                t.l[0] = a.x, t.l[1] = a.y, t.l[2] = a.z, t.l[3] = a.w, t.l[4] = b.x, t.l[5] = b.y, t.l[6] = b.z, t.l[7] = b.w, t.l[8] = q4[2].x;
+                wide_add(v, t);
+            }
+        } else {
+            for (size_t i = tid; i < nb; i += kLocalThreads) wide_add(v, wide_load(plan.partials[p], s * nb + i));
+        }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) wide_add(v, wide_shfl_down(v, o, 32));
         if (l32 == 0) wide_store(lds, grp, v);
@@ -341,7 +415,7 @@ __device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __
             v = wide_load(lds, l32);
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) wide_add(v, wide_shfl_down(v, o, 32));
-            if (l32 == 0) wide_store(wout, ob, v);
+            if (l32 == 0) wide_store(wout, plan.obase[p] + s, v);
         }
         return;
     }
@@ -355,7 +429,7 @@ __device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __
         v = fr_load(lds, l32);
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
-        if (l32 == 0) fr_store(out, ob, v);
+        if (l32 == 0) fr_store(out, plan.obase[p] + s, v);
     }
 }
 
@@ -603,6 +677,10 @@ static int sc_flat_k() {  // rounds per flat fold pass (0: the round-by-round pa
     static const int kf = getenv("ZK_SC_KF") ? atoi(getenv("ZK_SC_KF")) : 4;
     return kf < 0 ? 0 : (kf > 4 ? 4 : kf);
 }
+static bool sc_plain_flat() {
+    static const bool v = !(getenv("ZK_SC_PLAIN_FLAT") && atoi(getenv("ZK_SC_PLAIN_FLAT")) == 0);
+    return v;
+}
 static int sc_pass_k(int mode) {
     static const int kp = getenv("ZK_SC_KP") ? atoi(getenv("ZK_SC_KP")) : 2;  // product passes
     static const int k0 = getenv("ZK_SC_K0") ? atoi(getenv("ZK_SC_K0")) : 3;  // single-table passes
@@ -737,10 +815,31 @@ static inline F from_wide(const uint32_t* w) {
     }
     return add(add(mul(red(w0), one), red(w1)), mul(w2, r2));
 }
+// 9 x u32 limbs W0 + W1 2^256 (a sum of Montgomery forms, W1 < 2^32) -> its canonical residue: 2^256 = R (mod r)
+static inline F from_cols(const uint32_t* w) {
+    F w0, w1 = {{w[8], 0, 0, 0}}, r2;
+    for (int i = 0; i < 4; i++) {
+        w0.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+        r2.l[i] = R2M[i];
+    }
+    return add(red(w0), mul(w1, r2));
+}
 }  // namespace hfr
 
 // flat fold pass: weights w[S], S < 2^K, from the K challenges (Montgomery forms; MSB of S <-> the first challenge)
-static int launch_fold_flat(zk_ctx* ctx, const void* f, void* fo, size_t m, int K, const uint64_t* chal) {
+static size_t flat_blocks(zk_ctx* ctx, size_t m, int K, bool plain = false) {
+    const size_t q = m >> K;
+    size_t blocks = (q + kBlock - 1) / kBlock;
+    // fold: 8 .. 4096 workgroups per CU measured, 64 and up within noise, 8 is 5 % slower.  plain: a lane ends its life with a
+    // 288-bit shuffle reduction per column, so the resident set only (3 waves per SIMD at its 149 registers)
+    static const size_t wg_fold = getenv("ZK_SC_FLAT_WG") ? (size_t)atoi(getenv("ZK_SC_FLAT_WG")) : 64;
+    static const size_t wg_plain = getenv("ZK_SC_PLAIN_WG") ? (size_t)atoi(getenv("ZK_SC_PLAIN_WG")) : 3;
+    const size_t per_cu = plain ? wg_plain : wg_fold;
+    const size_t maxb = std::max<size_t>((size_t)ctx->cu_count * per_cu, (q + (size_t)kBlock * 32 - 1) / ((size_t)kBlock * 32));
+    return blocks > maxb ? maxb : blocks;
+}
+// partials == nullptr: fold only (k_fold_flat); else the plain sumcheck's pass (k_plain_flat, K <= 3)
+static int launch_fold_flat(zk_ctx* ctx, const void* f, void* fo, size_t m, int K, const uint64_t* chal, void* partials = nullptr) {
     using namespace hfr;
     FlatW fw;
     std::memset(&fw, 0, sizeof(fw));
@@ -759,11 +858,15 @@ static int launch_fold_flat(zk_ctx* ctx, const void* f, void* fo, size_t m, int 
         w.swap(nx);
     }
     for (size_t S = 0; S < w.size(); S++) std::memcpy(&fw.w[S], &w[S], 32);
-    const size_t q = m >> K;
-    size_t blocks = (q + kBlock - 1) / kBlock;
-    static const size_t per_cu = getenv("ZK_SC_FLAT_WG") ? (size_t)atoi(getenv("ZK_SC_FLAT_WG")) : 64;  // (8 .. 4096 measured: 64 and up within noise, 8 is 5 % slower)
-    const size_t maxb = std::max<size_t>((size_t)ctx->cu_count * per_cu, (q + (size_t)kBlock * 32 - 1) / ((size_t)kBlock * 32));
-    if (blocks > maxb) blocks = maxb;
+    const size_t blocks = flat_blocks(ctx, m, K, partials != nullptr);
+    if (partials) {
+        if (K == 3) hipLaunchKernelGGL((k_plain_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw, partials);
+        else if (K == 2) hipLaunchKernelGGL((k_plain_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw, partials);
+        else if (K == 1) hipLaunchKernelGGL((k_plain_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw, partials);
+        else return fail(ctx, ZK_ERR_INVALID, "internal: flat plain pass of %d rounds", K);
+        ZK_HIP(ctx, hipGetLastError());
+        return ZK_OK;
+    }
     if (K == 4) hipLaunchKernelGGL((k_fold_flat<4>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
     else if (K == 3) hipLaunchKernelGGL((k_fold_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
     else if (K == 2) hipLaunchKernelGGL((k_fold_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
@@ -842,7 +945,8 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     // a copy kernel and one more kernel boundary: the same kernel time, 1-4 us less per call)
     // product sumcheck: + one 80-byte slot per sum for the lazily reduced sums of the HBM passes (see struct Wide)
     const size_t res_elems = rounds * W + 2;
-    const size_t res_bytes = res_elems * fr + (MODE == 1 ? rounds * W * kWideBytes : 0);
+    const bool plain_flat = MODE == 0 && sc_plain_flat();
+    const size_t res_bytes = res_elems * fr + (MODE == 1 ? rounds * W * kWideBytes : (plain_flat ? (rounds + 1) * 4 * kWideBytes : 0));  // (plain: 8 column sums per 3 rounds)
     static const bool pinned_out = !(getenv("ZK_SC_PINNED_OUT") && atoi(getenv("ZK_SC_PINNED_OUT")) == 0);
     char* d_res = (MODE != 2 && pinned_out) ? (char*)pinned(ctx, res_bytes) : (char*)scratch(ctx, 5, res_bytes);
     if (!d_res) return ZK_ERR_OOM;
@@ -867,7 +971,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         if (mm > local_max) {
             st.kind = 0;
             st.k = (int)std::min<size_t>({(size_t)sc_pass_k(MODE), rounds - dd, (size_t)(ilog2(mm) - ilog2(local_max))});
-            st.blocks = pass_blocks(ctx, mm, st.k, MODE);
+            st.blocks = plain_flat ? flat_blocks(ctx, mm, st.k, true) : pass_blocks(ctx, mm, st.k, MODE);
         } else {
             st.kind = 1;
             st.pre = mm > emax * sc_local_g();  // (= 2 emax G: the first round runs out of the table)
@@ -878,6 +982,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         }
         st.part_off = part_bytes;
         if (MODE == 1 && st.kind == 0) part_bytes += (size_t)st.k * W * st.blocks * (kBlock / 64) * kWideBytes;  // one 544-bit partial per wave
+        else if (plain_flat && st.kind == 0) part_bytes += ((size_t)1 << st.k) * st.blocks * (kBlock / 64) * kW9Bytes;  // 2^k column sums, one 288-bit partial per wave
         else part_bytes += (size_t)st.k * W * st.blocks * fr;
         plan.push_back(st);
         mm = st.kind == 0 ? mm >> st.k : (size_t)st.G * (st.E >> (st.k - st.pre));
@@ -909,6 +1014,11 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     // (the passes keep t1 for their very first round only: a call with passes always derives)
     const bool derive = MODE == 1 && (len >= ((size_t)1 << 18) || !plan.empty() && plan[0].kind == 0);
     size_t wide_rounds = 0;  // rounds whose sums come back as 544-bit integers
+    struct ColStage {
+        size_t done, k, base;
+    };
+    std::vector<ColStage> col_stages;  // plain sumcheck: passes whose rounds are derived from 2^k column sums
+    size_t ncols = 0;
     ReducePlan rp;
     std::memset(&rp, 0, sizeof(rp));
     for (const Stage& st : plan) {
@@ -922,19 +1032,26 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         const int t1mode = !derive ? 2 : (done == 0 ? 1 : 0);  // t1 on the device: 2 every round, 1 the stage's first round only, 0 never
         if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, st.pre, k - st.pre, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode);
         else if (MODE == 2 && sc_flat_k()) rc = launch_fold_flat(ctx, cf, fo, m, k, h_chal + 4 * done);
+        else if (plain_flat) rc = launch_fold_flat(ctx, cf, fo, m, k, h_chal + 4 * done, part);
         else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         if (rc) return rc;
         if (W != 0) {  // outputs of this stage: sums of rounds done .. done+k-1, consecutive in d_res
             const bool wide = MODE == 1 && st.kind == 0;
+            const bool cols = plain_flat && st.kind == 0;  // outputs: the 2^k column sums of the pass
+            const unsigned nout = cols ? 1u << k : (unsigned)(k * W);
             rp.partials[rp.n] = part;
-            rp.nb[rp.n] = (unsigned)(wide ? st.blocks * (kBlock / 64) : st.blocks);
-            rp.wide[rp.n] = wide;
+            rp.nb[rp.n] = (unsigned)((wide || cols) ? st.blocks * (kBlock / 64) : st.blocks);
+            rp.wide[rp.n] = wide ? 1 : (cols ? 2 : 0);
+            rp.obase[rp.n] = cols ? (unsigned)ncols : (unsigned)(done * W);
             if (wide) wide_rounds = done + k;
-            rp.first[rp.n] = (unsigned)(done * W);
+            if (cols) {
+                col_stages.push_back({done, (size_t)k, ncols});
+                ncols += nout;
+            }
+            rp.first[rp.n + 1] = rp.first[rp.n] + nout;
             rp.n++;
-            rp.first[rp.n] = (unsigned)((done + k) * W);
         }
         cf = fo;
         cg = go;
@@ -975,6 +1092,23 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
                     const hfr::F v = hfr::from_wide((const uint32_t*)(hw + (rd * 3 + ws) * kWideBytes));
                     std::memcpy(h + (rd * 3 + ws) * fr, &v, fr);
                 }
+        }
+        if (MODE == 0) {  // the rounds of a flat pass = the plain sumcheck of its 2^k column sums
+            const char* hw = h + res_elems * fr;
+            for (const ColStage& cs : col_stages) {
+                std::vector<hfr::F> c((size_t)1 << cs.k);
+                for (size_t S = 0; S < c.size(); S++) c[S] = hfr::from_cols((const uint32_t*)(hw + (cs.base + S) * kWideBytes));
+                for (size_t i = 0; i < cs.k; i++) {
+                    const size_t half = c.size() >> 1;
+                    hfr::F t0 = c[0], t1 = c[half], r;
+                    for (size_t S = 1; S < half; S++) t0 = hfr::add(t0, c[S]), t1 = hfr::add(t1, c[half + S]);
+                    std::memcpy(h + ((cs.done + i) * 2) * fr, &t0, fr);
+                    std::memcpy(h + ((cs.done + i) * 2 + 1) * fr, &t1, fr);
+                    std::memcpy(&r, h_chal + 4 * (cs.done + i), fr);
+                    for (size_t S = 0; S < half; S++) c[S] = hfr::add(c[S], hfr::mul(r, hfr::sub(c[half + S], c[S])));  // dsumcheck.rs:14-19
+                    c.resize(half);
+                }
+            }
         }
         hts(false);
         if (derive) derive_t1((uint64_t*)h, h_chal, rounds);
