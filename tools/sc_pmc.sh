@@ -20,7 +20,7 @@ mode, n = sys.argv[1], int(sys.argv[2])
 def total(c):
     f = glob.glob(f"/tmp/scp_{c}/**/*counter_collection.csv", recursive=True)[0]
     calls = int([l for l in open(f"/tmp/scp_{c}.out") if l.startswith("calls")][0].split()[2])
-    kb = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "zk::k_pass" in r["Kernel_Name"] or "zk::k_local" in r["Kernel_Name"])
+    kb = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("zk::k_pass", "zk::k_local", "zk::k_fold_flat", "zk::k_plain_flat")))
     return kb * 1024.0 / calls
 fe, wr = total("FETCH_SIZE"), total("WRITE_SIZE")
 alg = {"product": 64, "plain": 32, "fold": 32, "open": 64}[mode] * (1 << n)
