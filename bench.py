@@ -342,7 +342,8 @@ def main():
                     if lg != big:
                         del f_t, g_t
                 sc["note"] = ("algorithmic bytes: product 64 N, plain 32 N, fold 32 N, open 64 N (SURVEY.md 8d model A); field-op counts as the reference writes them "
-                              "(product 9N mul + 9N add; plain 2N + 3N); the fused passes are integer-ALU bound: 5N Fr-mul / 133e9 caps the product sumcheck at ~0.21 of the HBM peak")
+                              "(product 9N mul + 9N add; plain 2N + 3N).  fold and plain run as flat linear passes (one wide multiply-accumulate per element): HBM-bound; "
+                              "the product sumcheck (2 wide accumulations + 2 multiplications per pair) is bound by the integer multiplier's issue rate")
                 extra["sumcheck"] = sc
             del sf, sg
             ctx.trim()
