@@ -59,6 +59,16 @@ def test_status_codes_and_version():
     assert lib.zk_ctx_create(0, None) == zkhip._lib.ZK_ERR_INVALID
 
 
+def test_generated_multiplier_is_in_sync():
+    """csrc/fp_mul_gen.cuh (FIPS multipliers, the wide multiply-accumulates, the wide reduction) is the output of tools/gen_fp_mul.py"""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_fp_mul.py")], capture_output=True, text=True, check=True).stdout
+    committed = open(os.path.join(ROOT, "scalable-collaborative-zksnark_amd", "csrc", "fp_mul_gen.cuh")).read()
+    assert out == committed, "run: python tools/gen_fp_mul.py > scalable-collaborative-zksnark_amd/csrc/fp_mul_gen.cuh"
+
+
 def test_rust_sys_is_in_sync():
     """rust/zkhip_sys.rs is generated from the header: regenerating must reproduce the committed file"""
     import importlib.util
