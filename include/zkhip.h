@@ -237,7 +237,10 @@ int zk_msm_last_timing(zk_ctx *ctx, float h_ms[6]);
 int zk_comm_unique_id(uint8_t h_id[ZK_COMM_ID_BYTES]);
 /* one process per GPU: collective over all `world` parties */
 int zk_comm_init(zk_ctx *ctx, int rank, int world, const uint8_t h_id[ZK_COMM_ID_BYTES]);
-/* one process holding a ctx per GPU (the reference's model: one task per party): ctxs[p] becomes party p */
+/* one process holding a ctx per GPU (the reference's model: one task per party, mpc-net/src/multi.rs:330-352):
+ * ctxs[p] becomes party p.  The collectives below block until every party has entered them, so each party's calls
+ * must come from ITS OWN host thread (as the reference's parties are separate tasks): driving two parties of one
+ * communicator from a single thread deadlocks in the first exchange that returns host results (e.g. zk_d_msm). */
 int zk_comm_init_all(zk_ctx *const *ctxs, int world);
 int zk_comm_destroy(zk_ctx *ctx); /* also done by zk_ctx_destroy */
 int zk_comm_rank(const zk_ctx *ctx);
@@ -256,11 +259,18 @@ int zk_scatter(zk_ctx *ctx, const void *d_send, size_t bytes, int root, void *d_
  * h_coeffs: world x 4 u64 CANONICAL scalars (for party p: coeffs[i] = c_p * lambda_i).  h_lambda (optional,
  * Montgomery): this party's scalars are multiplied by it on the device before its MSM; callers that pass
  * lambda_p = sum_j unpack2[j][p] pass coeffs[i] = c_p for all i (7 additions + one scalar multiplication).
- * h_out: count x 18 u64 normalised Jacobian -- this party's share of every result. */
+ * h_out: count x 18 u64 normalised Jacobian -- this party's share of every result.
+ * Error behaviour: a party whose local MSMs fail (ZK_ERR_LENGTH, ZK_ERR_OOM, ...) still takes part in the exchange and
+ * returns its own error; every other party returns ZK_ERR_COMM naming the failed party -- nobody is left blocking. */
 int zk_d_msm(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets, const void *const *d_scalars,
              const size_t *n, const uint64_t *h_lambda, const uint64_t *h_coeffs, uint64_t *h_out);
 
 /* ---- test hooks (used by tests/ only; stable but not part of the drop-in surface) --- */
+/* Process-wide experiment / diagnostics knobs (csrc/zk_ctx.hpp `struct Tuning` lists them; the same keys are read once
+ * from ZKHIP_TUNE="key=value,..."): e.g. "sc_t1_device" = 1 makes the product sumcheck compute t1 = sum f_hi g_hi of
+ * EVERY round on the device instead of deriving it from the previous round polynomial (the cross-check of
+ * tests/test_gpu_bigsizes.py).  Returns ZK_ERR_INVALID for an unknown key. */
+int zk_dbg_tune(const char *key, long value);
 int zk_dbg_fq_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
 int zk_dbg_fq_add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
 int zk_dbg_fq_sub(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);

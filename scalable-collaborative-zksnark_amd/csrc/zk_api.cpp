@@ -1,12 +1,67 @@
 // zk_api.cpp -- extern "C" surface of libzkhip.so (see include/zkhip.h) and context plumbing.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "zk_ctx.hpp"
 
 namespace zk {
+
+struct TuneKey {
+    const char* name;
+    long Tuning::*field;
+};
+static const TuneKey kTuneKeys[] = {
+    {"sc_pass_wg", &Tuning::sc_pass_wg}, {"sc_local_g", &Tuning::sc_local_g}, {"sc_ts", &Tuning::sc_ts}, {"sc_xcd", &Tuning::sc_xcd},
+    {"sc_kf", &Tuning::sc_kf}, {"sc_plain_flat", &Tuning::sc_plain_flat}, {"sc_kp", &Tuning::sc_kp}, {"sc_k0", &Tuning::sc_k0},
+    {"sc_flat_wg", &Tuning::sc_flat_wg}, {"sc_plain_wg", &Tuning::sc_plain_wg}, {"sc_pre", &Tuning::sc_pre},
+    {"sc_pinned_out", &Tuning::sc_pinned_out}, {"sc_t1_device", &Tuning::sc_t1_device}, {"sc_flag_sync", &Tuning::sc_flag_sync},
+    {"msm_table_dc", &Tuning::msm_table_dc}, {"msm_qstep", &Tuning::msm_qstep}, {"msm_tile", &Tuning::msm_tile}, {"msm_pair", &Tuning::msm_pair},
+    {"msm_fixq", &Tuning::msm_fixq}, {"msm_quad", &Tuning::msm_quad}, {"msm_stage", &Tuning::msm_stage}, {"msm_split", &Tuning::msm_split},
+    {"msm_np", &Tuning::msm_np}, {"msm_debug", &Tuning::msm_debug}, {"msm_serial", &Tuning::msm_serial}, {"msm_tail", &Tuning::msm_tail},
+};
+static Tuning g_tuning;
+int tune_set(const char* key, long value) {
+    if (!key) return ZK_ERR_INVALID;
+    for (const TuneKey& k : kTuneKeys)
+        if (!std::strcmp(k.name, key)) {
+            tuning().*(k.field) = value;
+            return ZK_OK;
+        }
+    return ZK_ERR_INVALID;
+}
+// the ONE environment read of the library: ZKHIP_TUNE="key=value,key=value" (unknown keys are reported on stderr)
+Tuning& tuning() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = std::getenv("ZKHIP_TUNE");
+        if (!e) return;
+        std::string s(e);
+        size_t pos = 0;
+        while (pos < s.size()) {
+            size_t end = s.find(',', pos);
+            if (end == std::string::npos) end = s.size();
+            const std::string kv = s.substr(pos, end - pos);
+            const size_t eq = kv.find('=');
+            bool ok = false;
+            if (eq != std::string::npos) {
+                const std::string k = kv.substr(0, eq);
+                for (const TuneKey& t : kTuneKeys)
+                    if (k == t.name) {
+                        g_tuning.*(t.field) = std::atol(kv.c_str() + eq + 1);
+                        ok = true;
+                    }
+            }
+            if (!ok && !kv.empty()) fprintf(stderr, "zkhip: ZKHIP_TUNE: unknown entry '%s'\n", kv.c_str());
+            pos = end + 1;
+        }
+    });
+    return g_tuning;
+}
 
 int fail(zk_ctx* ctx, int code, const char* fmt, ...) {
     if (ctx) {
@@ -435,6 +490,8 @@ int zk_msm_last_timing(zk_ctx* ctx, float h_ms[6]) {
     std::memcpy(h_ms, ctx->msm_ms, sizeof(ctx->msm_ms));
     return ZK_OK;
 }
+
+int zk_dbg_tune(const char* key, long value) { return tune_set(key, value); }
 
 int zk_dbg_fq_mul2add(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 3, a, b, out, n); }
 int zk_dbg_fq_add(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 0, a, b, out, n); }

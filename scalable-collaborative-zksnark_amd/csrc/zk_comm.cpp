@@ -12,13 +12,26 @@
 // RCCL is resolved at run time (dlopen of librccl.so.1, re-using the copy a host framework already
 // mapped): libzkhip.so has no link-time dependency on it and loads on machines without it.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "zk_ctx.hpp"
+
+// The handful of RCCL declarations this file needs, stated locally (ABI of nccl.h 2.x as shipped by RCCL): building
+// libzkhip.so does not require the RCCL headers, loading it does not require the library.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct {
+    char internal[NCCL_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;  // every other value is an error; the text comes from ncclGetErrorString
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+}
 
 namespace zk {
 
@@ -48,7 +61,8 @@ static Rccl* rccl() {
         for (const char* n : names)
             if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (!r.handle) {
-            r.err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "");
+            const char* e = dlerror();  // (a second call would return NULL: the first one clears the error)
+            r.err = std::string("librccl.so.1 not found: ") + (e ? e : "");
             return;
         }
         bool ok = true;
@@ -233,52 +247,78 @@ int zk_scatter(zk_ctx* ctx, const void* d_send, size_t bytes, int root, void* d_
 // h_lambda (optional, Montgomery): this party's scalars are multiplied by it on the device first
 // (MSM(b, lambda s) = lambda MSM(b, s)); with lambda_p = sum_j unpack2[j][p] every coeff_i collapses to the
 // one pack coefficient c_p and the map is 7 point additions and a single scalar multiplication.
+//
+// A party whose LOCAL part fails (length mismatch, out of memory, a HIP error) still joins the exchange: every
+// payload carries a status word, so all parties return an error instead of the healthy ones blocking forever in
+// the collective (the reference's `unwrap()` panic takes the whole job down; a silent distributed hang would not).
+// The MSM results reach the all-gather through pinned host memory: the last step of an MSM (the ~40-step bit-plane /
+// window chain and the normalisation) runs on the host by design, so the 144-byte points exist on the
+// host first; the payload is count x 144 + 16 bytes.
 int zk_d_msm(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* offsets, const void* const* d_scalars, const size_t* n,
              const uint64_t* h_lambda, const uint64_t* h_coeffs, uint64_t* h_out) {
     Rccl* r = nullptr;
     int rc = need_comm(ctx, &r);
-    if (rc) return rc;
+    if (rc) return rc;  // (no communicator: nobody is waiting for this party)
     if (count == 0) return ZK_OK;
-    if (!srs || !d_scalars || !n || !h_coeffs || !h_out) return fail(ctx, ZK_ERR_INVALID, "null argument");
     const int w = ctx->comm_world;
-    std::vector<MsmItem> items(count);
+    const size_t bytes = count * 144 + 16;  // results + status word (own 16-byte slot keeps the points aligned)
+    // ---- local part; any failure is carried into the exchange as `local_rc` ----
+    int local_rc = ZK_OK;
+    std::vector<uint64_t> local(count * 18 + 2, 0);
     std::vector<void*> scaled;
-    auto release = [&] {
-        for (void* p : scaled) zk_free(ctx, p);
-    };
-    const uint64_t zero[4] = {0, 0, 0, 0};
-    for (size_t k = 0; k < count; k++) {
-        const void* sc = d_scalars[k];
-        if (h_lambda && n[k]) {
-            void* t = nullptr;
-            rc = zk_malloc(ctx, n[k] * 32, &t);
-            if (!rc) {
-                scaled.push_back(t);
-                rc = fr_axpb(ctx, nullptr, sc, h_lambda, zero, t, n[k]);
-            }
-            if (rc) {
-                release();
-                return rc;
-            }
-            sc = t;
-        }
-        items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, sc, n[k]};
+    if (!srs || !d_scalars || !n || !h_coeffs || !h_out) local_rc = fail(ctx, ZK_ERR_INVALID, "null argument");
+    for (size_t k = 0; k < count && !local_rc; k++) {  // lengths first, before any device work
+        if (!srs[k]) local_rc = fail(ctx, ZK_ERR_INVALID, "null srs");
+        else if ((offsets ? offsets[k] : 0) + n[k] > srs[k]->n)
+            local_rc = fail(ctx, ZK_ERR_LENGTH, "d_msm item %zu: %zu scalars but only %zu bases from offset %zu", k, n[k],
+                            srs[k]->n - std::min(offsets ? offsets[k] : (size_t)0, srs[k]->n), offsets ? offsets[k] : (size_t)0);
     }
-    std::vector<uint64_t> local(count * 18), all((size_t)w * count * 18);
-    rc = msm_g1_batch(ctx, items.data(), count, local.data());
-    release();
-    if (rc) return rc;
-    const size_t bytes = count * 144;
+    if (!local_rc) {
+        std::vector<MsmItem> items(count);
+        const uint64_t zero[4] = {0, 0, 0, 0};
+        for (size_t k = 0; k < count && !local_rc; k++) {
+            const void* sc = d_scalars[k];
+            if (h_lambda && n[k]) {
+                void* t = nullptr;
+                local_rc = zk_malloc(ctx, n[k] * 32, &t);
+                if (!local_rc) {
+                    scaled.push_back(t);
+                    local_rc = fr_axpb(ctx, nullptr, sc, h_lambda, zero, t, n[k]);
+                }
+                sc = t;
+            }
+            items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, sc, n[k]};
+        }
+        if (!local_rc) local_rc = msm_g1_batch(ctx, items.data(), count, local.data());
+        for (void* p : scaled) zk_free(ctx, p);
+    }
+    const std::string local_err = local_rc ? ctx->err : std::string();
+    if (local_rc) std::fill(local.begin(), local.end(), 0);
+    local[count * 18] = (uint64_t)(int64_t)local_rc;
+    // ---- exchange (every party, healthy or not) ----
     char* d = (char*)scratch(ctx, 7, bytes * (size_t)(w + 1));
-    if (!d) return ZK_ERR_OOM;
-    ZK_HIP(ctx, hipMemcpyAsync(d, local.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    char* hp = d ? (char*)pinned(ctx, bytes * (size_t)(w + 1)) : nullptr;
+    if (!d || !hp) {
+        // no staging memory at all: this party cannot even send its status.  Nothing sensible is left but to report it;
+        // the peers see the failure as a communicator error when this party's ctx is torn down.
+        return local_rc ? local_rc : ZK_ERR_OOM;
+    }
+    std::memcpy(hp, local.data(), bytes);
+    ZK_HIP(ctx, hipMemcpyAsync(d, hp, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_NCCL(ctx, r, r->AllGather(d, d + bytes, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream));
-    ZK_HIP(ctx, hipMemcpyAsync(all.data(), d + bytes, bytes * w, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(hp + bytes, d + bytes, bytes * w, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const char* all = hp + bytes;
+    if (local_rc) return fail(ctx, local_rc, "%s", local_err.c_str());
+    for (int p = 0; p < w; p++) {
+        int64_t st;
+        std::memcpy(&st, all + (size_t)p * bytes + count * 144, 8);
+        if (st) return fail(ctx, ZK_ERR_COMM, "zk_d_msm: party %d failed in its local MSMs (code %d)", p, (int)st);
+    }
     // rows of the combination: item k <- the w points C_{0,k} .. C_{w-1,k}
     std::vector<uint64_t> rows((size_t)count * w * 18);
     for (size_t k = 0; k < count; k++)
-        for (int p = 0; p < w; p++) std::memcpy(&rows[(k * w + p) * 18], &all[((size_t)p * count + k) * 18], 144);
+        for (int p = 0; p < w; p++) std::memcpy(&rows[(k * w + p) * 18], all + (size_t)p * bytes + k * 144, 144);
     return g1_lincomb_batch_host(ctx, rows.data(), h_coeffs, (size_t)w, count, h_out);
 }
 

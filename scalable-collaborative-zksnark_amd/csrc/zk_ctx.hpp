@@ -56,6 +56,42 @@ struct zk_ctx {
 
 namespace zk {
 
+// Experiment / diagnostics knobs of the whole library in ONE place.  Defaults are the shipped configuration; the only
+// ways to change them are zk_dbg_tune(key, value) (tests, tools) and the ZKHIP_TUNE="key=value,key=value" environment
+// variable, read once by zk::tuning() (zk_api.cpp) -- no other getenv in the product code.
+struct Tuning {
+    // sumcheck family (zk_fr.hip)
+    long sc_pass_wg = 0;      // workgroups per CU of the HBM passes (0: 2 product / 4 others)
+    long sc_local_g = 256;    // workgroups of a local stage
+    long sc_ts = 0;           // 1: in-kernel stage timestamps of the local launches on stderr, 2: host-side phases
+    long sc_xcd = 1;          // XCD-aware slice map of the local stages
+    long sc_kf = 4;           // rounds per flat fold pass (0: round-by-round passes)
+    long sc_plain_flat = 1;   // plain sumcheck passes in flat form
+    long sc_kp = 2;           // rounds per product pass
+    long sc_k0 = 3;           // rounds per single-table pass
+    long sc_flat_wg = 64;     // workgroups per CU, flat fold
+    long sc_plain_wg = 3;     // workgroups per CU, flat plain pass
+    long sc_pre = 1;          // first round of a full-size local stage straight out of the table
+    long sc_pinned_out = 1;   // results written straight into pinned host memory
+    long sc_t1_device = 0;    // TEST SWITCH: t1 = sum f_hi g_hi of EVERY round computed on the device (never derived)
+    long sc_flag_sync = 1;    // completion through a flag in pinned memory instead of hipStreamSynchronize
+    // MSM (zk_msm.hip)
+    long msm_table_dc = 0;    // window-table width delta (sweeps)
+    long msm_qstep = 2;       // window-class quantisation step of batches
+    long msm_tile = 0;        // sorted entries per lane of k_accum_tiles (0: auto)
+    long msm_pair = 0;        // k_finish pairs the planes
+    long msm_fixq = 65536;    // buckets per class up to which the fix-up runs on quads
+    long msm_quad = 32768;    // additions per reduction pass up to which a quad of lanes shares one
+    long msm_stage = -1;      // level-1 scatter through LDS (-1: by row length)
+    long msm_split = 1;       // staggered parts of the largest class
+    long msm_np = 0;          // sort partitions per row (0: auto)
+    long msm_debug = 0;       // class geometry on stderr
+    long msm_serial = 0;      // all classes on the ctx stream
+    long msm_tail = 1;        // last reduction passes + conversion in ONE single-workgroup kernel
+};
+Tuning& tuning();
+int tune_set(const char* key, long value);  // 0, or ZK_ERR_INVALID for an unknown key
+
 int fail(zk_ctx* ctx, int code, const char* fmt, ...);
 int hip_fail(zk_ctx* ctx, hipError_t e, const char* what);
 // returns device scratch of at least `bytes` (slot 0..7), or nullptr after recording the error

@@ -153,16 +153,18 @@ struct ModeTraits {
 // (grid-stride), reading f[j + s*(m>>K)], s < 2^K (each a coalesced 2-KiB wave read).
 // partials layout: [(rd*W + w) * gridDim.x + blockIdx.x] Fr; product sumcheck: 544-bit integers, one per wave (see Wide)
 // ---------------------------------------------------------------------------------------
-template <int K, int MODE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, (K == 3 && MODE == 1) ? 1 : ((K <= 2 && MODE != 1) ? 4 : 2)))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
+// FULLT1 (product passes, test switch sc_t1_device): t1 = sum f_hi g_hi of EVERY round is accumulated on the device (3K wide
+// sums instead of 2K + 1) -- the independent value the derived t1 is checked against (tests/test_gpu_bigsizes.py).
+template <int K, int MODE, bool FULLT1 = false>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, ((K == 3 && MODE == 1) || FULLT1) ? 1 : ((K <= 2 && MODE != 1) ? 4 : 2)))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
                                                void* __restrict__ go, size_t m, ChalArgs ch, void* __restrict__ partials,
                                                void* __restrict__ qbase, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     constexpr int E = 1 << K;
     constexpr int NS = (W == 0) ? 1 : K * W;
-    constexpr bool LAZY = (MODE == 1);      // lazily reduced sums: t0, t2 of each round + t1 of the first
-    constexpr int NW = LAZY ? 2 * K + 1 : 1;
+    constexpr bool LAZY = (MODE == 1);      // lazily reduced sums: t0, t2 of each round + t1 of the first (FULLT1: of every round)
+    constexpr int NW = LAZY ? (FULLT1 ? 3 * K : 2 * K + 1) : 1;
     extern __shared__ uint4 lds[];
     const size_t q = m >> K;
     Fr acc[LAZY ? 1 : NS];
@@ -192,7 +194,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
             for (int s = 0; s < E / 2; s++) {
                 if (s < half) {
                     Fr qv;
-                    if (LAZY)
+                    if (LAZY && FULLT1)
+                        round_pair_lazy(ef[s], ef[s + half], eg[TWO ? s : 0], eg[TWO ? s + half : 0], ch.c[rd], wacc[FULLT1 ? 3 * rd : 0],
+                                        wacc[FULLT1 ? 3 * rd + 1 : 0], wacc[FULLT1 ? 3 * rd + 2 : 0], true);
+                    else if (LAZY)
                         round_pair_lazy(ef[s], ef[s + half], eg[TWO ? s : 0], eg[TWO ? s + half : 0], ch.c[rd], wacc[LAZY ? 2 * rd : 0],
                                         wacc[LAZY ? 2 * K : 0], wacc[LAZY ? 2 * rd + 1 : 0], t1mode != 0 && rd == 0);
                     else
@@ -215,7 +220,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
         for (int a = 0; a < NW; a++) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) wide_add(wacc[a], wide_shfl_down(wacc[a], off, 64));
-            const int slot = (a == 2 * K) ? 1 : (a >> 1) * 3 + ((a & 1) ? 2 : 0);
+            const int slot = FULLT1 ? a : ((a == 2 * K) ? 1 : (a >> 1) * 3 + ((a & 1) ? 2 : 0));
             if (lane == 0) wide_store(partials, (size_t)slot * nbw + (size_t)blockIdx.x * (kBlock / 64) + wave, wacc[a]);
         }
     } else if constexpr (W != 0) {
@@ -623,7 +628,7 @@ static size_t pass_blocks(zk_ctx* ctx, size_t m, int k, int mode) {
     size_t blocks = (q + kBlock - 1) / kBlock;
     // product passes: the resident set only (2 workgroups per CU at 2 waves/SIMD) -- every lane then runs >= 2 iterations from
     // 2^18 outputs on and the 544-bit shuffle reduction at the end of a lane's life is paid half as often (2^20: -7 us)
-    static const size_t env_cu = getenv("ZK_SC_PASS_WG") ? (size_t)atoi(getenv("ZK_SC_PASS_WG")) : 0;
+    const size_t env_cu = (size_t)tuning().sc_pass_wg;
     const size_t per_cu = env_cu ? env_cu : (mode == 1 ? 2 : 4);
     const size_t maxb = std::max<size_t>((size_t)ctx->cu_count * per_cu, (q + (size_t)kBlock * 32 - 1) / ((size_t)kBlock * 32));  // <= 32 grid-stride iterations per lane
     return blocks > maxb ? maxb : blocks;
@@ -638,6 +643,14 @@ static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void
     std::memcpy(&ch, chal, (size_t)K * 32);
     const size_t lds = (W != 0 && MODE != 1) ? (size_t)K * W * kBlock * 32 : 0;  // (the lazily reduced sums leave through shuffles)
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_pass<K, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (MODE == 1) {
+        if (t1mode == 2) {  // test switch: t1 of every round on the device
+            hipLaunchKernelGGL((k_pass<K, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
+                               qbase, t1mode);
+            ZK_HIP(ctx, hipGetLastError());
+            return ZK_OK;
+        }
+    }
     hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
                        qbase, t1mode);
     ZK_HIP(ctx, hipGetLastError());
@@ -645,16 +658,12 @@ static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void
 }
 
 // stage geometry knobs (A/B runs): workgroups of a local stage, rounds fused per HBM pass
-static unsigned sc_local_g() {
-    static const unsigned v = getenv("ZK_SC_LOCAL_G") ? (unsigned)atoi(getenv("ZK_SC_LOCAL_G")) : 256u;
-    return v;
-}
-// ZK_SC_TS=1: 100 MHz timestamps of the stages of workgroup 0 of every local launch of a call, printed on stderr
+static unsigned sc_local_g() { return (unsigned)tuning().sc_local_g; }
+// tuning sc_ts = 1: 100 MHz timestamps of the stages of workgroup 0 of every local launch of a call, printed on stderr
 static unsigned long long* g_ts = nullptr;
 static int g_ts_n = 0;
 static unsigned long long* sc_ts_next() {
-    static const bool on = getenv("ZK_SC_TS") && atoi(getenv("ZK_SC_TS"));
-    if (!on) return nullptr;
+    if (tuning().sc_ts != 1) return nullptr;
     if (!g_ts && hipMalloc((void**)&g_ts, 8 * 32 * 8) != hipSuccess) return nullptr;
     return g_ts_n < 8 ? g_ts + 32 * g_ts_n++ : nullptr;
 }
@@ -669,21 +678,15 @@ static void sc_ts_print() {
     }
     g_ts_n = 0;
 }
-static int sc_xcd_map() {
-    static const int v = getenv("ZK_SC_XCD") ? atoi(getenv("ZK_SC_XCD")) : 1;
-    return v;
-}
+static int sc_xcd_map() { return (int)tuning().sc_xcd; }
 static int sc_flat_k() {  // rounds per flat fold pass (0: the round-by-round passes)
-    static const int kf = getenv("ZK_SC_KF") ? atoi(getenv("ZK_SC_KF")) : 4;
+    const int kf = (int)tuning().sc_kf;
     return kf < 0 ? 0 : (kf > 4 ? 4 : kf);
 }
-static bool sc_plain_flat() {
-    static const bool v = !(getenv("ZK_SC_PLAIN_FLAT") && atoi(getenv("ZK_SC_PLAIN_FLAT")) == 0);
-    return v;
-}
+static bool sc_plain_flat() { return tuning().sc_plain_flat != 0; }
 static int sc_pass_k(int mode) {
-    static const int kp = getenv("ZK_SC_KP") ? atoi(getenv("ZK_SC_KP")) : 2;  // product passes
-    static const int k0 = getenv("ZK_SC_K0") ? atoi(getenv("ZK_SC_K0")) : 3;  // single-table passes
+    const int kp = std::max(1, std::min(3, (int)tuning().sc_kp));  // product passes
+    const int k0 = std::max(1, std::min(3, (int)tuning().sc_k0));  // single-table passes
     if (mode == 2 && sc_flat_k()) return sc_flat_k();
     return mode == 1 ? kp : k0;
 }
@@ -832,8 +835,7 @@ static size_t flat_blocks(zk_ctx* ctx, size_t m, int K, bool plain = false) {
     size_t blocks = (q + kBlock - 1) / kBlock;
     // fold: 8 .. 4096 workgroups per CU measured, 64 and up within noise, 8 is 5 % slower.  plain: a lane ends its life with a
     // 288-bit shuffle reduction per column, so the resident set only (3 waves per SIMD at its 149 registers)
-    static const size_t wg_fold = getenv("ZK_SC_FLAT_WG") ? (size_t)atoi(getenv("ZK_SC_FLAT_WG")) : 64;
-    static const size_t wg_plain = getenv("ZK_SC_PLAIN_WG") ? (size_t)atoi(getenv("ZK_SC_PLAIN_WG")) : 3;
+    const size_t wg_fold = (size_t)std::max(1L, tuning().sc_flat_wg), wg_plain = (size_t)std::max(1L, tuning().sc_plain_wg);
     const size_t per_cu = plain ? wg_plain : wg_fold;
     const size_t maxb = std::max<size_t>((size_t)ctx->cu_count * per_cu, (q + (size_t)kBlock * 32 - 1) / ((size_t)kBlock * 32));
     return blocks > maxb ? maxb : blocks;
@@ -927,7 +929,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
                     uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
-    static const bool host_ts = getenv("ZK_SC_TS") && atoi(getenv("ZK_SC_TS")) == 2;  // host-side phases of a call on stderr
+    const bool host_ts = tuning().sc_ts == 2;  // host-side phases of a call on stderr
     const auto hts0 = std::chrono::steady_clock::now();
     double hts_us[6];
     int hts_n = 0;
@@ -937,7 +939,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         if (last) fprintf(stderr, "[sc host] launched %.2f synced %.2f copied %.2f reduced %.2f derived %.2f us\n", hts_us[0], hts_us[1], hts_us[2], hts_us[3], hts_us[4]);
     };
     const size_t emax = TWO ? kLocalMaxE / 2 : kLocalMaxE;  // table elements a workgroup holds in LDS
-    static const int use_pre = getenv("ZK_SC_PRE") ? atoi(getenv("ZK_SC_PRE")) : 1;
+    const int use_pre = tuning().sc_pre != 0;
     const size_t local_max = emax * sc_local_g() * (use_pre ? 2 : 1);  // longest table handed to a local stage (x2: its pre-round)
     const size_t fr = 32;
     // result block on device: [sums rounds*W][last_f][last_g]
@@ -947,7 +949,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     const size_t res_elems = rounds * W + 2;
     const bool plain_flat = MODE == 0 && sc_plain_flat();
     const size_t res_bytes = res_elems * fr + (MODE == 1 ? rounds * W * kWideBytes : (plain_flat ? (rounds + 1) * 4 * kWideBytes : 0));  // (plain: 8 column sums per 3 rounds)
-    static const bool pinned_out = !(getenv("ZK_SC_PINNED_OUT") && atoi(getenv("ZK_SC_PINNED_OUT")) == 0);
+    const bool pinned_out = tuning().sc_pinned_out != 0;
     char* d_res = (MODE != 2 && pinned_out) ? (char*)pinned(ctx, res_bytes) : (char*)scratch(ctx, 5, res_bytes);
     if (!d_res) return ZK_ERR_OOM;
     void* d_last_f = d_res + rounds * W * fr;
@@ -1012,7 +1014,8 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     // product sumcheck on tables from 2^18: t1 of every round after the first is derived on the host (derive_t1); below
     // that size the host arithmetic (~0.2 us per round) costs more than the multiplications it saves
     // (the passes keep t1 for their very first round only: a call with passes always derives)
-    const bool derive = MODE == 1 && (len >= ((size_t)1 << 18) || !plan.empty() && plan[0].kind == 0);
+    // (test switch sc_t1_device: never derive -- every t1 is the device's own sum, through the FULLT1 passes)
+    const bool derive = MODE == 1 && !tuning().sc_t1_device && (len >= ((size_t)1 << 18) || (!plan.empty() && plan[0].kind == 0));
     size_t wide_rounds = 0;  // rounds whose sums come back as 544-bit integers
     struct ColStage {
         size_t done, k, base;
@@ -1088,7 +1091,7 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
             const char* hw = h + res_elems * fr;
             for (size_t rd = 0; rd < wide_rounds; rd++)
                 for (int ws = 0; ws < 3; ws++) {
-                    if (ws == 1 && rd != 0) continue;  // (derived below)
+                    if (ws == 1 && rd != 0 && derive) continue;  // (derived below)
                     const hfr::F v = hfr::from_wide((const uint32_t*)(hw + (rd * 3 + ws) * kWideBytes));
                     std::memcpy(h + (rd * 3 + ws) * fr, &v, fr);
                 }

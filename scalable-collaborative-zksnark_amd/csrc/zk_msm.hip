@@ -130,8 +130,7 @@ static int msm_pick_window_full(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     int c = lg <= 15 ? lg + 2 : (lg <= 18 ? 17 : lg - 1);
-    static const int delta = getenv("ZK_MSM_TABLE_DC") ? atoi(getenv("ZK_MSM_TABLE_DC")) : 0;  // (sweeps)
-    c += delta;
+    c += (int)tuning().msm_table_dc;  // (sweeps)
     if (c < 4) c = 4;
     if (c > 20) c = 20;
     return c;
@@ -1047,7 +1046,7 @@ struct MsmClass {
 // batches group their items into window classes: 5, 7, ..., 17 bits (rounded up), then 19.  Step 2 keeps the
 // padding of a class (rows are as long as its largest item) below 4x; measured 5 % faster end to end than step 3
 static int quantised_window(int c) {
-    static const int step = getenv("ZK_MSM_QSTEP") ? atoi(getenv("ZK_MSM_QSTEP")) : 2;
+    const int step = std::max(1, (int)tuning().msm_qstep);
     return c <= 5 ? 5 : (c > 17 ? 19 : std::min(17, 5 + step * ((c - 5 + step - 1) / step)));
 }
 
@@ -1057,12 +1056,13 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
     constexpr size_t kOutWords = 3 * zkhost::fe_words<HF>();  // 18 (G1) / 36 (G2) u64 per result
     if (!h_out && count) return fail(ctx, ZK_ERR_INVALID, "null argument");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    static const u32 T_env = getenv("ZK_MSM_TILE") ? (u32)atoi(getenv("ZK_MSM_TILE")) : 0;
-    static const bool pair_env = getenv("ZK_MSM_PAIR") && atoi(getenv("ZK_MSM_PAIR")) != 0;
-    static const size_t fixq_max = getenv("ZK_MSM_FIXQ") ? (size_t)atol(getenv("ZK_MSM_FIXQ")) : 65536;  // buckets per class
-    static const size_t quad_max = getenv("ZK_MSM_QUAD") ? (size_t)atol(getenv("ZK_MSM_QUAD")) : 32768;  // additions per pass (above it the plain pass is faster: measured)
-    static const int stage_env = getenv("ZK_MSM_STAGE") ? atoi(getenv("ZK_MSM_STAGE")) : -1;
-    static const int split_env = getenv("ZK_MSM_SPLIT") ? atoi(getenv("ZK_MSM_SPLIT")) : 1;  // measured on MI355X: no gain (every phase is ALU-bound), off by default
+    const Tuning& tn = tuning();
+    const u32 T_env = (u32)tn.msm_tile;
+    const bool pair_env = tn.msm_pair != 0;
+    const size_t fixq_max = (size_t)tn.msm_fixq;  // buckets per class
+    const size_t quad_max = (size_t)tn.msm_quad;  // additions per pass (above it the plain pass is faster: measured)
+    const int stage_env = (int)tn.msm_stage;
+    const int split_env = (int)tn.msm_split;  // measured on MI355X: no gain (every phase is ALU-bound), off by default
     // ---- validate + classify by window width ----
     std::vector<MsmClass> classes;
     for (size_t k = 0; k < count; k++) {
@@ -1172,7 +1172,7 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
             // 256 partitions per row; more for very long rows so a partition stays near 16 Ki entries (its
             // level-2 workgroup and the region it scatters into stay small)
             size_t want = 256;
-            static const size_t np_env = getenv("ZK_MSM_NP") ? (size_t)atol(getenv("ZK_MSM_NP")) : 0;
+            const size_t np_env = (size_t)tn.msm_np;
             while (want < kMaxParts && cl.row_len / want > 16384) want <<= 1;
             if (np_env) want = np_env;
             cl.np = (u32)std::min<size_t>(cl.nb, want);
@@ -1201,7 +1201,7 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
         cl.pinned_off = pinned_bytes;
         pinned_bytes += ((cl.rows * (size_t)cl.npair * Cv::kJacBytes + 255) & ~(size_t)255) + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
     }
-    static const bool dbg_classes = getenv("ZK_MSM_DEBUG") != nullptr;
+    const bool dbg_classes = tn.msm_debug != 0;
     if (dbg_classes)
         for (auto& cl : classes) {
             size_t nmin = ~(size_t)0, nmax2 = 0, tot = 0;
@@ -1222,7 +1222,7 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
     // streams (the small ones are pure launch/latency chains and overlap with the big one).
     // Phase timers: sort of the first class, accumulation from the first part's launch to the last
     // part's end, then fix-up / reduction of the last part -- i.e. the exposed time of each phase. ----
-    static const bool serial_env = getenv("ZK_MSM_SERIAL") != nullptr;  // diagnostics: all classes on the ctx stream (per-kernel times = work)
+    const bool serial_env = tn.msm_serial != 0;  // diagnostics: all classes on the ctx stream (per-kernel times = work)
     const bool multi = classes.size() > 1 && !serial_env;
     if (multi) {
         hipEventRecord(ctx->ev_fork, ctx->stream);

@@ -78,6 +78,7 @@ SYMBOLS = [
     ("zk_gather", _i, [_vp, _vp, _sz, _i, _vp]),
     ("zk_scatter", _i, [_vp, _vp, _sz, _i, _vp]),
     ("zk_d_msm", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("zk_dbg_tune", _i, [ctypes.c_char_p, ctypes.c_long]),
     ("zk_dbg_fq_mul", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_fq_add", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_fq_sub", _i, [_vp, _vp, _vp, _vp, _sz]),

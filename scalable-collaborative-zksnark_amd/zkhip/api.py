@@ -122,6 +122,16 @@ class Srs:
             pass
 
 
+def comm_init_all(ctxs) -> None:
+    """zk_comm_init_all: one process holding a ctx per GPU (the reference's one-task-per-party model,
+    mpc-net/src/multi.rs:330-352); ctxs[p] becomes party p.  Drive every party from its own thread afterwards."""
+    lib = _lib.lib()
+    arr = (ctypes.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    rc = lib.zk_comm_init_all(arr, len(ctxs))
+    if rc != 0:
+        raise ZkError(rc, (lib.zk_last_error(ctxs[0].h) or b"").decode() if ctxs else "zk_comm_init_all")
+
+
 class Ctx:
     def __init__(self, device: int = 0):
         self.lib = _lib.lib()
@@ -504,6 +514,12 @@ class Ctx:
         return t
 
     # ---- test hooks ----
+    def dbg_tune(self, key: str, value: int):
+        """process-wide experiment / diagnostics knob (zk_dbg_tune; csrc/zk_ctx.hpp `struct Tuning`)"""
+        rc = self.lib.zk_dbg_tune(key.encode(), int(value))
+        if rc != 0:
+            raise ZkError(rc, f"zk_dbg_tune: unknown key {key!r}")
+
     def dbg_fq(self, op: str, a, b, n, out=None):
         fn = {"add": self.lib.zk_dbg_fq_add, "sub": self.lib.zk_dbg_fq_sub, "mul": self.lib.zk_dbg_fq_mul, "mul2add": self.lib.zk_dbg_fq_mul2add}[op]
         out = out or self.alloc(max(48 * n, 1))

@@ -145,6 +145,14 @@ def _round_product(f: List[int], g: List[int], r: int):
     return (t0, t1, t2), fold(f), fold(g)
 
 
+def _trace(be, kind: str, f, g, length: int, challenge):
+    """test hook: a backend carrying a list `sc_trace` gets the operands of every product sumcheck appended
+    (tests/test_gpu_e2e_fullsize.py anchors every transcript of a protocol run on them through independent kernels)"""
+    t = getattr(be, "sc_trace", None)
+    if t is not None:
+        t.append((kind, f, g, length, np.array(challenge, copy=True)))
+
+
 def sumcheck(be, evaluation, length: int, challenge: np.ndarray) -> np.ndarray:
     """dsumcheck.rs:6-26 -> [n+1, 2, 4]; last entry (0, last)"""
     n = length.bit_length() - 1
@@ -155,6 +163,7 @@ def sumcheck(be, evaluation, length: int, challenge: np.ndarray) -> np.ndarray:
 def sumcheck_product(be, ef, eg, length: int, challenge: np.ndarray) -> np.ndarray:
     """dsumcheck.rs:28-90 -> [n+1, 3, 4]; last entry (0, f*g, 0)"""
     n = length.bit_length() - 1
+    _trace(be, "plain", ef, eg, length, challenge[:n])
     tr, lf, lg = be.sumcheck_product(ef, eg, length, challenge[:n])
     prod = fr_mont(fr_from_mont(lf) * fr_from_mont(lg) % R_MOD)
     return np.concatenate([tr, np.stack([ZERO, prod, ZERO])[None]])
@@ -177,6 +186,7 @@ def c_sumcheck(be, shares, length: int, challenge: np.ndarray, pp: PackedSharing
 def c_sumcheck_product(be, shares_f, shares_g, length: int, challenge: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
     """dsumcheck.rs:148-285 -> [n + log2(l) + 1, 3, 4]"""
     n = length.bit_length() - 1
+    _trace(be, "c", shares_f, shares_g, length, challenge[:n])
     tr, lf, lg = be.sumcheck_product(shares_f, shares_g, length, challenge[:n])
     vf = _fr_vec_to_ints(pss2ss(lf, pp, net))  # :224
     vg = _fr_vec_to_ints(pss2ss(lg, pp, net))  # :225
@@ -212,6 +222,7 @@ def d_sumcheck_product(be, partial_f, partial_g, length: int, challenge: np.ndar
     """dsumcheck.rs:359-512.  Leader: [n'+s, 3, 4]; workers: empty.  Marker tuple is (g, f, 0) (:433)"""
     n = length.bit_length() - 1
     s = net.n_parties.bit_length() - 1
+    _trace(be, "d", partial_f, partial_g, length, challenge[: n + s])
     tr, lf, lg = be.sumcheck_product(partial_f, partial_g, length, challenge[:n])
     local = np.concatenate([tr, np.stack([lg, lf, ZERO])[None]])
     allp = net.all_gather(local)

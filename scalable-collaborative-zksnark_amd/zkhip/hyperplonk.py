@@ -119,7 +119,7 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     # 2.a (:268-294): every party broadcasts local_s; s = concatenation over parties (an all-gather)
     if data_parallel:
         s_dev = be.to_device(random_fr(4 * M // l, seed * 31 + 4))
-    elif hasattr(net, "all_gather_device"):
+    elif hasattr(net, "all_gather_device") and getattr(net, "ctx", None) is be:  # (a foreign ctx's stream is not ordered with ours)
         # RCCL inside the ctx: the 4M/(l N_p) Fr of every party meet in HBM (256 MiB per party at n = 24),
         # nothing crosses PCIe
         s_dev = net.all_gather_device(local_s_l, 32 * (4 * M // npar // l))
@@ -146,6 +146,8 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     den = be.fr_axpb(T["eq_r1_p"], T["ssigma_p"], pk.alpha, pk.beta, hlen)
     h_p = be.fr_batch_div(num, den, hlen)
     subtree, top = dp.d_acc_product(be, h_p, hlen, net)  # :342
+    if getattr(be, "sc_trace", None) is not None:
+        be.sc_trace.append(("keepalive", subtree, None, 0, np.zeros((0, 4), dtype=np.uint64)))  # traced slices point into it
     v1x = _at(subtree, 32 * hlen)  # tree[N..]
     vx0, vx1 = be.fr_deinterleave(subtree, hlen)  # tree[0::2], tree[1::2]  :344-359
     # :363-380 / :383-407: independent commits / opens

@@ -129,9 +129,19 @@ class RcclNet(Net):
     numpy-typed methods of the Net interface stage through one cached device buffer.
     """
 
-    def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes = None):
         self.ctx, self.party_id, self.n_parties = ctx, rank, world
-        ctx.comm_init(rank, world, unique_id)
+        if unique_id is not None:  # (None: the ctx already carries its communicator, see from_init_all)
+            ctx.comm_init(rank, world, unique_id)
+
+    @staticmethod
+    def from_init_all(ctxs) -> list:
+        """one process, a ctx per GPU (zk_comm_init_all -- the reference's task-per-party model, mpc-net/src/multi.rs:330-352):
+        -> one net per party; each must then be driven from its own thread"""
+        from .api import comm_init_all
+
+        comm_init_all(ctxs)
+        return [RcclNet(c, p, len(ctxs)) for p, c in enumerate(ctxs)]
 
     @staticmethod
     def from_torch_dist(ctx, group=None) -> "RcclNet":

@@ -43,3 +43,24 @@ def synthetic_bases(n: int, seed: int) -> np.ndarray:
 def rand_fr(n: int, seed: int) -> np.ndarray:
     """uniform Fr limbs [n,4] (interpreted as Montgomery form)"""
     return co.rand_fr(seed, n)
+
+
+def oracle_msm_chunked(bases: np.ndarray, scalars: np.ndarray, threads: int = 0) -> np.ndarray:
+    """
+    the C oracle's MSM on many host threads: contiguous chunks (ctypes releases the GIL), partial results added with
+    the python oracle's group law -> affine Montgomery [12].  A 2^24-point MSM that takes ~200 s on one core of the
+    port finishes in seconds on the GPU box's cores.
+    """
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    m = len(scalars)
+    threads = threads or max(1, min(64, (os.cpu_count() or 1) // 2))
+    chunks = max(threads, (m + (1 << 18) - 1) >> 18)  # <= 2^18 points per chunk keeps every worker busy to the end
+    bounds = [m * i // chunks for i in range(chunks + 1)]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda i: co.msm_g1(bases[bounds[i] : bounds[i + 1]], scalars[bounds[i] : bounds[i + 1]]), range(chunks)))
+    acc = None
+    for pt in parts:
+        acc = po.g1_add(acc, pt_ints(pt))
+    return pt_mont(acc)

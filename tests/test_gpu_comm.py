@@ -185,3 +185,106 @@ def test_rccl_worker_script_world1():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("RANK_OK") == 1
+
+
+def _party_body(ctx, net, co):
+    """the protocol primitives of WORKER on a ready (ctx, net) pair: one thread per party under zk_comm_init_all"""
+    import pyoracle as po
+    from zkhip import dist_primitive as dp, sharding as sh
+    from zkhip.pss import PackedSharingParams
+
+    W, p = net.n_parties, net.party_id
+    to_m = lambda xs: np.array([po.fr_to_mont_limbs(x) for x in xs], dtype=np.uint64).reshape(-1, 4)
+    ints = lambda a: [po.fr_from_mont_limbs(r) for r in np.asarray(a).reshape(-1, 4)]
+    rng = po.SplitMix64(8642)  # the same stream for every party: each can rebuild all inputs
+    mine = np.full((5, 4), p + 1, dtype=np.uint64)
+    got = net.all_gather(mine)
+    assert all((got[q] == q + 1).all() for q in range(W))
+    got = net.all_to_all([np.full((3, 4), 100 * p + q, dtype=np.uint64) for q in range(W)])
+    assert all((got[q] == 100 * q + p).all() for q in range(W))
+    d = ctx.to_device(mine)
+    g = ctx.gather(d, mine.nbytes, W - 1)  # a remote root (serializing_net.rs:41-72)
+    if p == W - 1:
+        h = g.download((W, 5, 4))
+        assert all((h[q] == q + 1).all() for q in range(W))
+    src = ctx.to_device(np.arange(W * 8, dtype=np.uint64)) if p == W - 1 else None
+    r = ctx.scatter(src, 64, W - 1)  # scatter from a remote root (serializing_net.rs:98-122)
+    assert (r.download((8,)) == np.arange(8 * p, 8 * p + 8)).all()
+    # HBM -> HBM all-gather (step 2.a of the protocol, dhyperplonk.rs:270-294)
+    big = np.full((1 << 12, 4), 7 * p + 3, dtype=np.uint64)
+    ag = net.all_gather_device(ctx.to_device(big), big.nbytes).download((W, 1 << 12, 4))
+    assert all((ag[q] == 7 * q + 3).all() for q in range(W))
+    n = 6
+    pf = [rng.fr_vec(1 << n) for _ in range(W)]
+    pg = [rng.fr_vec(1 << n) for _ in range(W)]
+    s = W.bit_length() - 1
+    ch = rng.fr_vec(n + s)
+    out = dp.d_sumcheck_product(ctx, ctx.to_device(to_m(pf[p])), ctx.to_device(to_m(pg[p])), 1 << n, to_m(ch), net)
+    if p == 0:
+        assert [tuple(ints(t)) for t in out] == po.d_sumcheck_product_all(pf, pg, ch)
+    else:
+        assert len(out) == 0
+    pts, scs = po.g1_bases(64, 77), rng.fr_vec(64)
+    per = 64 // W
+    got = sh.sharded_msm(ctx, ctx.srs_register(np.array([pt_mont(P) for P in pts[p * per : (p + 1) * per]])), ctx.to_device(to_m(scs[p * per : (p + 1) * per])), per, net)
+    assert pt_ints(jac_norm_to_affine(got)) == po.g1_msm(pts, scs)
+    if W == 8:  # the l = 1, 8-party d_msm through ONE C-ABI call per party (zk_d_msm)
+        pp, opp = PackedSharingParams(1), po.PackedSharingParams(1)
+        bases = [[po.g1_bases(40, 50 + q)] for q in range(W)]
+        scal = [[rng.fr_vec(40)] for _ in range(W)]
+        exp = po.d_msm_all(bases, scal, opp)
+        srs = ctx.srs_register(np.array([pt_mont(P) for P in bases[p][0]]))
+        got = dp.d_msm(ctx, [srs], [ctx.to_device(to_m(scal[p][0]))], [40], pp, net)
+        assert pt_ints(jac_norm_to_affine(got[0])) == exp[p][0]
+    # error propagation of zk_d_msm: the LAST party asks for more scalars than it has bases; nobody may hang --
+    # that party reports its own ZK_ERR_LENGTH, every other party a ZK_ERR_COMM naming it
+    import zkhip
+    from zkhip._lib import ZK_ERR_COMM, ZK_ERR_LENGTH
+
+    srs = ctx.srs_generate(11 + p, 13, 64)
+    sc = ctx.to_device(to_m(rng.fr_vec(64)))
+    ones = np.tile(np.array([1, 0, 0, 0], dtype=np.uint64), (W, 1))
+    with pytest.raises(zkhip.ZkError) as e:
+        ctx.d_msm([srs], [sc], [128 if p == W - 1 else 64], ones)
+    assert e.value.code == (ZK_ERR_LENGTH if p == W - 1 else ZK_ERR_COMM), str(e.value)
+    ok = ctx.d_msm([srs], [sc], [64], ones)  # the communicator is still usable afterwards
+    assert ok.shape == (1, 18)
+    return True
+
+
+def test_comm_init_all_one_process_party_threads(co):
+    """
+    zk_comm_init_all (the reference's one-task-per-party model, mpc-net/src/multi.rs:330-352): ONE process, a ctx per
+    visible GPU (1 on the builder's boxes, 8 on the real node), one host thread per party running the same protocol
+    primitives as the torchrun worker -- exchanges through the communicator in each ctx.
+    """
+    import threading
+
+    import zkhip
+    from zkhip.net import RcclNet
+
+    ndev = zkhip.lib().zk_device_count()
+    world = 8 if ndev >= 8 else (4 if ndev >= 4 else (2 if ndev >= 2 else 1))
+    ctxs = [zkhip.Ctx(d) for d in range(world)]
+    try:
+        nets = RcclNet.from_init_all(ctxs)
+        assert [c.comm_rank for c in ctxs] == list(range(world)) and all(c.comm_size == world for c in ctxs)
+        res, errs = [None] * world, []
+
+        def run(p):
+            try:
+                res[p] = _party_body(ctxs[p], nets[p], co)
+            except BaseException as e:  # noqa: BLE001
+                errs.append((p, e))
+
+        th = [threading.Thread(target=run, args=(p,)) for p in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        assert not any(t.is_alive() for t in th), "a party is still blocked in an exchange"
+        assert not errs, errs
+        assert all(res)
+    finally:
+        for c in ctxs:
+            c.close()

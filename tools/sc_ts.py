@@ -1,4 +1,4 @@
-"""ZK_SC_TS=1 python tools/sc_ts.py <mode> <log2 size>: the stage timestamps of the local launches (stderr of the library)"""
+"""ZKHIP_TUNE=sc_ts=1 python tools/sc_ts.py <mode> <log2 size>: the stage timestamps of the local launches (stderr of the library)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd"))

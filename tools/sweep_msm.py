@@ -18,10 +18,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         for _ in range(R):
             ctx.msm_g1(srs, sc, n); ph += ctx.msm_last_timing()
         dt = (time.perf_counter() - t0) / R
-        print(f"  log2n={log2n} c={c} T={os.environ.get('ZK_MSM_TILE','-')} bpb={os.environ.get('ZK_MSM_BPB','-')}: {dt*1e3:7.3f} ms  sort={ph[0]/R:.3f} acc={ph[1]/R:.3f} fix={ph[2]/R:.3f} red={ph[3]/R:.3f} host={ph[4]/R:.3f}", flush=True)
+        print(f"  log2n={log2n} c={c} tune={os.environ.get('ZKHIP_TUNE','-')}: {dt*1e3:7.3f} ms  sort={ph[0]/R:.3f} acc={ph[1]/R:.3f} fix={ph[2]/R:.3f} red={ph[3]/R:.3f} host={ph[4]/R:.3f}", flush=True)
 else:
     for log2n, cs in ((20, "13,14,15,16"),):
         for T in ("32", "64"):
-            subprocess.run([sys.executable, __file__, "child", str(log2n), cs], env=dict(os.environ, ZK_MSM_TILE=T))
+            subprocess.run([sys.executable, __file__, "child", str(log2n), cs], env=dict(os.environ, ZKHIP_TUNE="msm_tile=" + T))
     for log2n, cs in ((18, "12,13,14,15"), (16, "10,11,12,13"), (14, "8,9,10,11"), (12, "6,7,8,9"), (10, "5,6,7"), (22, "15,16")):
-        subprocess.run([sys.executable, __file__, "child", str(log2n), cs], env=dict(os.environ, ZK_MSM_TILE="32"))
+        subprocess.run([sys.executable, __file__, "child", str(log2n), cs], env=dict(os.environ, ZKHIP_TUNE="msm_tile=32"))
