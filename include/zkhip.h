@@ -187,6 +187,17 @@ int zk_msm_g1(zk_ctx *ctx, const zk_srs *srs, size_t offset, const void *d_scala
  * offsets may be NULL (all zero).  h_out: count x 18 u64. */
 int zk_msm_g1_batch(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets,
                     const void *const *d_scalars, const size_t *n, uint64_t *h_out);
+/* Asynchronous form of zk_msm_g1_batch.  Nothing on the reference's path consumes an MSM result on the device (challenges are
+ * pre-sampled, hyperplonk/src/dhyperplonk.rs:159-571), so a caller can start the commitments of a protocol step, run the
+ * step's sumchecks on the same ctx while they are in flight, and collect the points afterwards.  The job is enqueued on
+ * streams of its own (ordered after the work already enqueued on the ctx stream, which produced its scalars) with buffers of
+ * its own; consecutive jobs alternate between two sets of streams, so the latency-bound end of one job overlaps with the
+ * sort and the accumulation of the next.  The scalar buffers must stay valid and unmodified until zk_msm_wait, which runs the
+ * host part, writes count x 18 u64 to h_out and releases the job (also on error). */
+typedef struct zk_msm_job zk_msm_job;
+int zk_msm_g1_batch_async(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets,
+                          const void *const *d_scalars, const size_t *n, zk_msm_job **job);
+int zk_msm_wait(zk_ctx *ctx, zk_msm_job *job, uint64_t *h_out);
 /* ---- G2: `d_msm` / `G::msm` are generic over CurveGroup (dmsm.rs:9,23); the reference's parameters carry G2 points
  * in powers_of_g2 (dpoly_comm.rs:27,59-62).  Same pipeline, coordinates in Fq2 = Fq[u]/(u^2 + 1).
  * Layouts (ark-bls12-381): G2Affine = { x: Fq2{c0, c1}, y: Fq2, infinity } -> 192-byte records x.c0|x.c1|y.c0|y.c1,

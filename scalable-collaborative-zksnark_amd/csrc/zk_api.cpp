@@ -167,10 +167,16 @@ int zk_ctx_create(int device_id, zk_ctx** out) {
     }
     c->own_stream = true;
     for (auto& e : c->ev) hipEventCreate(&e);
-    for (auto& s2 : c->aux) hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    for (auto& e : c->ev_join) hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    for (auto& e : c->ev_part) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    {  // lane 0 of the MSM pipeline = the ctx stream + auxiliary streams (the async lanes are created on first use)
+        zk_ctx::MsmLane& L = c->lanes[0];
+        L.main = c->stream;
+        for (auto& s2 : L.aux) hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming);
+        for (auto& e : L.ev_join) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        for (auto& e : L.ev_part) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        L.ready = true;
+    }
+    hipEventCreateWithFlags(&c->ev_async_in, hipEventDisableTiming);
     *out = c;
     return ZK_OK;
 }
@@ -186,15 +192,9 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     for (auto& e : ctx->ev)
         if (e) hipEventDestroy(e);
-    for (auto& s2 : ctx->aux)
-        if (s2) hipStreamDestroy(s2);
-    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-    for (auto& e : ctx->ev_join)
-        if (e) hipEventDestroy(e);
-    for (auto& e : ctx->ev_part)
-        if (e) hipEventDestroy(e);
-    for (auto& e : ctx->ev_cls)
-        if (e) hipEventDestroy(e);
+    zk::msm_lanes_destroy(ctx);
+    if (ctx->ev_async_in) hipEventDestroy(ctx->ev_async_in);
+    for (auto& pb : ctx->pin_free) hipHostFree(pb.second);
     zk::msm_host_pool_destroy(ctx);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -211,6 +211,7 @@ int zk_ctx_set_stream(zk_ctx* ctx, void* hip_stream) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return ZK_ERR_HIP;
         ctx->own_stream = true;
     }
+    ctx->lanes[0].main = ctx->stream;
     return ZK_OK;
 }
 int zk_ctx_sync(zk_ctx* ctx) {
@@ -426,6 +427,17 @@ int zk_msm_g1_batch(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const s
     std::vector<MsmItem> items(count);
     for (size_t k = 0; k < count; k++) items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, d_scalars[k], n[k]};
     return msm_g1_batch(ctx, items.data(), count, h_out);
+}
+int zk_msm_g1_batch_async(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* offsets, const void* const* d_scalars,
+                          const size_t* n, zk_msm_job** job) {
+    NEED(ctx, job && (count == 0 || (srs && d_scalars && n)));
+    std::vector<MsmItem> items(count);
+    for (size_t k = 0; k < count; k++) items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, d_scalars[k], n[k]};
+    return msm_g1_batch_async(ctx, items.data(), count, job);
+}
+int zk_msm_wait(zk_ctx* ctx, zk_msm_job* job, uint64_t* h_out) {
+    NEED(ctx, job);
+    return msm_job_wait(ctx, job, h_out);
 }
 int zk_srs_register_g2(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out) {
     NEED(ctx, out);

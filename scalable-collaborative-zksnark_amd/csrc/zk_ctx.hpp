@@ -9,6 +9,8 @@
 
 #include "../../include/zkhip.h"
 
+struct zk_msm_job;  // zk_msm.hip
+
 struct zk_srs {
     void* d_bases = nullptr;  // packed 96-B affine points (x||y Montgomery, x=y=0: infinity)
     size_t n = 0;
@@ -36,12 +38,23 @@ struct zk_ctx {
     int msm_window_override = 0;
     float msm_ms[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    static constexpr int kAux = 6;  // extra streams for independent MSM window classes of one batch
-    hipStream_t aux[kAux] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {};
+    static constexpr int kAux = 6;    // extra streams for independent MSM window classes of one batch
     static constexpr int kParts = 4;  // staggered parts of one MSM class (zk_msm.hip)
-    hipEvent_t ev_part[kParts] = {};
-    std::vector<hipEvent_t> ev_cls;  // completion event per MSM window class of a batch
+    // where one MSM batch runs: lane 0 = the ctx stream (blocking calls), lanes 1..2 = the asynchronous jobs
+    // (zk_msm_g1_batch_async), which alternate between two sets of streams so that the latency-bound tail of one job
+    // overlaps with the sort and the accumulation of the next.  Streams / events of the async lanes are created on first use.
+    struct MsmLane {
+        hipStream_t main = nullptr;
+        hipStream_t aux[kAux] = {};
+        hipEvent_t ev_fork = nullptr, ev_join[kAux] = {}, ev_part[kParts] = {};
+        std::vector<hipEvent_t> ev_cls;  // completion event per MSM window class of a batch
+        bool ready = false;
+    };
+    static constexpr int kLanes = 3;
+    MsmLane lanes[kLanes];
+    unsigned async_seq = 0;           // jobs issued so far (lane = 1 + seq % 2)
+    hipEvent_t ev_async_in = nullptr;  // ctx stream -> job stream: the scalars of a job are produced on the ctx stream
+    std::vector<std::pair<size_t, void*>> pin_free;  // pinned staging blocks of finished async jobs
     void* host_pool = nullptr;       // worker threads for the per-item host chains (zk_msm.hip)
     // zk_malloc / zk_free block recycling (zk_api.cpp)
     std::unordered_map<size_t, std::vector<void*>> pool_free;
@@ -130,6 +143,11 @@ struct MsmItem {
     size_t n;
 };
 int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out);
+// asynchronous form: enqueue on one of the ctx's job lanes and return; msm_job_wait runs the host chains, writes the
+// results (18 u64 per item) and releases the job.  The scalars must stay valid until then.
+int msm_g1_batch_async(zk_ctx* ctx, const MsmItem* items, size_t count, zk_msm_job** job);
+int msm_job_wait(zk_ctx* ctx, zk_msm_job* job, uint64_t* h_out);
+void msm_lanes_destroy(zk_ctx* ctx);
 int msm_g2_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out);  // h_out: 36 u64 per item
 int srs_pack_g2(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out);

@@ -743,14 +743,13 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
 
 // the same pass with one addition per QUAD of lanes (curve30.cuh: xyzz30_add_quad): for the late passes,
 // which are a single dependent addition of pure latency, this cuts the chain from 13 multiplications to 4
-__global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len,
-                                                   NarrowRows nr) {
+__device__ __forceinline__ void halve_quad_body(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len, const NarrowRows& nr,
+                                                size_t tq) {
     const size_t half = len >> 1;
     const size_t per_w = (size_t)(rows + 1) * half;
-    const size_t tq = (size_t)blockIdx.x * kBlk + threadIdx.x;
     const size_t t = tq >> 2;
     const int role = (int)(tq & 3);
-    if (t >= per_w * W) return;  // whole quads leave together (kBlk is a multiple of 4)
+    if (t >= per_w * W) return;  // whole quads leave together (callers hand out multiples of 4)
     const size_t w = t / per_w, rem = t % per_w;
     const int r = (int)(rem / half);
     const size_t j = rem % half;
@@ -769,6 +768,10 @@ __global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in
         return;
     }
     xyzz30_add_quad(in, ib - 1, ib, out, t, role);
+}
+__global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len,
+                                                   NarrowRows nr) {
+    halve_quad_body(in, out, W, rows, len, nr, (size_t)blockIdx.x * kBlk + threadIdx.x);
 }
 
 // last step on the device: the c reduced points of every window row (planes T_0..T_{c-2}, then T_all)
@@ -794,6 +797,46 @@ __global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void
         if (2 * j + 1 < planes) acc = Cv::add(acc, Cv::dbl(Cv::load(in, row * c + 2 * j + 1)));
     }
     Cv::finish(acc, out, t);
+}
+
+// The END of the bucket reduction in one launch: once a pass is down to a few hundred additions, every remaining pass is one
+// addition of pure latency (~6 us on a quad) plus a kernel boundary and a cold start from L2 (~12 us per launch measured).
+// ONE workgroup runs all of them -- a pass is <= kTailLanes / 4 quad additions, the workgroup barrier separates the passes, the
+// rows ping-pong between the same two buffers (they sit in this CU's L2 slice) -- and converts the c reduced points of every
+// row (k_finish).  Saves the launch + warm-up of ~6 dependent kernels per MSM (profiles/r03*_msm_*_dispatch_timeline.txt).
+static constexpr int kTailThreads = 1024;
+static constexpr size_t kTailLanes = 2048;  // quad lanes of the first fused pass (two sweeps of the workgroup)
+__global__ void __launch_bounds__(kTailThreads) k_tail_quad(void* bufA, void* bufB, int W, int rows, size_t len, NarrowRows nr, int c, int nout,
+                                                          int pair) {
+    void* in = bufA;
+    void* out = bufB;
+    while (len > 1) {
+        const size_t lanes = 4 * (size_t)W * (size_t)(rows + 1) * (len >> 1);
+        for (size_t tq = threadIdx.x; tq < lanes; tq += kTailThreads) halve_quad_body(in, out, W, rows, len, nr, tq);
+        __threadfence_block();
+        __syncthreads();
+        void* t = in;
+        in = out;
+        out = t;
+        rows++;
+        len >>= 1;
+    }
+    // rows == c points per bucket row -> Jacobian, reference Montgomery form (k_finish)
+    for (size_t t = threadIdx.x; t < (size_t)W * nout; t += kTailThreads) {
+        const size_t row = t / nout;
+        const int j = (int)(t % nout);
+        Xyzz30 acc;
+        if (!pair) {
+            acc = xyzz30_load(in, row * c + j);
+        } else {
+            const int planes = c - 1;
+            xyzz30_set_inf(acc);
+            if (2 * j < planes) acc = xyzz30_load(in, row * c + 2 * j);
+            if (j == 0) acc = xyzz30_add(acc, xyzz30_load(in, row * c + (c - 1)));
+            if (2 * j + 1 < planes) acc = xyzz30_add(acc, xyzz30_dbl(xyzz30_load(in, row * c + 2 * j + 1)));
+        }
+        CvG1::finish(acc, out, t);
+    }
 }
 
 // SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine, packed 96 B), one lane per point.
@@ -1050,12 +1093,75 @@ static int quantised_window(int c) {
     return c <= 5 ? 5 : (c > 17 ? 19 : std::min(17, 5 + step * ((c - 5 + step - 1) / step)));
 }
 
+// One batch in flight: what msm_enqueue leaves behind for msm_finish.  A blocking call (lane 0) works in the ctx's scratch
+// arenas and pinned staging area; an asynchronous job (lanes 1, 2) owns its buffers -- taken from the ctx's block pool and
+// handed back when the job is waited for -- because sumcheck calls and other jobs run while it is in flight.
+struct MsmRun {
+    int lane = 0;
+    bool own_mem = false;
+    size_t count = 0;
+    std::vector<MsmItem> items;
+    std::vector<MsmClass> classes;
+    std::vector<size_t> empty_items;  // n = 0: the result is the identity
+    void* buf[10] = {};
+    char* hpin = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+static void msm_release(zk_ctx* ctx, MsmRun& run) {
+    if (!run.own_mem) return;
+    for (void*& b : run.buf)
+        if (b) {
+            zk_free(ctx, b);
+            b = nullptr;
+        }
+    if (run.hpin) {
+        ctx->pin_free.emplace_back(run.pinned_bytes, (void*)run.hpin);
+        run.hpin = nullptr;
+    }
+}
+
+static int msm_lane_prepare(zk_ctx* ctx, int lane) {
+    zk_ctx::MsmLane& L = ctx->lanes[lane];
+    if (lane == 0) L.main = ctx->stream;
+    if (L.ready) return ZK_OK;
+    ZK_HIP(ctx, hipStreamCreateWithFlags(&L.main, hipStreamNonBlocking));
+    for (auto& s2 : L.aux) ZK_HIP(ctx, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    ZK_HIP(ctx, hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+    for (auto& e : L.ev_join) ZK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : L.ev_part) ZK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    L.ready = true;
+    return ZK_OK;
+}
+void msm_lanes_destroy(zk_ctx* ctx) {
+    for (int i = 0; i < zk_ctx::kLanes; i++) {
+        zk_ctx::MsmLane& L = ctx->lanes[i];
+        if (i > 0 && L.main) hipStreamDestroy(L.main);
+        for (auto& s2 : L.aux)
+            if (s2) hipStreamDestroy(s2);
+        if (L.ev_fork) hipEventDestroy(L.ev_fork);
+        for (auto& e : L.ev_join)
+            if (e) hipEventDestroy(e);
+        for (auto& e : L.ev_part)
+            if (e) hipEventDestroy(e);
+        for (auto& e : L.ev_cls)
+            if (e) hipEventDestroy(e);
+        L = zk_ctx::MsmLane();
+    }
+}
+
 template <class Cv>
-static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) {
-    typedef typename Cv::HostF HF;
-    constexpr size_t kOutWords = 3 * zkhost::fe_words<HF>();  // 18 (G1) / 36 (G2) u64 per result
-    if (!h_out && count) return fail(ctx, ZK_ERR_INVALID, "null argument");
+static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
+    const MsmItem* items = run.items.data();
+    const size_t count = run.count;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        const int rc = msm_lane_prepare(ctx, run.lane);
+        if (rc) return rc;
+    }
+    zk_ctx::MsmLane& L = ctx->lanes[run.lane];
+    const bool timers = run.lane == 0;
+    std::vector<MsmClass>& classes = run.classes;
     const Tuning& tn = tuning();
     const u32 T_env = (u32)tn.msm_tile;
     const bool pair_env = tn.msm_pair != 0;
@@ -1064,7 +1170,6 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
     const int stage_env = (int)tn.msm_stage;
     const int split_env = (int)tn.msm_split;  // measured on MI355X: no gain (every phase is ALU-bound), off by default
     // ---- validate + classify by window width ----
-    std::vector<MsmClass> classes;
     for (size_t k = 0; k < count; k++) {
         const MsmItem& it = items[k];
         if (!it.srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
@@ -1074,7 +1179,7 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
                         it.srs->n - std::min(it.offset, it.srs->n), it.offset);
         if (it.n >= ((size_t)1 << 30)) return fail(ctx, ZK_ERR_INVALID, "msm: n too large");  // 2n row entries, 31-bit indices
         if (it.n == 0) {
-            zkhost::write_normalised(zkhost::jac_inf_t<HF>(), h_out + kOutWords * k);
+            run.empty_items.push_back(k);
             continue;
         }
         const bool shared = Cv::kEndo && it.srs->d_table != nullptr && ctx->msm_window_override <= 0;
@@ -1211,13 +1316,44 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
         }
     // allocate every arena once, before anything is enqueued (no reallocation between classes)
     static const int slot[10] = {0, 1, 2, 3, 4, 5, 6, 9, 8, 11};
-    void* buf[10];
-    for (int i = 0; i < 10; i++) {
-        buf[i] = scratch(ctx, slot[i], need[i]);
-        if (!buf[i]) return ZK_ERR_OOM;
+    void** buf = run.buf;
+    run.pinned_bytes = pinned_bytes;
+    if (run.own_mem) {
+        for (int i = 0; i < 10; i++) {
+            const int rc = zk_malloc(ctx, std::max<size_t>(need[i], 256), &buf[i]);
+            if (rc) {
+                msm_release(ctx, run);
+                return rc;
+            }
+        }
+        for (size_t i = 0; i < ctx->pin_free.size() && !run.hpin; i++)
+            if (ctx->pin_free[i].first >= pinned_bytes) {
+                run.hpin = (char*)ctx->pin_free[i].second;
+                run.pinned_bytes = ctx->pin_free[i].first;
+                ctx->pin_free.erase(ctx->pin_free.begin() + i);
+            }
+        if (!run.hpin) {
+            run.pinned_bytes = std::max<size_t>(pinned_bytes, 4096);
+            const hipError_t e = hipHostMalloc((void**)&run.hpin, run.pinned_bytes, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                run.hpin = nullptr;
+                msm_release(ctx, run);
+                return hip_fail(ctx, e, "hipHostMalloc(msm job)");
+            }
+        }
+    } else {
+        for (int i = 0; i < 10; i++) {
+            buf[i] = scratch(ctx, slot[i], need[i]);
+            if (!buf[i]) return ZK_ERR_OOM;
+        }
+        run.hpin = (char*)pinned(ctx, pinned_bytes);
+        if (!run.hpin) return ZK_ERR_OOM;
     }
-    char* hpin = (char*)pinned(ctx, pinned_bytes);
-    if (!hpin) return ZK_ERR_OOM;
+    char* hpin = run.hpin;
+    if (run.lane != 0) {  // the scalars are produced by work on the ctx stream
+        hipEventRecord(ctx->ev_async_in, ctx->stream);
+        hipStreamWaitEvent(L.main, ctx->ev_async_in, 0);
+    }
     // ---- enqueue every class without host synchronisation; independent classes go to separate
     // streams (the small ones are pure launch/latency chains and overlap with the big one).
     // Phase timers: sort of the first class, accumulation from the first part's launch to the last
@@ -1225,8 +1361,8 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
     const bool serial_env = tn.msm_serial != 0;  // diagnostics: all classes on the ctx stream (per-kernel times = work)
     const bool multi = classes.size() > 1 && !serial_env;
     if (multi) {
-        hipEventRecord(ctx->ev_fork, ctx->stream);
-        for (int k = 0; k < zk_ctx::kAux; k++) hipStreamWaitEvent(ctx->aux[k], ctx->ev_fork, 0);
+        hipEventRecord(L.ev_fork, L.main);
+        for (int k = 0; k < zk_ctx::kAux; k++) hipStreamWaitEvent(L.aux[k], L.ev_fork, 0);
     }
     // an error while classes are in flight: forked aux streams may still read the scratch arenas and the
     // caller's scalars -- drain the device before handing control (and those buffers) back
@@ -1235,14 +1371,15 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
         hipError_t _e = (call);                                      \
         if (_e != hipSuccess) {                                      \
             hipDeviceSynchronize();                                  \
+            msm_release(ctx, run);                                   \
             return zk::hip_fail(ctx, _e, #call);                     \
         }                                                            \
     } while (0)
     size_t cls_i = 0;
     for (auto& cl : classes) {
         const size_t nitems = cl.idx.size(), ns = cl.ns, nb = cl.nb, total = cl.total;
-        const bool t_first = (cls_i == 0), t_last = (cls_i + 1 == (size_t)classes[0].nparts);  // the first class's parts carry the timers
-        hipStream_t st = (!multi || cls_i == 0) ? ctx->stream : ctx->aux[(cls_i - 1) % zk_ctx::kAux];
+        const bool t_first = timers && (cls_i == 0), t_last = timers && (cls_i + 1 == (size_t)classes[0].nparts);  // the first class's parts carry the timers
+        hipStream_t st = (!multi || cls_i == 0) ? L.main : L.aux[(cls_i - 1) % zk_ctx::kAux];
         u32* digits = (u32*)((char*)buf[0] + cl.off[0]);
         u32* sorted = digits;  // the digits are dead once partitioned: the sorted entries take their place
         u32* part_idx = (u32*)((char*)buf[1] + cl.off[1]);
@@ -1293,11 +1430,11 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
                                cl.np, cl.low_bits, cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, oc, cl.T, cl.tiles_per_w, tile_b, sorted);
         }
         if (t_first) hipEventRecord(ctx->ev[1], st);
-        if (cl.part > 0) hipStreamWaitEvent(st, ctx->ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
+        if (cl.part > 0) hipStreamWaitEvent(st, L.ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
         hipLaunchKernelGGL((k_accum_tiles<Cv>), dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const uint2*)oc, (const u32*)tile_b, cl.row_len,
                            (u32)ns, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
-        if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(ctx->ev_part[cl.part % zk_ctx::kParts], st);
+        if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(L.ev_part[cl.part % zk_ctx::kParts], st);
         if (t_last) hipEventRecord(ctx->ev[4], st);
         const NarrowRows nrw{cl.rpi, cl.w0, cl.narrow_from};
         if (Cv::kQuad && total <= fixq_max)
@@ -1315,8 +1452,19 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
         void* out = bufB;
         int rows = 1;
         size_t len = nb;
+        bool tail_done = false;
         while (len > 1) {
             size_t threads = cl.rows * (size_t)(rows + 1) * (len >> 1);
+            if constexpr (Cv::kQuad) {
+                if (tn.msm_tail && 4 * threads <= kTailLanes) {  // the rest of the reduction + the conversion in one workgroup
+                    hipLaunchKernelGGL(k_tail_quad, dim3(1), dim3(kTailThreads), 0, st, in, out, (int)cl.rows, rows, len, nrw, cl.c, cl.npair, cl.pair ? 1 : 0);
+                    int passes = 0;
+                    for (size_t l2 = len; l2 > 1; l2 >>= 1) passes++;
+                    if (passes & 1) std::swap(in, out);  // the points ended in `in`, the Jacobians went to `out`
+                    tail_done = true;
+                    break;
+                }
+            }
             if (Cv::kQuad && threads <= quad_max)  // too few additions to fill the chip: spend four lanes on each
                 hipLaunchKernelGGL(k_halve_quad, dim3((unsigned)((4 * threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
                                    (int)cl.rows, rows, len, nrw);
@@ -1328,28 +1476,41 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
             len >>= 1;
         }
         // rows == c reduced points per window row -> Jacobian points in the reference form
-        {
+        if (!tail_done) {
             const size_t threads = cl.rows * (size_t)cl.npair;
             hipLaunchKernelGGL((k_finish<Cv>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, (const void*)in, out, cl.rows, cl.c, cl.npair, cl.pair ? 1 : 0);
         }
         ZK_HIP_INFLIGHT(ctx, hipGetLastError());
         ZK_HIP_INFLIGHT(ctx, hipMemcpyAsync(h_pts, out, cl.rows * (size_t)cl.npair * Cv::kJacBytes, hipMemcpyDeviceToHost, st));
         if (t_last) hipEventRecord(ctx->ev[3], st);
-        while (ctx->ev_cls.size() <= cls_i) {  // one completion event per class: the host starts on a class as soon as it lands
+        while (L.ev_cls.size() <= cls_i) {  // one completion event per class: the host starts on a class as soon as it lands
             hipEvent_t e;
             ZK_HIP_INFLIGHT(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->ev_cls.push_back(e);
+            L.ev_cls.push_back(e);
         }
-        hipEventRecord(ctx->ev_cls[cls_i], st);
+        hipEventRecord(L.ev_cls[cls_i], st);
         cls_i++;
     }
 #undef ZK_HIP_INFLIGHT
-    if (multi) {  // join: later work on the ctx stream is ordered after every class
+    if (multi) {  // join: later work on the lane's main stream is ordered after every class
         for (int k = 0; k < zk_ctx::kAux; k++) {
-            hipEventRecord(ctx->ev_join[k], ctx->aux[k]);
-            hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0);
+            hipEventRecord(L.ev_join[k], L.aux[k]);
+            hipStreamWaitEvent(L.main, L.ev_join[k], 0);
         }
     }
+    return ZK_OK;
+}
+
+template <class Cv>
+static int msm_finish(zk_ctx* ctx, MsmRun& run, uint64_t* h_out) {
+    typedef typename Cv::HostF HF;
+    constexpr size_t kOutWords = 3 * zkhost::fe_words<HF>();  // 18 (G1) / 36 (G2) u64 per result
+    const size_t count = run.count;
+    std::vector<MsmClass>& classes = run.classes;
+    zk_ctx::MsmLane& L = ctx->lanes[run.lane];
+    char* hpin = run.hpin;
+    for (size_t k : run.empty_items) zkhost::write_normalised(zkhost::jac_inf_t<HF>(), h_out + kOutWords * k);
+    if (classes.empty()) return ZK_OK;
     // ---- host combine: one doubling chain of ~129 steps per item, run by the ctx's worker pool.  Classes
     // are taken in the order they finish on the device (least work first; the parts of a staggered class
     // in window order): while the big class is still running, the items of the small ones are already
@@ -1374,9 +1535,10 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
     for (size_t oi = 0; oi < order.size(); oi++) {
         const MsmClass& cl = classes[order[oi]];
         {
-            const hipError_t e = hipEventSynchronize(ctx->ev_cls[order[oi]]);
+            const hipError_t e = hipEventSynchronize(L.ev_cls[order[oi]]);
             if (e != hipSuccess) {
                 if (pool) pool->wait();  // jobs in flight reference this frame
+                msm_release(ctx, run);
                 return hip_fail(ctx, e, "hipEventSynchronize(class done)");
             }
         }
@@ -1391,7 +1553,9 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
             host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();  // exposed part
         }
     }
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(L.main));
+    msm_release(ctx, run);
+    if (run.lane != 0) return ZK_OK;  // (the phase timers belong to the blocking calls)
     float ms;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
     ctx->msm_ms[0] = ms;  // digits + sort (first part)
@@ -1406,8 +1570,54 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
     return ZK_OK;
 }
 
+template <class Cv>
+static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) {
+    if (!h_out && count) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    MsmRun run;
+    run.count = count;
+    run.items.assign(items, items + count);
+    int rc = msm_enqueue<Cv>(ctx, run);
+    if (rc) return rc;
+    return msm_finish<Cv>(ctx, run, h_out);
+}
+
 int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) { return msm_batch<CvG1>(ctx, items, count, h_out); }
 int msm_g2_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) { return msm_batch<CvG2>(ctx, items, count, h_out); }
+
+}  // namespace zk
+struct zk_msm_job {
+    zk::MsmRun run;
+};
+namespace zk {
+int msm_g1_batch_async(zk_ctx* ctx, const MsmItem* items, size_t count, zk_msm_job** job) {
+    if (!job) return fail(ctx, ZK_ERR_INVALID, "null argument");
+    *job = nullptr;
+    zk_msm_job* j = new zk_msm_job();
+    j->run.count = count;
+    j->run.items.assign(items, items + count);
+    j->run.lane = 1 + (int)(ctx->async_seq++ & 1u);
+    j->run.own_mem = true;
+    const int rc = msm_enqueue<CvG1>(ctx, j->run);
+    if (rc) {
+        delete j;
+        return rc;
+    }
+    *job = j;
+    return ZK_OK;
+}
+int msm_job_wait(zk_ctx* ctx, zk_msm_job* job, uint64_t* h_out) {
+    if (!job) return fail(ctx, ZK_ERR_INVALID, "null job");
+    int rc;
+    if (!h_out && job->run.count) {
+        hipStreamSynchronize(ctx->lanes[job->run.lane].main);
+        msm_release(ctx, job->run);
+        rc = fail(ctx, ZK_ERR_INVALID, "null argument");
+    } else {
+        rc = msm_finish<CvG1>(ctx, job->run, h_out);
+    }
+    delete job;
+    return rc;
+}
 
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out) {
     if (!srs || !h_out) return fail(ctx, ZK_ERR_INVALID, "null argument");

@@ -132,6 +132,48 @@ def comm_init_all(ctxs) -> None:
         raise ZkError(rc, (lib.zk_last_error(ctxs[0].h) or b"").decode() if ctxs else "zk_comm_init_all")
 
 
+class MsmJob:
+    """an asynchronous batch of MSMs in flight (zk_msm_g1_batch_async / zk_msm_wait)"""
+
+    def __init__(self, ctx: "Ctx", srs_list, scalars_list, lens, offsets=None):
+        self.ctx, self.count = ctx, len(lens)
+        self.keep = (list(srs_list), list(scalars_list))  # inputs must outlive the job
+        self.lens = [int(x) for x in lens]
+        self.h = None
+        self.res = None
+        if self.count == 0:
+            self.res = np.zeros((0, 18), dtype=np.uint64)
+            return
+        count = self.count
+        h = (ctypes.c_void_p * count)(*[s.h for s in srs_list])
+        sp = (ctypes.c_void_p * count)(*[_ptr(s) for s in scalars_list])
+        nn = (ctypes.c_size_t * count)(*self.lens)
+        off = (ctypes.c_size_t * count)(*[int(x) for x in (offsets or [0] * count)])
+        job = ctypes.c_void_p()
+        rc = ctx.lib.zk_msm_g1_batch_async(ctx.h, count, h, off, sp, nn, ctypes.byref(job))
+        if rc == ZK_ERR_LENGTH:
+            raise MsmLengthError(rc, (ctx.lib.zk_last_error(ctx.h) or b"").decode(), 0)
+        ctx._check(rc)
+        self.h = job.value
+
+    def wait(self) -> np.ndarray:
+        if self.res is None:
+            out = np.zeros((self.count, 18), dtype=np.uint64)
+            h, self.h = self.h, None
+            self.ctx._check(self.ctx.lib.zk_msm_wait(self.ctx.h, h, _h(out)))
+            self.res, self.keep = out, None
+        return self.res
+
+    def __del__(self):
+        try:
+            if self.h and getattr(self.ctx, "h", None):  # never waited for: drain and release it
+                out = np.zeros((self.count, 18), dtype=np.uint64)
+                self.ctx.lib.zk_msm_wait(self.ctx.h, self.h, _h(out))
+                self.h = None
+        except Exception:
+            pass
+
+
 class Ctx:
     def __init__(self, device: int = 0):
         self.lib = _lib.lib()
@@ -375,6 +417,11 @@ class Ctx:
 
             print("zkhip-msm", [int(x) for x in lens], [round(float(x), 3) for x in self.msm_last_timing()], file=sys.stderr)
         return out
+
+    def msm_g1_batch_async(self, srs_list, scalars_list, lens, offsets=None):
+        """start a batch of MSMs on the ctx's job streams; -> job with .wait() -> [count, 18].  The scalar buffers must
+        stay alive and unmodified until wait() (the job object keeps references to them)."""
+        return MsmJob(self, srs_list, scalars_list, lens, offsets)
 
     # ---- G2 (same pipeline over Fq2) ----
     def srs_register_g2(self, bases: np.ndarray, stride: int = 192) -> Srs:

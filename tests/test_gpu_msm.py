@@ -232,3 +232,42 @@ def test_device_buffers_are_recycled(ctx):
     assert b.ptr == p
     c = ctx.alloc(12345 * 32)
     assert c.ptr != p
+
+
+def test_async_jobs_match_blocking_calls(ctx, co):
+    """zk_msm_g1_batch_async / zk_msm_wait: two jobs in flight with sumchecks running on the ctx stream in between;
+    results bit-identical to the blocking batch (and through it to the oracle: test_batch_*), in any wait order"""
+    sizes = [1 << 14, 300, 1 << 12, 0, 5000, 1 << 15]
+    srs = [ctx.srs_generate(101 + i, 17 + 2 * i, max(n, 1)) for i, n in enumerate(sizes)]
+    srs[0].precompute(0)  # one item on the window-table path
+    sc = [rand_fr(max(n, 1), 900 + i) for i, n in enumerate(sizes)]
+    dsc = [ctx.to_device(s) for s in sc]
+    want = ctx.msm_g1_batch(srs, dsc, sizes)
+    assert (jac_norm_to_affine(want[1]) == co.msm_g1(srs[1].download()[:300], sc[1][:300])).all()
+    f, g, ch = rand_fr(1 << 16, 1), rand_fr(1 << 16, 2), rand_fr(16, 3)
+    df, dg = ctx.to_device(f), ctx.to_device(g)
+    tr0 = ctx.sumcheck_product(df, dg, 1 << 16, ch)
+    j1 = ctx.msm_g1_batch_async(srs, dsc, sizes)
+    tr1 = ctx.sumcheck_product(df, dg, 1 << 16, ch)  # shares the GPU (and would share scratch arenas) with the job
+    j2 = ctx.msm_g1_batch_async(srs[:3], dsc[:3], sizes[:3])
+    q, val = ctx.open_rounds(df, 1 << 16, ch)
+    j3 = ctx.msm_g1_batch_async(srs, dsc, sizes)
+    r2 = j2.wait()
+    r1 = j1.wait()
+    r3 = j3.wait()
+    assert (r1 == want).all() and (r3 == want).all() and (r2 == want[:3]).all()
+    assert (r1 is j1.wait())  # idempotent
+    for a, b in zip(tr0, tr1):
+        assert (a == b).all()
+    assert (val == co.open_quotients(f, ch)[1]).all()
+    # scalars produced on the ctx stream right before the job starts (the job must be ordered after them)
+    a2 = ctx.fr_add(dsc[0], dsc[0], sizes[0])
+    j = ctx.msm_g1_batch_async([srs[0]], [a2], [sizes[0]])
+    got = jac_norm_to_affine(j.wait()[0])
+    assert (got == co.g1_add_affine(jac_norm_to_affine(want[0]), jac_norm_to_affine(want[0]))).all()
+    # an error at enqueue time leaves nothing behind
+    import zkhip
+
+    with pytest.raises(zkhip.MsmLengthError):
+        ctx.msm_g1_batch_async([srs[1]], [dsc[0]], [sizes[0]])
+    assert (ctx.msm_g1_batch_async(srs, dsc, sizes).wait() == want).all()
