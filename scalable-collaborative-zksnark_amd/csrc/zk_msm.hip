@@ -799,46 +799,6 @@ __global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void
     Cv::finish(acc, out, t);
 }
 
-// The END of the bucket reduction in one launch: once a pass is down to a few hundred additions, every remaining pass is one
-// addition of pure latency (~6 us on a quad) plus a kernel boundary and a cold start from L2 (~12 us per launch measured).
-// ONE workgroup runs all of them -- a pass is <= kTailLanes / 4 quad additions, the workgroup barrier separates the passes, the
-// rows ping-pong between the same two buffers (they sit in this CU's L2 slice) -- and converts the c reduced points of every
-// row (k_finish).  Saves the launch + warm-up of ~6 dependent kernels per MSM (profiles/r03*_msm_*_dispatch_timeline.txt).
-static constexpr int kTailThreads = 1024;
-static constexpr size_t kTailLanes = 2048;  // quad lanes of the first fused pass (two sweeps of the workgroup)
-__global__ void __launch_bounds__(kTailThreads) k_tail_quad(void* bufA, void* bufB, int W, int rows, size_t len, NarrowRows nr, int c, int nout,
-                                                          int pair) {
-    void* in = bufA;
-    void* out = bufB;
-    while (len > 1) {
-        const size_t lanes = 4 * (size_t)W * (size_t)(rows + 1) * (len >> 1);
-        for (size_t tq = threadIdx.x; tq < lanes; tq += kTailThreads) halve_quad_body(in, out, W, rows, len, nr, tq);
-        __threadfence_block();
-        __syncthreads();
-        void* t = in;
-        in = out;
-        out = t;
-        rows++;
-        len >>= 1;
-    }
-    // rows == c points per bucket row -> Jacobian, reference Montgomery form (k_finish)
-    for (size_t t = threadIdx.x; t < (size_t)W * nout; t += kTailThreads) {
-        const size_t row = t / nout;
-        const int j = (int)(t % nout);
-        Xyzz30 acc;
-        if (!pair) {
-            acc = xyzz30_load(in, row * c + j);
-        } else {
-            const int planes = c - 1;
-            xyzz30_set_inf(acc);
-            if (2 * j < planes) acc = xyzz30_load(in, row * c + 2 * j);
-            if (j == 0) acc = xyzz30_add(acc, xyzz30_load(in, row * c + (c - 1)));
-            if (2 * j + 1 < planes) acc = xyzz30_add(acc, xyzz30_dbl(xyzz30_load(in, row * c + 2 * j + 1)));
-        }
-        CvG1::finish(acc, out, t);
-    }
-}
-
 // SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine, packed 96 B), one lane per point.
 // With it every window's digit can use the SAME bucket set (the factor 2^{c w} is in the base).
 __global__ void __launch_bounds__(kBlk) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
@@ -1452,19 +1412,8 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         void* out = bufB;
         int rows = 1;
         size_t len = nb;
-        bool tail_done = false;
         while (len > 1) {
             size_t threads = cl.rows * (size_t)(rows + 1) * (len >> 1);
-            if constexpr (Cv::kQuad) {
-                if (tn.msm_tail && 4 * threads <= kTailLanes) {  // the rest of the reduction + the conversion in one workgroup
-                    hipLaunchKernelGGL(k_tail_quad, dim3(1), dim3(kTailThreads), 0, st, in, out, (int)cl.rows, rows, len, nrw, cl.c, cl.npair, cl.pair ? 1 : 0);
-                    int passes = 0;
-                    for (size_t l2 = len; l2 > 1; l2 >>= 1) passes++;
-                    if (passes & 1) std::swap(in, out);  // the points ended in `in`, the Jacobians went to `out`
-                    tail_done = true;
-                    break;
-                }
-            }
             if (Cv::kQuad && threads <= quad_max)  // too few additions to fill the chip: spend four lanes on each
                 hipLaunchKernelGGL(k_halve_quad, dim3((unsigned)((4 * threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
                                    (int)cl.rows, rows, len, nrw);
@@ -1476,7 +1425,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
             len >>= 1;
         }
         // rows == c reduced points per window row -> Jacobian points in the reference form
-        if (!tail_done) {
+        {
             const size_t threads = cl.rows * (size_t)cl.npair;
             hipLaunchKernelGGL((k_finish<Cv>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, (const void*)in, out, cl.rows, cl.c, cl.npair, cl.pair ? 1 : 0);
         }
