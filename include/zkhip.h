@@ -133,6 +133,29 @@ int zk_open_rounds(zk_ctx *ctx, const void *d_tab, size_t len, const uint64_t *h
  * d_tree receives 2N Fr: tree[0..N) = x, tree[N+j] = tree[2j]*tree[2j+1], tree[2N-1] = 0. */
 int zk_product_tree(zk_ctx *ctx, const void *d_x, size_t N, void *d_tree);
 
+/* Several INDEPENDENT calls of the four functions above in one go.  A proof issues them in groups that do not depend on each
+ * other -- three product sumchecks and three opens per layer of the wiring identity (hyperplonk/src/dhyperplonk.rs:417-478),
+ * the six gate sumchecks (:223-260), the opens of :383-407 -- and most of them are chains of one to three latency-bound
+ * launches.  The batch gives every item its own scratch, spreads the items over several streams and waits ONCE; every
+ * output is bit-identical to the one-call-at-a-time form (same kernels, same launch plan per item).
+ *   mode 0: zk_sumcheck          h_sums 2 log2(len) Fr, h_last_f = the remaining element
+ *   mode 1: zk_sumcheck_product  h_sums 3 log2(len) Fr, h_last_f / h_last_g
+ *   mode 2: zk_fold              n_points points, d_out receives len >> min(log2 len, n_points) Fr
+ *   mode 3: zk_open_rounds       d_out receives the len - 1 quotient elements, h_last_f = the value */
+typedef struct {
+    int mode;
+    const void *d_f;
+    const void *d_g;
+    size_t len;
+    const uint64_t *h_chal;
+    size_t n_points;
+    uint64_t *h_sums;
+    uint64_t *h_last_f;
+    uint64_t *h_last_g;
+    void *d_out;
+} zk_sc_item;
+int zk_sumcheck_batch(zk_ctx *ctx, size_t count, const zk_sc_item *items);
+
 /* ---- G1 MSM -------------------------------------------------------------------------- */
 /* Upload a base vector once (the reference clones powers_of_g[level] per call, dpoly_comm.rs:258).
  * h_bases: n affine points at `stride` bytes (96 or 104).  The device copy is the library's own:

@@ -361,6 +361,10 @@ int zk_open_rounds(zk_ctx* ctx, const void* d_tab, size_t len, const uint64_t* h
     NEED(ctx, d_tab && h_value && (len <= 1 || (h_point && d_q_out)));
     return multilinear_run(ctx, 3, d_tab, nullptr, len, h_point, (size_t)log2_exact(len), nullptr, h_value, nullptr, nullptr, d_q_out);
 }
+int zk_sumcheck_batch(zk_ctx* ctx, size_t count, const zk_sc_item* items) {
+    NEED(ctx, count == 0 || items);
+    return multilinear_batch(ctx, items, count);
+}
 int zk_product_tree(zk_ctx* ctx, const void* d_x, size_t N, void* d_tree) {
     NEED(ctx, d_x && d_tree);
     return product_tree(ctx, d_x, N, d_tree);

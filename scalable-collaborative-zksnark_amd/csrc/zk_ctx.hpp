@@ -131,6 +131,7 @@ int fr_batch_div(zk_ctx* ctx, const void* num, const void* den, void* out, size_
 // mode 0 plain sums, 1 product sums, 2 fold only, 3 open quotients
 int multilinear_run(zk_ctx* ctx, int mode, const void* d_f, const void* d_g, size_t len, const uint64_t* h_chal,
                     size_t rounds, uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q);
+int multilinear_batch(zk_ctx* ctx, const zk_sc_item* items, size_t count);
 int product_tree(zk_ctx* ctx, const void* d_x, size_t N, void* d_tree);
 int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n);
 

@@ -634,7 +634,7 @@ static size_t pass_blocks(zk_ctx* ctx, size_t m, int k, int mode) {
     return blocks > maxb ? maxb : blocks;
 }
 template <int K, int MODE>
-static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void* go, size_t m, const uint64_t* chal, void* partials,
+static int launch_pass(zk_ctx* ctx, hipStream_t st, const void* f, const void* g, void* fo, void* go, size_t m, const uint64_t* chal, void* partials,
                        void* qbase, int t1mode) {
     constexpr int W = ModeTraits<MODE>::W;
     const size_t blocks = pass_blocks(ctx, m, K, MODE);
@@ -645,13 +645,13 @@ static int launch_pass(zk_ctx* ctx, const void* f, const void* g, void* fo, void
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_pass<K, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (MODE == 1) {
         if (t1mode == 2) {  // test switch: t1 of every round on the device
-            hipLaunchKernelGGL((k_pass<K, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
+            hipLaunchKernelGGL((k_pass<K, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), lds, st, f, g, fo, go, m, ch, partials,
                                qbase, t1mode);
             ZK_HIP(ctx, hipGetLastError());
             return ZK_OK;
         }
     }
-    hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, f, g, fo, go, m, ch, partials,
+    hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, st, f, g, fo, go, m, ch, partials,
                        qbase, t1mode);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
@@ -841,7 +841,7 @@ static size_t flat_blocks(zk_ctx* ctx, size_t m, int K, bool plain = false) {
     return blocks > maxb ? maxb : blocks;
 }
 // partials == nullptr: fold only (k_fold_flat); else the plain sumcheck's pass (k_plain_flat, K <= 3)
-static int launch_fold_flat(zk_ctx* ctx, const void* f, void* fo, size_t m, int K, const uint64_t* chal, void* partials = nullptr) {
+static int launch_fold_flat(zk_ctx* ctx, hipStream_t st, const void* f, void* fo, size_t m, int K, const uint64_t* chal, void* partials = nullptr) {
     using namespace hfr;
     FlatW fw;
     std::memset(&fw, 0, sizeof(fw));
@@ -862,17 +862,17 @@ static int launch_fold_flat(zk_ctx* ctx, const void* f, void* fo, size_t m, int 
     for (size_t S = 0; S < w.size(); S++) std::memcpy(&fw.w[S], &w[S], 32);
     const size_t blocks = flat_blocks(ctx, m, K, partials != nullptr);
     if (partials) {
-        if (K == 3) hipLaunchKernelGGL((k_plain_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw, partials);
-        else if (K == 2) hipLaunchKernelGGL((k_plain_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw, partials);
-        else if (K == 1) hipLaunchKernelGGL((k_plain_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw, partials);
+        if (K == 3) hipLaunchKernelGGL((k_plain_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials);
+        else if (K == 2) hipLaunchKernelGGL((k_plain_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials);
+        else if (K == 1) hipLaunchKernelGGL((k_plain_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials);
         else return fail(ctx, ZK_ERR_INVALID, "internal: flat plain pass of %d rounds", K);
         ZK_HIP(ctx, hipGetLastError());
         return ZK_OK;
     }
-    if (K == 4) hipLaunchKernelGGL((k_fold_flat<4>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
-    else if (K == 3) hipLaunchKernelGGL((k_fold_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
-    else if (K == 2) hipLaunchKernelGGL((k_fold_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
-    else hipLaunchKernelGGL((k_fold_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, f, fo, m, fw);
+    if (K == 4) hipLaunchKernelGGL((k_fold_flat<4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw);
+    else if (K == 3) hipLaunchKernelGGL((k_fold_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw);
+    else if (K == 2) hipLaunchKernelGGL((k_fold_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw);
+    else hipLaunchKernelGGL((k_fold_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -899,8 +899,8 @@ static void derive_t1(uint64_t* sums, const uint64_t* chal, size_t rounds) {
 }
 
 template <int MODE>
-static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, unsigned E, int pre, int rl, const uint64_t* chal, void* sums,
-                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out, void* red_wide, int t1mode) {
+static int launch_local(zk_ctx* ctx, hipStream_t st, const void* f, const void* g, unsigned G, unsigned E, int pre, int rl, const uint64_t* chal, void* sums,
+                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out, void* red_wide, int t1mode, bool want_ts) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     TailChal tc;
@@ -918,62 +918,84 @@ static int launch_local(zk_ctx* ctx, const void* f, const void* g, unsigned G, u
     while ((1u << elog) < E) elog++;
     // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_local<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(kLocalThreads), lds, ctx->stream, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
-                       rp ? *rp : none, red_out, red_wide, t1mode, sc_xcd_map(), pre, sc_ts_next());
+    hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(kLocalThreads), lds, st, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
+                       rp ? *rp : none, red_out, red_wide, t1mode, sc_xcd_map(), pre, want_ts ? sc_ts_next() : nullptr);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
 
+// One call of the family, in three steps so that several independent calls can share the enqueue and ONE completion
+// (multilinear_batch): sc_plan (geometry, scratch sizes), sc_enqueue (every launch of the call on a given stream, into
+// given scratch and result blocks -- no synchronisation), sc_collect (host: the Montgomery reductions of the lazily reduced
+// sums, the derived t1, the rounds of the flat plain passes; copies into the caller's arrays).
+struct ScStage {
+    int kind;  // 0 = pass, 1 = local (G > 1)
+    int k;     // rounds
+    size_t m, blocks, part_off;
+    unsigned G, E;
+    int pre;
+};
+struct ScColStage {
+    size_t done, k, base;
+};
+struct ScCall {
+    // the request
+    int mode = 0;  // 0 plain sums, 1 product sums, 2 fold only, 3 open quotients
+    const void* d_f = nullptr;
+    const void* d_g = nullptr;
+    size_t len = 0, rounds = 0;
+    const uint64_t* h_chal = nullptr;
+    uint64_t* h_sums = nullptr;
+    uint64_t* h_last_f = nullptr;
+    uint64_t* h_last_g = nullptr;
+    void* d_out = nullptr;
+    void* d_q = nullptr;
+    // sc_plan
+    std::vector<ScStage> plan;
+    size_t emax = 0, part_bytes = 0, res_elems = 0, res_bytes = 0;
+    size_t buf_bytes[4] = {0, 0, 0, 0};  // ping-pong tables: f (len/2, len/4), g (len/2, len/4)
+    bool plain_flat = false;
+    // resources, assigned by the caller between plan and enqueue
+    hipStream_t st = nullptr;
+    void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
+    char* d_part = nullptr;
+    char* d_res = nullptr;   // result block: [sums rounds*W][last_f][last_g][wide sums]; pinned host memory (device-visible) or device
+    char* h_res = nullptr;   // where the host reads it (== d_res when that is pinned host memory)
+    bool want_ts = false;
+    // sc_enqueue -> sc_collect
+    bool derive = false;
+    size_t wide_rounds = 0;
+    std::vector<ScColStage> col_stages;
+};
+
 template <int MODE>
-static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, const uint64_t* h_chal, size_t rounds,
-                    uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q) {
+static int sc_plan(zk_ctx* ctx, ScCall& c) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
-    const bool host_ts = tuning().sc_ts == 2;  // host-side phases of a call on stderr
-    const auto hts0 = std::chrono::steady_clock::now();
-    double hts_us[6];
-    int hts_n = 0;
-    auto hts = [&](bool last) {
-        if (!host_ts) return;
-        hts_us[hts_n++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hts0).count();
-        if (last) fprintf(stderr, "[sc host] launched %.2f synced %.2f copied %.2f reduced %.2f derived %.2f us\n", hts_us[0], hts_us[1], hts_us[2], hts_us[3], hts_us[4]);
-    };
+    const size_t len = c.len, rounds = c.rounds;
     const size_t emax = TWO ? kLocalMaxE / 2 : kLocalMaxE;  // table elements a workgroup holds in LDS
+    c.emax = emax;
     const int use_pre = tuning().sc_pre != 0;
     const size_t local_max = emax * sc_local_g() * (use_pre ? 2 : 1);  // longest table handed to a local stage (x2: its pre-round)
     const size_t fr = 32;
-    // result block on device: [sums rounds*W][last_f][last_g]
+    // result block: [sums rounds*W][last_f][last_g]
     // (written by the last kernel straight into pinned host memory: a few dozen 32-byte stores over the link instead of
     // a copy kernel and one more kernel boundary: the same kernel time, 1-4 us less per call)
     // product sumcheck: + one 80-byte slot per sum for the lazily reduced sums of the HBM passes (see struct Wide)
-    const size_t res_elems = rounds * W + 2;
-    const bool plain_flat = MODE == 0 && sc_plain_flat();
-    const size_t res_bytes = res_elems * fr + (MODE == 1 ? rounds * W * kWideBytes : (plain_flat ? (rounds + 1) * 4 * kWideBytes : 0));  // (plain: 8 column sums per 3 rounds)
-    const bool pinned_out = tuning().sc_pinned_out != 0;
-    char* d_res = (MODE != 2 && pinned_out) ? (char*)pinned(ctx, res_bytes) : (char*)scratch(ctx, 5, res_bytes);
-    if (!d_res) return ZK_ERR_OOM;
-    void* d_last_f = d_res + rounds * W * fr;
-    void* d_last_g = d_res + (rounds * W + 1) * fr;
-    char* d_wide = d_res + res_elems * fr;
-
+    c.res_elems = rounds * W + 2;
+    c.plain_flat = MODE == 0 && sc_plain_flat();
+    c.res_bytes = c.res_elems * fr + (MODE == 1 ? rounds * W * kWideBytes : (c.plain_flat ? (rounds + 1) * 4 * kWideBytes : 0));  // (plain: 8 column sums per 3 rounds)
     // ---- plan: HBM passes (K rounds fused in registers) down to local_max, one multi-workgroup local
     // stage down to <= 256 elements, one single-workgroup local stage for the rest ----
-    struct Stage {
-        int kind;  // 0 = pass, 1 = local (G > 1)
-        int k;     // rounds
-        size_t m, blocks, part_off;
-        unsigned G, E;
-        int pre;
-    };
-    std::vector<Stage> plan;
+    c.plan.clear();
     size_t part_bytes = 0, mm = len, dd = 0;
     while (dd < rounds && mm > emax) {
-        Stage st{};
+        ScStage st{};
         st.m = mm;
         if (mm > local_max) {
             st.kind = 0;
             st.k = (int)std::min<size_t>({(size_t)sc_pass_k(MODE), rounds - dd, (size_t)(ilog2(mm) - ilog2(local_max))});
-            st.blocks = plain_flat ? flat_blocks(ctx, mm, st.k, true) : pass_blocks(ctx, mm, st.k, MODE);
+            st.blocks = c.plain_flat ? flat_blocks(ctx, mm, st.k, true) : pass_blocks(ctx, mm, st.k, MODE);
         } else {
             st.kind = 1;
             st.pre = mm > emax * sc_local_g();  // (= 2 emax G: the first round runs out of the table)
@@ -984,31 +1006,42 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         }
         st.part_off = part_bytes;
         if (MODE == 1 && st.kind == 0) part_bytes += (size_t)st.k * W * st.blocks * (kBlock / 64) * kWideBytes;  // one 544-bit partial per wave
-        else if (plain_flat && st.kind == 0) part_bytes += ((size_t)1 << st.k) * st.blocks * (kBlock / 64) * kW9Bytes;  // 2^k column sums, one 288-bit partial per wave
+        else if (c.plain_flat && st.kind == 0) part_bytes += ((size_t)1 << st.k) * st.blocks * (kBlock / 64) * kW9Bytes;  // 2^k column sums, one 288-bit partial per wave
         else part_bytes += (size_t)st.k * W * st.blocks * fr;
-        plan.push_back(st);
+        part_bytes = (part_bytes + 15) & ~(size_t)15;
+        c.plan.push_back(st);
         mm = st.kind == 0 ? mm >> st.k : (size_t)st.G * (st.E >> (st.k - st.pre));
         dd += st.k;
     }
-    if ((int)plan.size() > ReducePlan::kMax) return fail(ctx, ZK_ERR_INVALID, "internal: too many passes");
-    void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (!plan.empty()) {
-        bufs[0] = scratch(ctx, 0, (len / 2) * fr);
-        bufs[1] = scratch(ctx, 1, std::max<size_t>(len / 4, 1) * fr);
-        if (!bufs[0] || !bufs[1]) return ZK_ERR_OOM;
-        if (TWO) {
-            bufs[2] = scratch(ctx, 2, (len / 2) * fr);
-            bufs[3] = scratch(ctx, 3, std::max<size_t>(len / 4, 1) * fr);
-            if (!bufs[2] || !bufs[3]) return ZK_ERR_OOM;
-        }
+    if ((int)c.plan.size() > ReducePlan::kMax) return fail(ctx, ZK_ERR_INVALID, "internal: too many passes");
+    c.part_bytes = W != 0 ? part_bytes : 0;
+    for (size_t& b : c.buf_bytes) b = 0;
+    if (!c.plan.empty()) {
+        c.buf_bytes[0] = (len / 2) * fr;
+        c.buf_bytes[1] = std::max<size_t>(len / 4, 1) * fr;
+        if (TWO) c.buf_bytes[2] = c.buf_bytes[0], c.buf_bytes[3] = c.buf_bytes[1];
     }
-    char* d_part = nullptr;
-    if (W != 0 && part_bytes) {
-        d_part = (char*)scratch(ctx, 4, part_bytes);
-        if (!d_part) return ZK_ERR_OOM;
-    }
-    const void* cf = d_f;
-    const void* cg = d_g;
+    return ZK_OK;
+}
+
+template <int MODE>
+static int sc_enqueue(zk_ctx* ctx, ScCall& c) {
+    constexpr int W = ModeTraits<MODE>::W;
+    constexpr bool TWO = ModeTraits<MODE>::TWO;
+    const size_t fr = 32, len = c.len, rounds = c.rounds, emax = c.emax;
+    const uint64_t* h_chal = c.h_chal;
+    void* const d_out = c.d_out;
+    void* const d_q = c.d_q;
+    void** bufs = c.bufs;
+    char* d_res = c.d_res;
+    char* d_part = c.d_part;
+    hipStream_t st_ = c.st;
+    void* d_last_f = d_res ? d_res + rounds * W * fr : nullptr;
+    void* d_last_g = d_res ? d_res + (rounds * W + 1) * fr : nullptr;
+    char* d_wide = d_res ? d_res + c.res_elems * fr : nullptr;
+    const std::vector<ScStage>& plan = c.plan;
+    const void* cf = c.d_f;
+    const void* cg = c.d_g;
     size_t m = len, done = 0;
     int flip = 0;
     // product sumcheck on tables from 2^18: t1 of every round after the first is derived on the host (derive_t1); below
@@ -1016,15 +1049,13 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
     // (the passes keep t1 for their very first round only: a call with passes always derives)
     // (test switch sc_t1_device: never derive -- every t1 is the device's own sum, through the FULLT1 passes)
     const bool derive = MODE == 1 && !tuning().sc_t1_device && (len >= ((size_t)1 << 18) || (!plan.empty() && plan[0].kind == 0));
-    size_t wide_rounds = 0;  // rounds whose sums come back as 544-bit integers
-    struct ColStage {
-        size_t done, k, base;
-    };
-    std::vector<ColStage> col_stages;  // plain sumcheck: passes whose rounds are derived from 2^k column sums
+    c.derive = derive;
+    c.wide_rounds = 0;  // rounds whose sums come back as 544-bit integers
+    c.col_stages.clear();  // plain sumcheck: passes whose rounds are derived from 2^k column sums
     size_t ncols = 0;
     ReducePlan rp;
     std::memset(&rp, 0, sizeof(rp));
-    for (const Stage& st : plan) {
+    for (const ScStage& st : plan) {
         const int k = st.k;
         const bool final_out = (MODE == 2) && (done + k == rounds);
         void* fo = final_out ? d_out : bufs[flip];
@@ -1033,24 +1064,24 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         void* part = d_part ? d_part + st.part_off : nullptr;
         int rc;
         const int t1mode = !derive ? 2 : (done == 0 ? 1 : 0);  // t1 on the device: 2 every round, 1 the stage's first round only, 0 never
-        if (st.kind == 1) rc = launch_local<MODE>(ctx, cf, cg, st.G, st.E, st.pre, k - st.pre, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode);
-        else if (MODE == 2 && sc_flat_k()) rc = launch_fold_flat(ctx, cf, fo, m, k, h_chal + 4 * done);
-        else if (plain_flat) rc = launch_fold_flat(ctx, cf, fo, m, k, h_chal + 4 * done, part);
-        else if (k == 3) rc = launch_pass<3, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
-        else if (k == 2) rc = launch_pass<2, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
-        else rc = launch_pass<1, MODE>(ctx, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
+        if (st.kind == 1) rc = launch_local<MODE>(ctx, st_, cf, cg, st.G, st.E, st.pre, k - st.pre, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode, c.want_ts);
+        else if (MODE == 2 && sc_flat_k()) rc = launch_fold_flat(ctx, st_, cf, fo, m, k, h_chal + 4 * done);
+        else if (c.plain_flat) rc = launch_fold_flat(ctx, st_, cf, fo, m, k, h_chal + 4 * done, part);
+        else if (k == 3) rc = launch_pass<3, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
+        else if (k == 2) rc = launch_pass<2, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
+        else rc = launch_pass<1, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
         if (rc) return rc;
         if (W != 0) {  // outputs of this stage: sums of rounds done .. done+k-1, consecutive in d_res
             const bool wide = MODE == 1 && st.kind == 0;
-            const bool cols = plain_flat && st.kind == 0;  // outputs: the 2^k column sums of the pass
+            const bool cols = c.plain_flat && st.kind == 0;  // outputs: the 2^k column sums of the pass
             const unsigned nout = cols ? 1u << k : (unsigned)(k * W);
             rp.partials[rp.n] = part;
             rp.nb[rp.n] = (unsigned)((wide || cols) ? st.blocks * (kBlock / 64) : st.blocks);
             rp.wide[rp.n] = wide ? 1 : (cols ? 2 : 0);
             rp.obase[rp.n] = cols ? (unsigned)ncols : (unsigned)(done * W);
-            if (wide) wide_rounds = done + k;
+            if (wide) c.wide_rounds = done + k;
             if (cols) {
-                col_stages.push_back({done, (size_t)k, ncols});
+                c.col_stages.push_back({done, (size_t)k, ncols});
                 ncols += nout;
             }
             rp.first[rp.n + 1] = rp.first[rp.n] + nout;
@@ -1069,72 +1100,208 @@ static int run_mode(zk_ctx* ctx, const void* d_f, const void* d_g, size_t len, c
         if (m > emax) return fail(ctx, ZK_ERR_INVALID, "internal: last stage too large");
         void* fo = (MODE == 2) ? d_out : d_last_f;
         void* qb = (MODE == 3) ? (char*)d_q + (len - m) * fr : nullptr;
-        int rc = launch_local<MODE>(ctx, cf, cg, 1u, (unsigned)m, 0, rl, h_chal + 4 * done, (void*)(d_res + done * W * fr), qb, fo, d_last_g,
-                                    (W != 0 && rp.n) ? &rp : nullptr, (void*)d_res, (void*)d_wide, !derive ? 2 : (done == 0 ? 1 : 0));
+        int rc = launch_local<MODE>(ctx, st_, cf, cg, 1u, (unsigned)m, 0, rl, h_chal + 4 * done, (void*)(d_res + done * W * fr), qb, fo, d_last_g,
+                                    (W != 0 && rp.n) ? &rp : nullptr, (void*)d_res, (void*)d_wide, !derive ? 2 : (done == 0 ? 1 : 0), c.want_ts);
         if (rc) return rc;
     } else if (rounds == 0) {
-        ZK_HIP(ctx, hipMemcpyAsync(d_out, d_f, len * fr, hipMemcpyDeviceToDevice, ctx->stream));
+        ZK_HIP(ctx, hipMemcpyAsync(d_out, c.d_f, len * fr, hipMemcpyDeviceToDevice, st_));
     }
-    if (MODE != 2) {
-        char* h = d_res;
-        if (!pinned_out) {
-            h = (char*)pinned(ctx, res_bytes);
-            if (!h) return ZK_ERR_OOM;
-            ZK_HIP(ctx, hipMemcpyAsync(h, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        hts(false);
-        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        hts(false);
-        sc_ts_print();
-        hts(false);
-        if (MODE == 1) {  // the one Montgomery reduction of every lazily reduced sum
-            const char* hw = h + res_elems * fr;
-            for (size_t rd = 0; rd < wide_rounds; rd++)
-                for (int ws = 0; ws < 3; ws++) {
-                    if (ws == 1 && rd != 0 && derive) continue;  // (derived below)
-                    const hfr::F v = hfr::from_wide((const uint32_t*)(hw + (rd * 3 + ws) * kWideBytes));
-                    std::memcpy(h + (rd * 3 + ws) * fr, &v, fr);
-                }
-        }
-        if (MODE == 0) {  // the rounds of a flat pass = the plain sumcheck of its 2^k column sums
-            const char* hw = h + res_elems * fr;
-            for (const ColStage& cs : col_stages) {
-                std::vector<hfr::F> c((size_t)1 << cs.k);
-                for (size_t S = 0; S < c.size(); S++) c[S] = hfr::from_cols((const uint32_t*)(hw + (cs.base + S) * kWideBytes));
-                for (size_t i = 0; i < cs.k; i++) {
-                    const size_t half = c.size() >> 1;
-                    hfr::F t0 = c[0], t1 = c[half], r;
-                    for (size_t S = 1; S < half; S++) t0 = hfr::add(t0, c[S]), t1 = hfr::add(t1, c[half + S]);
-                    std::memcpy(h + ((cs.done + i) * 2) * fr, &t0, fr);
-                    std::memcpy(h + ((cs.done + i) * 2 + 1) * fr, &t1, fr);
-                    std::memcpy(&r, h_chal + 4 * (cs.done + i), fr);
-                    for (size_t S = 0; S < half; S++) c[S] = hfr::add(c[S], hfr::mul(r, hfr::sub(c[half + S], c[S])));  // dsumcheck.rs:14-19
-                    c.resize(half);
-                }
+    return ZK_OK;
+}
+
+// host side of a finished call (MODE != 2): c.h_res holds the result block
+template <int MODE>
+static void sc_collect(ScCall& c) {
+    constexpr int W = ModeTraits<MODE>::W;
+    constexpr bool TWO = ModeTraits<MODE>::TWO;
+    const size_t fr = 32, rounds = c.rounds;
+    char* h = c.h_res;
+    if (MODE == 1) {  // the one Montgomery reduction of every lazily reduced sum
+        const char* hw = h + c.res_elems * fr;
+        for (size_t rd = 0; rd < c.wide_rounds; rd++)
+            for (int ws = 0; ws < 3; ws++) {
+                if (ws == 1 && rd != 0 && c.derive) continue;  // (derived below)
+                const hfr::F v = hfr::from_wide((const uint32_t*)(hw + (rd * 3 + ws) * kWideBytes));
+                std::memcpy(h + (rd * 3 + ws) * fr, &v, fr);
+            }
+    }
+    if (MODE == 0) {  // the rounds of a flat pass = the plain sumcheck of its 2^k column sums
+        const char* hw = h + c.res_elems * fr;
+        for (const ScColStage& cs : c.col_stages) {
+            std::vector<hfr::F> col((size_t)1 << cs.k);
+            for (size_t S = 0; S < col.size(); S++) col[S] = hfr::from_cols((const uint32_t*)(hw + (cs.base + S) * kWideBytes));
+            for (size_t i = 0; i < cs.k; i++) {
+                const size_t half = col.size() >> 1;
+                hfr::F t0 = col[0], t1 = col[half], r;
+                for (size_t S = 1; S < half; S++) t0 = hfr::add(t0, col[S]), t1 = hfr::add(t1, col[half + S]);
+                std::memcpy(h + ((cs.done + i) * 2) * fr, &t0, fr);
+                std::memcpy(h + ((cs.done + i) * 2 + 1) * fr, &t1, fr);
+                std::memcpy(&r, c.h_chal + 4 * (cs.done + i), fr);
+                for (size_t S = 0; S < half; S++) col[S] = hfr::add(col[S], hfr::mul(r, hfr::sub(col[half + S], col[S])));  // dsumcheck.rs:14-19
+                col.resize(half);
             }
         }
-        hts(false);
-        if (derive) derive_t1((uint64_t*)h, h_chal, rounds);
-        hts(true);
-        if (h_sums && rounds * W) std::memcpy(h_sums, h, rounds * W * fr);
-        if (h_last_f) std::memcpy(h_last_f, h + rounds * W * fr, fr);
-        if (TWO && h_last_g) std::memcpy(h_last_g, h + (rounds * W + 1) * fr, fr);
     }
+    if (c.derive) derive_t1((uint64_t*)h, c.h_chal, rounds);
+    if (c.h_sums && rounds * W) std::memcpy(c.h_sums, h, rounds * W * fr);
+    if (c.h_last_f) std::memcpy(c.h_last_f, h + rounds * W * fr, fr);
+    if (TWO && c.h_last_g) std::memcpy(c.h_last_g, h + (rounds * W + 1) * fr, fr);
+}
+
+#define ZK_SC_DISPATCH(fn, mode, ...)                  \
+    ((mode) == 0 ? fn<0>(__VA_ARGS__) : (mode) == 1 ? fn<1>(__VA_ARGS__) : (mode) == 2 ? fn<2>(__VA_ARGS__) : fn<3>(__VA_ARGS__))
+
+static int sc_validate(zk_ctx* ctx, const ScCall& c) {
+    if (c.mode < 0 || c.mode > 3) return fail(ctx, ZK_ERR_INVALID, "bad mode");
+    if (c.len == 0 || (c.len & (c.len - 1))) return fail(ctx, ZK_ERR_INVALID, "table length %zu is not a power of two", c.len);
+    if (c.rounds > (size_t)ilog2(c.len)) return fail(ctx, ZK_ERR_INVALID, "more rounds than variables");
     return ZK_OK;
 }
 
 int multilinear_run(zk_ctx* ctx, int mode, const void* d_f, const void* d_g, size_t len, const uint64_t* h_chal, size_t rounds,
                     uint64_t* h_sums, uint64_t* h_last_f, uint64_t* h_last_g, void* d_out, void* d_q) {
-    if (len == 0 || (len & (len - 1))) return fail(ctx, ZK_ERR_INVALID, "table length %zu is not a power of two", len);
-    if (rounds > (size_t)ilog2(len)) return fail(ctx, ZK_ERR_INVALID, "more rounds than variables");
+    ScCall c;
+    c.mode = mode, c.d_f = d_f, c.d_g = d_g, c.len = len, c.rounds = rounds, c.h_chal = h_chal;
+    c.h_sums = h_sums, c.h_last_f = h_last_f, c.h_last_g = h_last_g, c.d_out = d_out, c.d_q = d_q;
+    int rc = sc_validate(ctx, c);
+    if (rc) return rc;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    switch (mode) {
-        case 0: return run_mode<0>(ctx, d_f, d_g, len, h_chal, rounds, h_sums, h_last_f, h_last_g, d_out, d_q);
-        case 1: return run_mode<1>(ctx, d_f, d_g, len, h_chal, rounds, h_sums, h_last_f, h_last_g, d_out, d_q);
-        case 2: return run_mode<2>(ctx, d_f, d_g, len, h_chal, rounds, h_sums, h_last_f, h_last_g, d_out, d_q);
-        case 3: return run_mode<3>(ctx, d_f, d_g, len, h_chal, rounds, h_sums, h_last_f, h_last_g, d_out, d_q);
+    const bool host_ts = tuning().sc_ts == 2;  // host-side phases of a call on stderr
+    const auto hts0 = std::chrono::steady_clock::now();
+    double hts_us[6];
+    int hts_n = 0;
+    auto hts = [&](bool last) {
+        if (!host_ts) return;
+        hts_us[hts_n++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hts0).count();
+        if (last) fprintf(stderr, "[sc host] launched %.2f synced %.2f collected %.2f us\n", hts_us[0], hts_us[1], hts_us[2]);
+    };
+    rc = ZK_SC_DISPATCH(sc_plan, mode, ctx, c);
+    if (rc) return rc;
+    const bool pinned_out = tuning().sc_pinned_out != 0;
+    c.d_res = (mode != 2 && pinned_out) ? (char*)pinned(ctx, c.res_bytes) : (char*)scratch(ctx, 5, c.res_bytes);
+    if (!c.d_res) return ZK_ERR_OOM;
+    for (int i = 0; i < 4; i++)
+        if (c.buf_bytes[i]) {
+            c.bufs[i] = scratch(ctx, i, c.buf_bytes[i]);
+            if (!c.bufs[i]) return ZK_ERR_OOM;
+        }
+    if (c.part_bytes) {
+        c.d_part = (char*)scratch(ctx, 4, c.part_bytes);
+        if (!c.d_part) return ZK_ERR_OOM;
     }
-    return fail(ctx, ZK_ERR_INVALID, "bad mode");
+    c.st = ctx->stream;
+    c.want_ts = true;
+    rc = ZK_SC_DISPATCH(sc_enqueue, mode, ctx, c);
+    if (rc) return rc;
+    if (mode != 2) {
+        c.h_res = c.d_res;
+        if (!pinned_out) {
+            c.h_res = (char*)pinned(ctx, c.res_bytes);
+            if (!c.h_res) return ZK_ERR_OOM;
+            ZK_HIP(ctx, hipMemcpyAsync(c.h_res, c.d_res, c.res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        hts(false);
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hts(false);
+        sc_ts_print();
+        switch (mode) {
+            case 0: sc_collect<0>(c); break;
+            case 1: sc_collect<1>(c); break;
+            default: sc_collect<3>(c); break;
+        }
+        hts(true);
+    }
+    return ZK_OK;
+}
+
+// Several INDEPENDENT calls of the family in one go (the ~180 sumcheck / fold / open calls of a proof come in groups that do not
+// depend on each other: three per layer of the wiring identity, hyperplonk/src/dhyperplonk.rs:417-478; the six gate sumchecks
+// :223-260; the opens of :383-407).  Every item gets its own slice of the scratch arenas and of the pinned result block, the
+// items are spread over the ctx's auxiliary streams (a small item is a chain of 1-3 latency-bound launches: chains of different
+// items overlap), and the host waits ONCE.  Results are bit-identical to the one-call-at-a-time form (same kernels, same plan).
+int multilinear_batch(zk_ctx* ctx, const zk_sc_item* items, size_t count) {
+    if (count == 0) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<ScCall> calls(count);
+    for (size_t i = 0; i < count; i++) {
+        const zk_sc_item& it = items[i];
+        ScCall& c = calls[i];
+        if (it.mode < 0 || it.mode > 3) return fail(ctx, ZK_ERR_INVALID, "batch item %zu: bad mode", i);
+        if (it.len == 0 || (it.len & (it.len - 1))) return fail(ctx, ZK_ERR_INVALID, "batch item %zu: table length %zu is not a power of two", i, it.len);
+        const size_t n = (size_t)ilog2(it.len);
+        c.mode = it.mode, c.d_f = it.d_f, c.d_g = it.d_g, c.len = it.len, c.h_chal = it.h_chal;
+        c.rounds = it.mode == 2 ? std::min(n, it.n_points) : n;  // min(n, points_cnt), mle.rs:94
+        c.h_sums = it.h_sums, c.h_last_f = it.h_last_f, c.h_last_g = it.h_last_g;
+        c.d_out = it.mode == 2 ? it.d_out : nullptr;
+        c.d_q = it.mode == 3 ? it.d_out : nullptr;
+        const bool ok = it.d_f && (it.mode != 1 || it.d_g) && (c.rounds == 0 || it.h_chal) && (it.mode == 2 || it.h_last_f) && (it.mode != 1 || it.h_last_g) &&
+                        ((it.mode != 0 && it.mode != 1) || n == 0 || it.h_sums) && ((it.mode != 2 && !(it.mode == 3 && it.len > 1)) || it.d_out);
+        if (!ok) return fail(ctx, ZK_ERR_INVALID, "batch item %zu: null argument", i);
+    }
+    size_t need[5] = {0, 0, 0, 0, 0}, res_total = 0;
+    std::vector<size_t> off(count * 5), res_off(count);
+    for (size_t i = 0; i < count; i++) {
+        ScCall& c = calls[i];
+        int rc = sc_validate(ctx, c);
+        if (!rc) rc = ZK_SC_DISPATCH(sc_plan, c.mode, ctx, c);
+        if (rc) return rc;
+        for (int b = 0; b < 4; b++) {
+            off[i * 5 + b] = need[b];
+            need[b] += (c.buf_bytes[b] + 255) & ~(size_t)255;
+        }
+        off[i * 5 + 4] = need[4];
+        need[4] += (c.part_bytes + 255) & ~(size_t)255;
+        res_off[i] = res_total;
+        res_total += (c.res_bytes + 63) & ~(size_t)63;
+    }
+    char* base[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int b = 0; b < 5; b++)
+        if (need[b]) {
+            base[b] = (char*)scratch(ctx, b, need[b]);
+            if (!base[b]) return ZK_ERR_OOM;
+        }
+    char* hres = (char*)pinned(ctx, std::max<size_t>(res_total, 64));
+    if (!hres) return ZK_ERR_OOM;
+    zk_ctx::MsmLane& L = ctx->lanes[0];
+    const int nst = count > 1 ? zk_ctx::kAux : 0;  // streams besides the ctx stream
+    if (nst) {
+        hipEventRecord(L.ev_fork, ctx->stream);
+        for (int k = 0; k < nst; k++) hipStreamWaitEvent(L.aux[k], L.ev_fork, 0);
+    }
+    // largest items first, round-robin over the streams: the long chains start early, the short ones fill in beside them
+    std::vector<size_t> order(count);
+    for (size_t i = 0; i < count; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return calls[a].len > calls[b].len; });
+    int rc = ZK_OK;
+    for (size_t oi = 0; oi < count && !rc; oi++) {
+        const size_t i = order[oi];
+        ScCall& c = calls[i];
+        for (int b = 0; b < 4; b++) c.bufs[b] = c.buf_bytes[b] ? base[b] + off[i * 5 + b] : nullptr;
+        c.d_part = c.part_bytes ? base[4] + off[i * 5 + 4] : nullptr;
+        c.d_res = c.h_res = hres + res_off[i];
+        c.st = nst ? (oi % (size_t)(nst + 1) == 0 ? ctx->stream : L.aux[oi % (size_t)(nst + 1) - 1]) : ctx->stream;
+        c.want_ts = false;
+        rc = ZK_SC_DISPATCH(sc_enqueue, c.mode, ctx, c);
+    }
+    if (nst) {  // join (also on the error path: nothing may still be running on the auxiliary streams when we return)
+        for (int k = 0; k < nst; k++) {
+            hipEventRecord(L.ev_join[k], L.aux[k]);
+            hipStreamWaitEvent(ctx->stream, L.ev_join[k], 0);
+        }
+    }
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (rc) return rc;
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamSynchronize(batch)");
+    for (size_t i = 0; i < count; i++) {
+        ScCall& c = calls[i];
+        switch (c.mode) {
+            case 0: sc_collect<0>(c); break;
+            case 1: sc_collect<1>(c); break;
+            case 3: sc_collect<3>(c); break;
+            default: break;
+        }
+    }
+    return ZK_OK;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("zk_sumcheck_product", _i, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     ("zk_fold", _i, [_vp, _vp, _sz, _vp, _sz, _vp]),
     ("zk_open_rounds", _i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    ("zk_sumcheck_batch", _i, [_vp, _sz, _vp]),
     ("zk_product_tree", _i, [_vp, _vp, _sz, _vp]),
     ("zk_srs_register", _i, [_vp, _vp, _sz, _sz, _pp]),
     ("zk_srs_wrap_device", _i, [_vp, _vp, _sz, _pp]),
@@ -88,6 +89,13 @@ SYMBOLS = [
     ("zk_dbg_g1_op", _i, [_vp, _i, _vp, _vp, _vp, _sz]),
     ("zk_dbg_g2_op", _i, [_vp, _i, _vp, _vp, _vp, _sz]),
 ]
+
+class ScItem(ctypes.Structure):
+    """include/zkhip.h `zk_sc_item`"""
+
+    _fields_ = [("mode", _i), ("d_f", _vp), ("d_g", _vp), ("len", _sz), ("h_chal", _vp), ("n_points", _sz), ("h_sums", _vp), ("h_last_f", _vp),
+                ("h_last_g", _vp), ("d_out", _vp)]
+
 
 ZK_OK, ZK_ERR_INVALID, ZK_ERR_LENGTH, ZK_ERR_HIP, ZK_ERR_NO_DEVICE, ZK_ERR_DIV_ZERO, ZK_ERR_OOM, ZK_ERR_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 

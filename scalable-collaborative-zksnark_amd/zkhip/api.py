@@ -317,6 +317,58 @@ class Ctx:
         self._check(self.lib.zk_sumcheck_product(self.h, _ptr(f), _ptr(g), length, _h(chal), _h(out), _h(lf), _h(lg)))
         return out, lf, lg
 
+    def sumcheck_batch(self, reqs):
+        """
+        several INDEPENDENT calls of the family in one C-ABI call (zk_sumcheck_batch): one enqueue over several streams, one
+        completion.  reqs: list of
+            ("plain", tab, length, chal) | ("product", f, g, length, chal) | ("fold", tab, length, points[, out]) | ("open", tab, length, point[, q_out])
+        -> list of what the single calls return: (pairs, last) | (triples, last_f, last_g) | folded buffer | (q buffer, value).
+        """
+        from ._lib import ScItem
+
+        n = len(reqs)
+        if n == 0:
+            return []
+        items = (ScItem * n)()
+        keep, outs = [], []
+        for i, r in enumerate(reqs):
+            kind = r[0]
+            it = items[i]
+            if kind == "product":
+                _, f, g, length, chal = r
+                k = length.bit_length() - 1
+                ch = np.ascontiguousarray(chal, dtype=np.uint64).reshape(-1, 4)[:k]
+                tr, lf, lg = np.zeros((k, 3, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+                it.mode, it.d_f, it.d_g, it.len, it.h_chal, it.h_sums, it.h_last_f, it.h_last_g = 1, _ptr(f), _ptr(g), length, _h(ch), _h(tr), _h(lf), _h(lg)
+                outs.append((tr, lf, lg))
+            elif kind == "plain":
+                _, f, length, chal = r
+                k = length.bit_length() - 1
+                ch = np.ascontiguousarray(chal, dtype=np.uint64).reshape(-1, 4)[:k]
+                pr, last = np.zeros((k, 2, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+                it.mode, it.d_f, it.len, it.h_chal, it.h_sums, it.h_last_f = 0, _ptr(f), length, _h(ch), _h(pr), _h(last)
+                outs.append((pr, last))
+            elif kind == "fold":
+                _, f, length, points = r[:4]
+                k = length.bit_length() - 1
+                ch = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 4)
+                out = (r[4] if len(r) > 4 else None) or self.alloc(32 * (length >> min(k, len(ch))))
+                it.mode, it.d_f, it.len, it.h_chal, it.n_points, it.d_out = 2, _ptr(f), length, _h(ch), len(ch), _ptr(out)
+                outs.append(out)
+            elif kind == "open":
+                _, f, length, point = r[:4]
+                k = length.bit_length() - 1
+                ch = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)[:k]
+                q = (r[4] if len(r) > 4 else None) or self.alloc(max(32 * (length - 1), 1))
+                val = np.zeros(4, dtype=np.uint64)
+                it.mode, it.d_f, it.len, it.h_chal, it.h_last_f, it.d_out = 3, _ptr(f), length, _h(ch), _h(val), _ptr(q)
+                outs.append((q, val))
+            else:
+                raise ValueError(kind)
+            keep.append(ch)
+        self._check(self.lib.zk_sumcheck_batch(self.h, n, items))
+        return outs
+
     def fold(self, tab, length: int, points: np.ndarray, out=None):
         points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 4)
         n = length.bit_length() - 1

@@ -153,6 +153,23 @@ def _trace(be, kind: str, f, g, length: int, challenge):
         t.append((kind, f, g, length, np.array(challenge, copy=True)))
 
 
+def _sc_batch(be, reqs):
+    """several independent sumcheck-family calls: ONE C-ABI call (zk_sumcheck_batch) where the backend has it"""
+    if hasattr(be, "sumcheck_batch") and len(reqs) > 1:
+        return be.sumcheck_batch(reqs)
+    out = []
+    for r in reqs:
+        if r[0] == "product":
+            out.append(be.sumcheck_product(r[1], r[2], r[3], r[4]))
+        elif r[0] == "plain":
+            out.append(be.sumcheck(r[1], r[2], r[3]))
+        elif r[0] == "fold":
+            out.append(be.fold(r[1], r[2], r[3]))
+        else:
+            out.append(be.open_rounds(r[1], r[2], r[3]))
+    return out
+
+
 def sumcheck(be, evaluation, length: int, challenge: np.ndarray) -> np.ndarray:
     """dsumcheck.rs:6-26 -> [n+1, 2, 4]; last entry (0, last)"""
     n = length.bit_length() - 1
@@ -199,6 +216,29 @@ def c_sumcheck_product(be, shares_f, shares_g, length: int, challenge: np.ndarra
     return np.concatenate([tr, _ints_to_fr([x for t in extra for x in t]).reshape(-1, 3, 4)])
 
 
+def c_sumcheck_product_many(be, pairs: Sequence, length: int, challenge: np.ndarray, pp: PackedSharingParams, net: Net) -> List[np.ndarray]:
+    """
+    several independent c_sumcheck_product (dsumcheck.rs:148-285) on tables of one length: their phase-1 loops run as ONE
+    batched call, the pss2ss hand-offs (:224-225) and phase 2 follow item by item in the reference's order.
+    """
+    n = length.bit_length() - 1
+    for f, g in pairs:
+        _trace(be, "c", f, g, length, challenge[:n])
+    phase1 = _sc_batch(be, [("product", f, g, length, challenge[:n]) for f, g in pairs])
+    ch = _fr_vec_to_ints(challenge)
+    out = []
+    for tr, lf, lg in phase1:
+        vf = _fr_vec_to_ints(pss2ss(lf, pp, net))  # :224
+        vg = _fr_vec_to_ints(pss2ss(lg, pp, net))  # :225
+        extra = []
+        for i in range(pp.l.bit_length() - 1):
+            t, vf, vg = _round_product(vf, vg, ch[i])
+            extra.append(t)
+        extra.append((0, vf[0] * vg[0] % R_MOD, 0))  # :282
+        out.append(np.concatenate([tr, _ints_to_fr([x for t in extra for x in t]).reshape(-1, 3, 4)]))
+    return out
+
+
 def d_sumcheck(be, partial_poly, length: int, challenge: np.ndarray, net: Net) -> np.ndarray:
     """dsumcheck.rs:287-357.  Leader: [n'+s, 2, 4]; workers: empty"""
     n = length.bit_length() - 1
@@ -237,6 +277,39 @@ def d_sumcheck_product(be, partial_f, partial_g, length: int, challenge: np.ndar
         t, f, g = _round_product(f, g, ch[i])
         res.append(t)
     return np.concatenate([head.reshape(-1, 3, 4), _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)])
+
+
+def d_sumcheck_product_many(be, items: Sequence, net: Net) -> List[np.ndarray]:
+    """
+    several independent d_sumcheck_product (dsumcheck.rs:359-512); items = [(partial_f, partial_g, length, challenge)].
+    The local phases run as ONE batched call; the per-item gathers of the round tuples (:437) travel as ONE all-gather of
+    the concatenated payloads (same bytes, one exchange instead of len(items)); the leader part is unchanged per item.
+    """
+    if not len(items):
+        return []
+    s = net.n_parties.bit_length() - 1
+    ns = [length.bit_length() - 1 for _, _, length, _ in items]
+    for (f, g, length, ch), n in zip(items, ns):
+        _trace(be, "d", f, g, length, ch[: n + s])
+    phase1 = _sc_batch(be, [("product", f, g, length, ch[:n]) for (f, g, length, ch), n in zip(items, ns)])
+    locals_ = [np.concatenate([tr, np.stack([lg, lf, ZERO])[None]]) for tr, lf, lg in phase1]  # marker (g, f, 0)  :433
+    cuts = np.cumsum([0] + [len(x) for x in locals_])
+    allp = net.all_gather(np.concatenate(locals_))  # [party][sum(n_i + 1), 3, 4]
+    if not net.is_leader:
+        return [np.zeros((0, 3, 4), dtype=np.uint64) for _ in items]
+    out = []
+    for k, ((_, _, _, challenge), n) in enumerate(zip(items, ns)):
+        mine = [np.asarray(allp[p])[cuts[k] : cuts[k + 1]] for p in range(net.n_parties)]
+        head = fr_sum_mont([m[:n] for m in mine])  # per-round sums (:440-447)
+        f = [fr_from_mont(m[n][1]) for m in mine]  # :448
+        g = [fr_from_mont(m[n][0]) for m in mine]  # :449
+        ch = _fr_vec_to_ints(challenge[n : n + s])
+        res = []
+        for i in range(s):
+            t, f, g = _round_product(f, g, ch[i])
+            res.append(t)
+        out.append(np.concatenate([head.reshape(-1, 3, 4), _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)]))
+    return out
 
 
 # ---------------------------------------------------------------------------------------
@@ -321,10 +394,9 @@ def commit(be, powers_of_g, peval, length: int) -> np.ndarray:
     return be.msm_g1(powers_of_g[level], peval, length)
 
 
-def _open_items(be, powers_of_g, peval, length: int, point: np.ndarray):
-    """the fold rounds of one open (:309-323): returns (value [4], q buffer, srs list, scalar views, lens)"""
+def _open_msm_items(powers_of_g, q, length: int):
+    """the n commitments of one open (:318-321) as MSM items over the quotient buffer q: (srs list, scalar views, lens)"""
     n = length.bit_length() - 1
-    q, value = be.open_rounds(peval, length, point[:n])
     srs, bufs, lens, off, m = [], [], [], 0, length
     for _ in range(n):
         h = m // 2
@@ -333,14 +405,16 @@ def _open_items(be, powers_of_g, peval, length: int, point: np.ndarray):
         lens.append(h)
         off += h
         m = h
-    return value, q, srs, bufs, lens
+    return srs, bufs, lens
 
 
 def open_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray]):
     """several independent opens: the fold rounds run now, the commitments of all q_i are queued; -> closure"""
     vals, cuts = [], []
-    for pe, length, pt in zip(pevals, lens, points):
-        v, qb, s_, b_, l_ = _open_items(be, powers_of_g, pe, length, np.asarray(pt, dtype=np.uint64).reshape(-1, 4))
+    pts = [np.asarray(pt, dtype=np.uint64).reshape(-1, 4) for pt in points]
+    rounds = _sc_batch(be, [("open", pe, length, pt[: length.bit_length() - 1]) for pe, length, pt in zip(pevals, lens, pts)])  # :309-323, all items at once
+    for (qb, v), length in zip(rounds, lens):
+        s_, b_, l_ = _open_msm_items(powers_of_g, qb, length)
         vals.append(v)
         cuts.append(q.add(s_, b_, l_, keep=[qb]))  # the q buffers must outlive the batched MSM
     def fin():
@@ -484,9 +558,9 @@ def c_open_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence
     k = len(lens)
     pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
     vals, bufs, ms, cuts = [], [], [], [0]
-    for pe, length, pt in zip(pevals, lens, pts):
+    rounds = _sc_batch(be, [("open", pe, length, pt[: length.bit_length() - 1]) for pe, length, pt in zip(pevals, lens, pts)])  # :418-432
+    for (qb, value), length in zip(rounds, lens):
         n = length.bit_length() - 1
-        qb, value = be.open_rounds(pe, length, pt[:n])
         q.keep.append(qb)
         vals.append(value)
         off, m = 0, length

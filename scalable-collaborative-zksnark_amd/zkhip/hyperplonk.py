@@ -154,19 +154,15 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
     tabs8 = [T["ssigma_p"], T["sid_p"], h_p, num, den, v1x, vx0, vx1]
     f_dcommit = dp.d_commit_many_q(be, q, dc, [local_s_p] + tabs8, [4 * M // npar] + [hlen] * 8, net)  # 2.b, then :363-380
     lay_tabs, lay_lens, lay_pts = [local_s_p] + tabs8[:5], [4 * M // npar] + [hlen] * 5, [pk.challenge_r2] * 6  # 2.d, then :383-407
-    dsp = lambda f, g, length, ch: dp.d_sumcheck_product(be, f, g, length, ch, net)
-    wiring_proofs.append(dsp(den, T["eq_r2_p"], hlen, pk.challenge_r2))  # 2.e.1 :411-413
-    wiring_proofs.append(dsp(h_p, den, hlen, pk.challenge_r2))
-    wiring_proofs.append(dsp(num, T["eq_r2_p"], hlen, pk.challenge_r2))
+    # the 3 + 3 (n - s) d_sumcheck_products of 2.e are independent of each other: one batched local phase, one exchange
+    dsp_items = [(den, T["eq_r2_p"], hlen, pk.challenge_r2), (h_p, den, hlen, pk.challenge_r2), (num, T["eq_r2_p"], hlen, pk.challenge_r2)]  # 2.e.1 :411-413
     # 2.e.2 layered sumcheck + opens on halving slices (:417-478)
     sbits = npar.bit_length() - 1
     cur = {"v1x": v1x, "vx0": vx0, "vx1": vx1, "eq": T["eq_r2_p"]}
     clen = hlen // 2  # current_* = first half
     for i in range(1, n - sbits + 1):
         ch = pk.challenge_r2[i:]
-        wiring_proofs.append(dsp(cur["eq"], cur["v1x"], clen, ch))
-        wiring_proofs.append(dsp(cur["eq"], cur["vx0"], clen, ch))
-        wiring_proofs.append(dsp(cur["vx0"], cur["vx1"], clen, ch))
+        dsp_items += [(cur["eq"], cur["v1x"], clen, ch), (cur["eq"], cur["vx0"], clen, ch), (cur["vx0"], cur["vx1"], clen, ch)]
         for k in ("v1x", "vx0", "vx1"):
             lay_tabs.append(cur[k])
             lay_lens.append(clen)
@@ -174,6 +170,7 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
         for k in cur:  # current = current[len/2..]
             cur[k] = _at(cur[k], 32 * (clen // 2))
         clen //= 2
+    wiring_proofs += dp.d_sumcheck_product_many(be, dsp_items, net)
     # the opens of local_s, of the five tables and of all layers are independent of each other
     f_dopen = dp.d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net)
     f_top_commits, f_top_opens, top_proofs = [], None, []
@@ -236,17 +233,12 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
 
     # Step 3: gate identity (:223-260)
     tm.start("Gate identity")
-    gate_proofs = []
-    csp = lambda f, g, length: dp.c_sumcheck_product(be, f, g, length, pk.challenge, pp, net)
     Ml = M // l
-    gate_proofs.append(csp(T["eq"], T["S1"], Ml))
     sum_ab = be.fr_add(T["a_evals"], T["b_evals"], Ml)  # :233-238
-    gate_proofs.append(csp(T["S1"], sum_ab, Ml))
-    gate_proofs.append(csp(T["eq"], T["S2"], Ml))
-    gate_proofs.append(csp(T["a_evals"], T["b_evals"], Ml))
-    gate_proofs.append(csp(T["S2"], T["a_evals"], Ml))
     sum_ci = be.fr_sub(T["I"], T["c_evals"], Ml)  # -c + I  :251-256
-    gate_proofs.append(csp(T["eq"], sum_ci, Ml))
+    # the six sumchecks are independent: one batched phase 1, then the hand-offs in the reference's order
+    gate_proofs = dp.c_sumcheck_product_many(be, [(T["eq"], T["S1"]), (T["S1"], sum_ab), (T["eq"], T["S2"]), (T["a_evals"], T["b_evals"]),
+                                                  (T["S2"], T["a_evals"]), (T["eq"], sum_ci)], Ml, pk.challenge, pp, net)
     tm.end()
 
     # Step 2: wiring identity (shared with dpermcheck)

@@ -72,3 +72,72 @@ def test_product_tree_reference_kat(ctx, co):
     tree = ctx.product_tree(ctx.to_device(x), 4).download((8, 4))
     vals = [po.fr_from_mont_limbs(t) for t in tree]
     assert vals[0::2] == [1, 3, 2, 24] and vals[1::2] == [2, 4, 12, 0] and vals[4:] == [2, 12, 24, 0]
+
+
+def test_batched_calls_match_single_calls(ctx, co):
+    """zk_sumcheck_batch: a mixed batch (all four modes, sizes 2^0 .. 2^20 across every stage boundary, partial folds,
+    repeated tables) gives the same bits as one call at a time, and as the oracle on the sampled items"""
+    rng = np.random.default_rng(5)
+    reqs, tabs = [], {}
+
+    def tab(lg, seed):
+        if (lg, seed) not in tabs:
+            a = rand_fr(1 << lg, 7000 + 37 * lg + seed)
+            tabs[(lg, seed)] = (a, ctx.to_device(a))
+        return tabs[(lg, seed)]
+
+    sizes = [0, 1, 2, 5, 8, 9, 10, 11, 13, 16, 17, 18, 19, 20, 18, 17, 9, 3]
+    for i, lg in enumerate(sizes):
+        ch = rand_fr(max(lg, 1) + 2, 8000 + i)
+        kind = ("product", "plain", "fold", "open")[i % 4]
+        if kind == "product":
+            reqs.append(("product", tab(lg, 0)[1], tab(lg, 1)[1], 1 << lg, ch))
+        elif kind == "plain":
+            reqs.append(("plain", tab(lg, 0)[1], 1 << lg, ch))
+        elif kind == "fold":
+            reqs.append(("fold", tab(lg, 1)[1], 1 << lg, ch[: int(rng.integers(0, lg + 3))]))
+        else:
+            reqs.append(("open", tab(lg, 0)[1], 1 << lg, ch))
+    # the layered shape of the wiring identity: three products per halving slice of the same tables
+    base_f, base_g = tab(18, 0)[1], tab(18, 1)[1]
+    off, clen = 0, 1 << 17
+    while clen >= 1:
+        ch = rand_fr(20, 9000 + clen.bit_length())
+        reqs += [("product", base_f.at(32 * off), base_g.at(32 * off), clen, ch)] * 2
+        off += clen // 2 if clen > 1 else 0
+        clen //= 2
+    got = ctx.sumcheck_batch(reqs)
+    assert len(got) == len(reqs)
+    for r, g in zip(reqs, got):
+        if r[0] == "product":
+            want = ctx.sumcheck_product(r[1], r[2], r[3], r[4])
+            assert all((a == b).all() for a, b in zip(g, want))
+        elif r[0] == "plain":
+            want = ctx.sumcheck(r[1], r[2], r[3])
+            assert all((a == b).all() for a, b in zip(g, want))
+        elif r[0] == "fold":
+            rounds = min(r[2].bit_length() - 1, len(r[3]))
+            want = ctx.fold(r[1], r[2], r[3])
+            assert (g.download((r[2] >> rounds, 4)) == want.download((r[2] >> rounds, 4))).all()
+        else:
+            qw, vw = ctx.open_rounds(r[1], r[2], r[3])
+            assert (g[1] == vw).all()
+            if r[2] > 1:
+                assert (g[0].download((r[2] - 1, 4)) == qw.download((r[2] - 1, 4))).all()
+    # oracle on two of them
+    f20, g20 = tab(20, 0)[0], tab(20, 1)[0]
+    i20 = sizes.index(20)
+    assert reqs[i20][0] == "plain"
+    exp = co.sumcheck(f20, reqs[i20][3][:20])
+    assert (got[i20][0] == exp[:20]).all() and (got[i20][1] == exp[20, 1]).all()
+    i16 = sizes.index(16)
+    assert reqs[i16][0] == "product"
+    etr, elf, elg = co.sumcheck_product_rounds(tab(16, 0)[0], tab(16, 1)[0], reqs[i16][4][:16])
+    assert (got[i16][0] == etr).all() and (got[i16][1] == elf).all() and (got[i16][2] == elg).all()
+    # errors name the item and leave the ctx usable
+    import zkhip
+
+    with pytest.raises(zkhip.ZkError):
+        ctx.sumcheck_batch([("plain", tab(5, 0)[1], 32, rand_fr(5, 1)), ("plain", tab(5, 0)[1], 33, rand_fr(5, 1))])
+    again = ctx.sumcheck_batch(reqs[:4])
+    assert all((a == b).all() for a, b in zip(again[0], got[0]))
