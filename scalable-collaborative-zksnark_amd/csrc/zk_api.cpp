@@ -22,7 +22,7 @@ static const TuneKey kTuneKeys[] = {
     {"sc_pinned_out", &Tuning::sc_pinned_out}, {"sc_t1_device", &Tuning::sc_t1_device}, {"sc_flag_sync", &Tuning::sc_flag_sync},
     {"msm_table_dc", &Tuning::msm_table_dc}, {"msm_qstep", &Tuning::msm_qstep}, {"msm_tile", &Tuning::msm_tile}, {"msm_pair", &Tuning::msm_pair},
     {"msm_fixq", &Tuning::msm_fixq}, {"msm_quad", &Tuning::msm_quad}, {"msm_stage", &Tuning::msm_stage}, {"msm_split", &Tuning::msm_split},
-    {"msm_np", &Tuning::msm_np}, {"msm_debug", &Tuning::msm_debug}, {"msm_serial", &Tuning::msm_serial},
+    {"msm_np", &Tuning::msm_np}, {"msm_debug", &Tuning::msm_debug}, {"msm_serial", &Tuning::msm_serial}, {"msm_size_classes", &Tuning::msm_size_classes},
 };
 static Tuning g_tuning;
 int tune_set(const char* key, long value) {

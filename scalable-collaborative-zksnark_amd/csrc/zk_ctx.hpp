@@ -100,6 +100,7 @@ struct Tuning {
     long msm_np = 0;          // sort partitions per row (0: auto)
     long msm_debug = 0;       // class geometry on stderr
     long msm_serial = 0;      // all classes on the ctx stream
+    long msm_size_classes = 1;  // window-table items: one class per power-of-two length
 };
 Tuning& tuning();
 int tune_set(const char* key, long value);  // 0, or ZK_ERR_INVALID for an unknown key

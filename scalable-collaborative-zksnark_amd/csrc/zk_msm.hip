@@ -1030,6 +1030,7 @@ struct MsmClass {
     int copies = 2;
     int c = 0;            // bits of the widest window: 2^(c-1) buckets per row, c reduced points per row
     int key_c = 0;        // the window bits asked for (class key)
+    int size_key = 0;     // window-table classes: log2 of the item length (class key)
     int narrow_from = 0x7fffffff;  // windows with index >= this are one bit narrower
     int w0 = 0, wc = 0;   // the windows [w0, w0 + wc) of the layout this class works on
     int part = 0, nparts = 1;  // a big class is cut by windows into parts that run staggered (see below)
@@ -1146,13 +1147,20 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         int c = ctx->msm_window_override > 0 ? ctx->msm_window_override : msm_pick_window(it.n);
         if (count > 1 && ctx->msm_window_override <= 0) c = quantised_window(c);
         if (shared) c = it.srs->table_c;
+        // window-table items of one table width can differ 8x in length (17-bit tables serve 2^15 .. 2^18 points): rows are as
+        // long as the class's longest item, so such items get a class per power of two (padding < 2x; the digits / sort
+        // passes walk the padded rows)
+        int lgn = 0;
+        while (((size_t)1 << lgn) < it.n) lgn++;
+        const int size_key = (shared && tn.msm_size_classes) ? lgn : 0;
         MsmClass* cl = nullptr;
         for (auto& x : classes)
-            if (x.key_c == c && x.shared == shared) cl = &x;
+            if (x.key_c == c && x.shared == shared && x.size_key == size_key) cl = &x;
         if (!cl) {
             classes.emplace_back();
             cl = &classes.back();
             cl->key_c = c;
+            cl->size_key = size_key;
             cl->shared = shared;
             cl->L = msm_layout(c, (shared || !Cv::kEndo) ? kFullBits : kEndoBits);
             // the balanced layout may end up narrower than asked: buckets and planes follow the WIDEST window;
