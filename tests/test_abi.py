@@ -81,6 +81,11 @@ def test_rust_sys_is_in_sync():
     declared = _header_symbols()
     for name in declared:
         assert f"pub fn {name}(" in committed, name
-    patched = open(os.path.join(ROOT, "rust", "dmsm_patched.rs")).read()
-    for used in re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", patched):
-        assert used in declared, f"rust/dmsm_patched.rs calls {used}, which the header does not declare"
+    for name in ("zkhip_party.rs", "dmsm_patched.rs", "dsumcheck_patched.rs", "dpoly_comm_patched.rs", "dacc_product_patched.rs"):
+        patched = open(os.path.join(ROOT, "rust", name)).read()
+        for used in re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", patched):
+            assert used in declared, f"rust/{name} calls {used}, which the header does not declare"
+    # the patched d_msm keeps the reference's signature (dist-primitive/src/dmsm.rs:9-15)
+    dmsm = " ".join(open(os.path.join(ROOT, "rust", "dmsm_patched.rs")).read().split())
+    assert ("pub async fn d_msm<G: CurveGroup, Net: MPCSerializeNet>( bases: &Vec<Vec<G::Affine>>, scalars: &Vec<Vec<G::ScalarField>>, "
+            "pp: &PackedSharingParams<G::ScalarField>, net: &Net, sid: MultiplexedStreamID, ) -> Result<Vec<G>, MPCNetError>") in dmsm
