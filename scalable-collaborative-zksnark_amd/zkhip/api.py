@@ -240,6 +240,18 @@ class Ctx:
     def copy_d2d(self, dst, src, nbytes: int):
         self._check(self.lib.zk_memcpy_d2d(self.h, _ptr(dst), _ptr(src), nbytes))
 
+    def download_ptr(self, src, nbytes: int) -> np.ndarray:
+        """nbytes from a device buffer / raw device address -> uint8 array"""
+        out = np.empty(nbytes, dtype=np.uint8)
+        if nbytes:
+            self._check(self.lib.zk_memcpy_d2h(self.h, _h(out), _ptr(src), nbytes))
+        return out
+
+    def upload_ptr(self, dst, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        if a.nbytes:
+            self._check(self.lib.zk_memcpy_h2d(self.h, _ptr(dst), _h(a), a.nbytes))
+
     def to_device(self, a: np.ndarray) -> DeviceBuffer:
         a = np.ascontiguousarray(a)
         return DeviceBuffer(self, max(a.nbytes, 1)).upload(a) if a.nbytes else DeviceBuffer(self, 1)

@@ -15,7 +15,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 from .field import R_MOD, fr_from_mont, fr_mont, fr_sum_mont, int_to_limbs
-from .net import Net
+from .net import Net, _at
 from .pss import PackedSharingParams
 
 ZERO = np.zeros(4, dtype=np.uint64)
@@ -787,50 +787,88 @@ def merge(results: Sequence[np.ndarray]) -> np.ndarray:
 
 def _pack_chunks(be, vals: np.ndarray, pp: PackedSharingParams) -> List[np.ndarray]:
     """
-    `vals.chunks(l).map(pack_from_public)` transposed: out[p] = party p's share of every chunk.
-    One application of the n x l public pack matrix to all chunks on the GPU (any l; a short last
-    chunk is zero-padded exactly as pack_from_public pads).
+    `vals.chunks(l).map(pack_from_public)` transposed: out[p] = party p's share of every chunk (host arrays; the small
+    leader-tree payloads).  A short last chunk is zero-padded exactly as pack_from_public pads.
     """
     vals = np.asarray(vals, dtype=np.uint64).reshape(-1, 4)
     if len(vals) == 0:
         return [np.zeros((0, 4), dtype=np.uint64) for _ in range(pp.n)]
-    l = pp.l
-    k = (len(vals) + l - 1) // l
-    if len(vals) != k * l:
-        vals = np.concatenate([vals, np.zeros((k * l - len(vals), 4), dtype=np.uint64)])
-    if pp.n >= NTT_FROM_N and hasattr(be, "fr_ntt_map"):
-        out = be.fr_ntt_map(pp.ntt_tables("pack"), be.to_device(vals), l, 1, k, 1, k).download((pp.n * k, 4))  # out[p*k + j]
-    else:
-        m = _mont_matrix([row[:l] for row in pp.pack_matrix])  # [n, l]
-        out = be.fr_apply_matrix(m, be.to_device(vals), l, 1, k, 1, k).download((pp.n * k, 4))  # out[p*k + j]
+    k = (len(vals) + pp.l - 1) // pp.l
+    out = _pack_chunks_device(be, be.to_device(vals), len(vals), pp).download((pp.n * k, 4))  # out[p*k + j]
     return [np.ascontiguousarray(out[p * k : (p + 1) * k]) for p in range(pp.n)]
+
+
+def _pack_chunks_device(be, d_vals, count: int, pp: PackedSharingParams):
+    """
+    the same on a device buffer of `count` Fr -> device buffer [n][k] (party-major: the send buffer of an all-to-all),
+    k = ceil(count / l).  One application of the n x l public pack matrix (or its transform form) to all chunks.
+    """
+    l = pp.l
+    k = (count + l - 1) // l
+    if count != k * l:  # zero-extend the last chunk
+        padded = be.alloc(32 * k * l)
+        be.copy_d2d(padded, d_vals, 32 * count)
+        be.upload_ptr(_at(padded, 32 * count), np.zeros((k * l - count, 4), dtype=np.uint64))
+        d_vals = padded
+    if pp.n >= NTT_FROM_N and hasattr(be, "fr_ntt_map"):
+        return be.fr_ntt_map(pp.ntt_tables("pack"), d_vals, l, 1, k, 1, k)
+    return be.fr_apply_matrix(_mont_matrix([row[:l] for row in pp.pack_matrix]), d_vals, l, 1, k, 1, k)
+
+
+def _merge_device(be, d_in, k: int, nparties: int):
+    """`merge` (dacc_product.rs:416-428) on a device buffer [n][k] (what every party sent me): level by level, the parties'
+    pieces side by side.  A handful of device-to-device copies per level -> (buffer, merged length)"""
+    num = 1
+    while num < k + 1:
+        num <<= 1
+    num >>= 1
+    out = be.alloc(32 * max(k * nparties, 1))
+    start, pos = 0, 0
+    while num > 0 and start + num <= k:
+        for q in range(nparties):
+            be.copy_d2d(_at(out, 32 * pos), _at(d_in, 32 * (q * k + start)), 32 * num)
+            pos += num
+        start += num
+        num >>= 1
+    return out, pos
 
 
 def c_acc_product_and_share(be, shares, masks, unmask0, unmask1, unmask2, S: int, pp: PackedSharingParams, net: Net):
     """
-    dacc_product.rs:66-292 -> (share0, share1, share2) as [S,4] host arrays (un-reduced, exactly as
-    the reference returns them: its three trailing degree_reduce_many calls discard their results).
-    GPU: mask / unmask multiplications, the product tree, the l = 1 packing; exchanges: one
-    all-to-all of masked blocks, one all-to-all per share vector, the leader-tree scatter.
+    dacc_product.rs:66-292 -> three (device buffer, length) pairs: the shares of v(x,0), v(x,1), v(1,x), un-reduced exactly
+    as the reference returns them (its three trailing degree_reduce_many calls discard their results).
+    DEVICE-RESIDENT: mask -> all-to-all of the masked blocks -> unpack2 of every column -> product tree -> strided views ->
+    pack_from_public of every l-chunk -> all-to-all of the share vectors -> merge -> unmask, with no table leaving HBM
+    (over RcclNet the two all-to-alls are zk_alltoall on HBM buffers; the thread / gloo / echo nets of the tests stage the
+    exchange itself through the host, the compute chain is the same).  Only the N_p-sized tails of the trees (the
+    leader's top tree, :213-263) travel as host arrays.
     """
     N = pp.n
     assert S > N  # :82
     bs = S // N
-    masked = be.fr_mul(shares, masks, S).download((S, 4))  # :88-92
-    # every party receives everyone's i-th block and unpack2s it element-wise (:94-104)
-    recv = net.all_to_all([np.ascontiguousarray(masked[i * bs : (i + 1) * bs]) for i in range(N)], echo="slot0")
-    mx = _unpack2_many_device(be, recv, pp)
-    mlen = len(mx)
-    subtree, leader_tree = c_acc_product(be, be.to_device(mx), mlen, pp, net)
-    st = subtree.download((2 * mlen, 4))
+    fr = 32
+    masked = be.fr_mul(shares, masks, S)  # :88-92
+    # every party receives everyone's i-th block (:94-104) ...
+    recv = net.all_to_all_device(masked, bs * fr, be=be, echo="slot0")  # [N][bs], party-major
+    # ... and unpack2s it element-wise: transpose(.).flat_map(unpack2) -> mx[j * l + r]   (unpack.rs:55-70)
+    if pp.n >= NTT_FROM_N and hasattr(be, "fr_ntt_map"):
+        mx = be.fr_ntt_map(pp.ntt_tables("unpack2"), recv, 1, bs, bs, pp.l, 1)
+    else:
+        mx = be.fr_apply_matrix(_mont_matrix(pp.unpack2_matrix), recv, 1, bs, bs, pp.l, 1)
+    mlen = bs * pp.l
+    subtree, leader_tree = c_acc_product(be, mx, mlen, pp, net)
     num_to_send = min(N, 2 * mlen)
-    to_share = st[: 2 * mlen - num_to_send]
+    # to_share = subtree[.. 2 mlen - num_to_send]; its three views (:118-150) as device buffers
+    half = (2 * mlen - num_to_send) // 2
+    vx0, vx1 = be.fr_deinterleave(subtree, half)  # to_share[0::2], to_share[1::2]
+    views = ((vx0, half), (vx1, half), (_at(subtree, fr * mlen), mlen - num_to_send))  # v(x,0), v(x,1), v(1,x) = to_share[mlen..]
     outs = []
-    for sel in (to_share[0::2], to_share[1::2], to_share[mlen:]):  # v(x,0), v(x,1), v(1,x)  (:118-150)
-        mine = _pack_chunks(be, np.ascontiguousarray(sel), pp)
-        got = net.all_to_all(mine, echo="identity")  # (:155-203)
-        outs.append(merge(got))
-    # leader-tree shares (:213-263): note the v(1,x) share packs the WHOLE leader tree (:243-250)
+    for d_sel, cnt in views:
+        k = (cnt + pp.l - 1) // pp.l
+        mine = _pack_chunks_device(be, d_sel, cnt, pp)  # [N][k]: party q's share of every chunk
+        got = net.all_to_all_device(mine, k * fr, be=be, echo="identity")  # (:155-203)
+        outs.append(_merge_device(be, got, k, N))
+    # leader-tree shares (:213-263): note the v(1,x) share packs the WHOLE leader tree (:243-250).  N_p-sized: host arrays
     if net.is_leader:
         lt = np.asarray(leader_tree, dtype=np.uint64).reshape(-1, 4)
         rows = [_pack_chunks(be, np.ascontiguousarray(v), pp) for v in (lt[0::2], lt[1::2], lt)]
@@ -844,10 +882,23 @@ def c_acc_product_and_share(be, shares, masks, unmask0, unmask1, unmask2, S: int
     mine = net.all_to_all(payload, echo="identity")[0]  # what the leader (party 0) sent to me
     lead = (mine[:k0], mine[k0 : k0 + k1], mine[k0 + k1 :])
     res = []
-    for sh, le, um in zip(outs, lead, (unmask0, unmask1, unmask2)):
-        full = np.concatenate([sh, le])
-        k = len(full)
-        res.append(be.fr_mul(be.to_device(full), um, k).download((k, 4)))  # unmask (:266-275)
-    for r in res:  # :278-285 -- communication only; the results are dropped by the reference too
-        degree_reduce_many(r[: len(r) // N * 2], pp, net, be)
+    for (sh, shlen), le, um in zip(outs, lead, (unmask0, unmask1, unmask2)):
+        k = shlen + len(le)
+        full = be.alloc(fr * max(k, 1))
+        be.copy_d2d(full, sh, fr * shlen)
+        be.upload_ptr(_at(full, fr * shlen), np.ascontiguousarray(le))
+        res.append((be.fr_mul(full, um, k), k))  # unmask (:266-275)
+    for buf, k in res:  # :278-285 -- communication only; the results are dropped by the reference too
+        degree_reduce_many_device(be, buf, k // N * 2, pp, net)
     return tuple(res)
+
+
+def degree_reduce_many_device(be, d_shares, k: int, pp: PackedSharingParams, net: Net):
+    """degree_reduce_many (degree_reduce.rs:10-26) on a device vector of k shares: HBM all-gather + this party's row of
+    the public map pack o unpack2 -> device buffer of k Fr"""
+    if k == 0:
+        return be.alloc(32)
+    allp = net.all_gather_device(d_shares, 32 * k, be=be)  # [n][k]
+    p = net.party_id
+    row = [sum(pp.pack_matrix[p][j] * pp.unpack2_matrix[j][i] for j in range(pp.l)) % R_MOD for i in range(pp.n)]
+    return be.fr_apply_matrix(_mont_matrix([row]), allp, 1, k, k, 1, k)

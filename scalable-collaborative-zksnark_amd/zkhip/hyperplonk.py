@@ -304,8 +304,8 @@ def cpermcheck(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be,
         commits.append(ccommit(T[name]))
         opens.append(copen(T[name]))
     for ev in (num, den):
-        vx0, vx1, v1x = dp.c_acc_product_and_share(be, ev, T["mask"], T["unmask0"], T["unmask1"], T["unmask2"], G4, pp, net)
-        d0, d1, d2 = be.to_device(vx0), be.to_device(vx1), be.to_device(v1x)
+        (d0, n0), (d1, n1), (d2, n2) = dp.c_acc_product_and_share(be, ev, T["mask"], T["unmask0"], T["unmask1"], T["unmask2"], G4, pp, net)
+        assert n0 == n1 == n2 == G4  # the three share vectors stay in HBM and feed the commits / opens / sumchecks below
         for tab in (ev, d0, d1, d2):  # :1324-1363
             commits.append(ccommit(tab))
             opens.append(copen(tab))

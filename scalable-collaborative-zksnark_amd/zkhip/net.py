@@ -22,6 +22,11 @@ from typing import Callable, List
 import numpy as np
 
 
+def _at(buf, byte_off: int):
+    """a device buffer (or raw address) advanced by byte_off"""
+    return buf.at(byte_off) if hasattr(buf, "at") else buf + byte_off
+
+
 class Net:
     n_parties: int
     party_id: int
@@ -45,6 +50,24 @@ class Net:
 
     def sync(self):
         self.all_gather(np.zeros(1, dtype=np.uint64))
+
+    # device-buffer forms of the two exchanges.  `be` is the compute backend that owns the buffers (a zkhip.Ctx in
+    # production).  These defaults stage through the numpy methods above (thread / gloo / echo nets of the tests);
+    # RcclNet overrides them with collectives that never leave HBM.
+    def all_gather_device(self, d_send, nbytes: int, d_recv=None, be=None):
+        """-> device buffer holding n_parties * nbytes, ordered by party"""
+        parts = self.all_gather(be.download_ptr(d_send, nbytes))
+        out = d_recv or be.alloc(max(nbytes * self.n_parties, 1))
+        be.upload_ptr(out, np.concatenate([np.asarray(x, dtype=np.uint8).reshape(-1) for x in parts]))
+        return out
+
+    def all_to_all_device(self, d_send, nbytes_per_peer: int, d_recv=None, be=None, echo: str = "slot0"):
+        """party p sends bytes [q * nbytes_per_peer, (q + 1) * nbytes_per_peer) of d_send to party q; -> what every party sent to me, ordered by party"""
+        a = be.download_ptr(d_send, nbytes_per_peer * self.n_parties).reshape(self.n_parties, nbytes_per_peer)
+        got = self.all_to_all([a[q] for q in range(self.n_parties)], echo=echo)
+        out = d_recv or be.alloc(max(nbytes_per_peer * self.n_parties, 1))
+        be.upload_ptr(out, np.concatenate([np.asarray(x, dtype=np.uint8).reshape(-1) for x in got]))
+        return out
 
     # byte accounting like MPCNet::get_comm (multi.rs:378-387): (up, down)
     def __init_counters(self):
@@ -78,6 +101,24 @@ class LeaderEchoNet(Net):
         if echo == "identity":
             return [np.array(c, copy=True) for c in chunks]
         return [np.array(chunks[0], copy=True) for _ in range(self.n_parties)]
+
+    # device forms: the fabricated copies are made in HBM (the leader's data never visits the host)
+    def all_gather_device(self, d_send, nbytes: int, d_recv=None, be=None):
+        self._count(nbytes)
+        out = d_recv or be.alloc(max(nbytes * self.n_parties, 1))
+        for q in range(self.n_parties):
+            be.copy_d2d(_at(out, q * nbytes), d_send, nbytes)
+        return out
+
+    def all_to_all_device(self, d_send, nbytes_per_peer: int, d_recv=None, be=None, echo: str = "slot0"):
+        self._count(nbytes_per_peer)
+        out = d_recv or be.alloc(max(nbytes_per_peer * self.n_parties, 1))
+        if echo == "identity":
+            be.copy_d2d(out, d_send, nbytes_per_peer * self.n_parties)
+        else:
+            for q in range(self.n_parties):
+                be.copy_d2d(_at(out, q * nbytes_per_peer), d_send, nbytes_per_peer)
+        return out
 
 
 class TorchDistNet(Net):
@@ -153,12 +194,15 @@ class RcclNet(Net):
         dist.broadcast_object_list(box, src=0, group=group)
         return RcclNet(ctx, rank, world, box[0])
 
-    def all_gather_device(self, d_send, nbytes: int, d_recv=None):
-        """-> device buffer with n_parties * nbytes, ordered by party; stays in HBM"""
+    def all_gather_device(self, d_send, nbytes: int, d_recv=None, be=None):
+        """-> device buffer with n_parties * nbytes, ordered by party; stays in HBM (zk_allgather on the ctx stream)"""
+        assert be is None or be is self.ctx, "the communicator lives in its own ctx"
         self._count(nbytes)
         return self.ctx.allgather(d_send, nbytes, d_recv)
 
-    def all_to_all_device(self, d_send, nbytes_per_peer: int, d_recv=None):
+    def all_to_all_device(self, d_send, nbytes_per_peer: int, d_recv=None, be=None, echo: str = "slot0"):
+        """zk_alltoall on the ctx stream: HBM -> HBM over xGMI (the looped dynamic scatters of dacc_product.rs:94-104,155-203)"""
+        assert be is None or be is self.ctx, "the communicator lives in its own ctx"
         self._count(nbytes_per_peer)
         return self.ctx.alltoall(d_send, nbytes_per_peer, d_recv)
 

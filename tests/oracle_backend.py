@@ -49,6 +49,19 @@ class OracleSrs:
 
 
 class OracleBackend:
+    def alloc(self, nbytes):
+        return NumpyBuf(np.zeros((max(nbytes, 32) // 32, 4), dtype=np.uint64))
+
+    def copy_d2d(self, dst, src, nbytes):
+        _arr(dst).reshape(-1)[: nbytes // 8] = _arr(src).reshape(-1)[: nbytes // 8]
+
+    def download_ptr(self, src, nbytes):
+        return _arr(src).reshape(-1)[: nbytes // 8].copy().view(np.uint8)
+
+    def upload_ptr(self, dst, a):
+        a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        _arr(dst).reshape(-1)[: a.nbytes // 8] = a.view(np.uint64)
+
     def to_device(self, a):
         return NumpyBuf(a)
 

@@ -249,4 +249,5 @@ def test_c_acc_product_and_share(l):
     exp = po.c_acc_product_and_share_all(shares, masks, u0, u1, u2, opp)
     for p in range(pp.n):
         for k in range(3):
-            assert ints(res[p][k]) == exp[p][k], (p, k)
+            buf, cnt = res[p][k]  # device-resident results: (buffer, length)
+            assert ints(buf.download((cnt, 4))) == exp[p][k], (p, k)
