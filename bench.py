@@ -258,23 +258,25 @@ def main():
             },
             "msm_without_window_table": default_path,
             "msm_phase_ms": {"digits_sort": float(phase[0]), "k_accum_tiles": accum_ms, "fixup": float(phase[2]), "bucket_reduce": float(phase[3]), "host_combine": float(phase[4])},
+            # The dominant kernel is bound by the 32-bit integer multiplier ("not HBM and not MFMA"): the roofline
+            # object prices it against the MEASURED v_mad_u64_u32 issue rate of the chip; the HBM figure the north star asks for
+            # (algorithmic 128 B per scalar-mul over the kernel's HIP-event time, against 8 TB/s) sits beside it under "hbm".
             "roofline": {
                 "kernel": "zk::k_accum_tiles (bucket accumulation)",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "bound": "int_alu",
+                "achieved": (madds * MADS_PER_MADD / (accum_ms * 1e-3) / 1e12) if accum_ms > 0 else 0.0,
+                "peak": MAD_PEAK / 1e12,
+                "unit": "T v_mad_u64_u32/s",
+                "frac": (madds * MADS_PER_MADD / (accum_ms * 1e-3) / MAD_PEAK) if accum_ms > 0 else 0.0,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "note": "integer-VALU bound, not HBM bound: see int_alu",
-                "int_alu": {
-                    "achieved_mad_u64_u32_per_s": madds * MADS_PER_MADD / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,
-                    "measured_peak_mad_u64_u32_per_s": MAD_PEAK,
-                    "frac": (madds * MADS_PER_MADD / (accum_ms * 1e-3) / MAD_PEAK) if accum_ms > 0 else 0.0,
-                    "mads_per_mixed_addition": MADS_PER_MADD,
-                    "peak_source": "profiles/r01_ubench_int_alu.txt (v_mad_u64_u32, carry to SGPR)",
-                },
+                "mads_per_mixed_addition": MADS_PER_MADD,
+                "mixed_additions_per_launch": madds,
+                "kernel_ms": accum_ms,
+                "peak_source": "profiles/r01_ubench_int_alu.txt (v_mad_u64_u32 issue rate measured on this chip, carry to SGPR)",
+                "counters": "profiles/r03c_accum_valu_counters.csv (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES of this kernel)",
+                "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes, "note": "128 B per (point, scalar) pair / the kernel's HIP-event time (SURVEY.md 8d)"},
             },
         }
 
@@ -344,6 +346,31 @@ def main():
                 sc["note"] = ("algorithmic bytes: product 64 N, plain 32 N, fold 32 N, open 64 N (SURVEY.md 8d model A); field-op counts as the reference writes them "
                               "(product 9N mul + 9N add; plain 2N + 3N).  fold and plain run as flat linear passes (one wide multiply-accumulate per element): HBM-bound; "
                               "the product sumcheck (2 wide accumulations + 2 multiplications per pair) is bound by the integer multiplier's issue rate")
+                # roofline of the product sumcheck's dominant kernel, k_pass<2,1> (first HBM pass of the call: two rounds fused in
+                # registers), HIP events on the ctx stream (zk_sumcheck_last_timing).  Per lane iteration (4 + 4 elements in, one
+                # pair out): three pair-rounds of 2 wide accumulations (64 mad) + 2 multiplications (128 mad), + 2 wide accumulations
+                # for the t1 of the call's first round.
+                try:
+                    ctx.dbg_tune("sc_ts", 3)
+                    kp = {}
+                    for lg in (args.log2n, big, big + 2):
+                        m = 1 << lg
+                        f_t, g_t = device_table(ctx, lg, 11), device_table(ctx, lg, 12)
+                        ts = []
+                        for _ in range(6):
+                            ctx.sumcheck_product(f_t, g_t, m, chal)
+                            ts.append(ctx.sumcheck_last_timing().copy())
+                        first_ms, all_ms = [float(x) for x in np.median(np.array(ts[1:]), axis=0)]
+                        mads = (m / 4) * (3 * (2 * 64 + 2 * 128) + 2 * 64)
+                        kp[f"2p{lg}"] = {"kernel": "zk::k_pass<2, 1> (first pass)", "kernel_ms": first_ms, "all_launches_ms": all_ms,
+                                         "bound": "int_alu", "achieved": mads / (first_ms * 1e-3) / 1e12, "peak": MAD_PEAK / 1e12, "unit": "T v_mad_u64_u32/s",
+                                         "frac": mads / (first_ms * 1e-3) / MAD_PEAK,
+                                         "hbm": {"achieved": 64.0 * m / (first_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 64.0 * m / (first_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "note": "the pass reads both tables once (64 B per index pair of the call's algorithmic bytes)"}}
+                        del f_t, g_t
+                    sc["roofline_k_pass"] = kp
+                finally:
+                    ctx.dbg_tune("sc_ts", 0)
                 extra["sumcheck"] = sc
             del sf, sg
             ctx.trim()
@@ -357,7 +384,7 @@ def main():
                 from zkhip.hyperplonk import PackedProvingParameters, dhyperplonk
                 from zkhip.net import LeaderEchoNet
                 from zkhip.pss import PackedSharingParams
-                from zkhip.verify import check_dhyperplonk_transcripts
+                from zkhip.verify import check_dhyperplonk_transcripts, dhyperplonk_anchors, trace_anchor_values
 
                 e_n = 20
                 e_pp = PackedSharingParams(1)
@@ -370,9 +397,20 @@ def main():
                     res, tm = dhyperplonk(e_n, pk, e_pp, ctx, e_net, seed=7 + rank)
                     if best is None or tm.get("Distributed HyperPlonk", 1e9) < best.get("Distributed HyperPlonk", 1e9):
                         best = tm
-                bad = check_dhyperplonk_transcripts(e_n, res, pk, 8, e_net.is_leader, world == 1)
+                # self-check of the reported run: every transcript's verifier chain with both ends pinned by independently
+                # computed values (claim and final evaluation through other kernels, zkhip.verify) -- leader-echo mode; the
+                # 8-rank run checks the consistency of its chains (its anchors would need another exchange)
+                anchors = None
+                if world == 1:
+                    ctx.sc_trace = []
+                    res, _ = dhyperplonk(e_n, pk, e_pp, ctx, e_net, seed=7 + rank)
+                    trace, ctx.sc_trace = ctx.sc_trace, None
+                    anchors = dhyperplonk_anchors([trace_anchor_values(ctx, trace)], 0, 8)
+                    del trace
+                bad = check_dhyperplonk_transcripts(e_n, res, pk, 8, e_net.is_leader, world == 1, anchors=anchors)
                 extra["e2e"] = {"n": e_n, "l": 1, "parties": 8, "mode": "leader (party 0's full work, no-comm echo net)" if world == 1 else f"8 parties = 8 ranks, exchanges: {type(e_net).__name__} ({backend})",
-                                "setup_s": setup_s, "timers_s": best, "scalar_muls_per_proof": 24903603, "transcript_checks": "ok" if not bad else bad}
+                                "setup_s": setup_s, "timers_s": best, "scalar_muls_per_proof": 24903603, "transcript_checks": "ok" if not bad else bad,
+                                "transcript_check_kind": "chains anchored at both ends (independent claim + final evaluation)" if anchors else "chain consistency"}
                 if bad:
                     extra["e2e"]["timers_s"] = None  # an unverified figure is not a figure
                 del pk

@@ -254,6 +254,11 @@ int zk_msm_set_window(zk_ctx *ctx, int c_override);
  * [2] fix-up, [3] bucket reduction + conversion + D2H, [4] host combine (wall), [5] total */
 int zk_msm_last_timing(zk_ctx *ctx, float h_ms[6]);
 
+/* device time of the last zk_sumcheck / zk_sumcheck_product / zk_open_rounds call on this ctx, HIP events on the ctx stream,
+ * recorded only while the knob "sc_ts" is 3 (zk_dbg_tune): [0] the first stage (the first HBM pass of a large table:
+ * k_pass<2,1> for the product sumcheck), [1] all launches of the call */
+int zk_sumcheck_last_timing(zk_ctx *ctx, float h_ms[2]);
+
 /* ---- party exchanges on one node: an RCCL communicator inside the ctx -------------------------
  * Replaces the typed adapter over mpc-net's TCP star, dist-primitive/src/utils/serializing_net.rs:11-141.
  * The party axis is the GPU axis (party p = rank p); payloads are raw Montgomery limbs in HBM, moved over

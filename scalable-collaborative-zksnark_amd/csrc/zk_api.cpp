@@ -507,6 +507,11 @@ int zk_msm_last_timing(zk_ctx* ctx, float h_ms[6]) {
     return ZK_OK;
 }
 
+int zk_sumcheck_last_timing(zk_ctx* ctx, float h_ms[2]) {
+    if (!ctx || !h_ms) return ZK_ERR_INVALID;
+    h_ms[0] = ctx->sc_ms[0], h_ms[1] = ctx->sc_ms[1];
+    return ZK_OK;
+}
 int zk_dbg_tune(const char* key, long value) { return tune_set(key, value); }
 
 int zk_dbg_fq_mul2add(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n) { return dbg_fq(ctx, 3, a, b, out, n); }

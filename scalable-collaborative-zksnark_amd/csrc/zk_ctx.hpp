@@ -37,6 +37,7 @@ struct zk_ctx {
     size_t h_pinned_cap = 0;
     int msm_window_override = 0;
     float msm_ms[6] = {0, 0, 0, 0, 0, 0};
+    float sc_ms[2] = {0, 0};  // tuning sc_ts = 3: device time of the first stage / of all launches of the last sumcheck-family call
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     static constexpr int kAux = 6;    // extra streams for independent MSM window classes of one batch
     static constexpr int kParts = 4;  // staggered parts of one MSM class (zk_msm.hip)
@@ -76,7 +77,7 @@ struct Tuning {
     // sumcheck family (zk_fr.hip)
     long sc_pass_wg = 0;      // workgroups per CU of the HBM passes (0: 2 product / 4 others)
     long sc_local_g = 256;    // workgroups of a local stage
-    long sc_ts = 0;           // 1: in-kernel stage timestamps of the local launches on stderr, 2: host-side phases
+    long sc_ts = 0;           // 1: in-kernel stage timestamps of the local launches on stderr, 2: host-side phases, 3: HIP events (zk_sumcheck_last_timing)
     long sc_xcd = 1;          // XCD-aware slice map of the local stages
     long sc_kf = 4;           // rounds per flat fold pass (0: round-by-round passes)
     long sc_plain_flat = 1;   // plain sumcheck passes in flat form

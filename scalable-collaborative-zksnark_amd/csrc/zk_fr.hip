@@ -1055,6 +1055,8 @@ static int sc_enqueue(zk_ctx* ctx, ScCall& c) {
     size_t ncols = 0;
     ReducePlan rp;
     std::memset(&rp, 0, sizeof(rp));
+    const bool time_it = c.want_ts && tuning().sc_ts == 3;  // HIP events around the first stage and around the whole chain
+    if (time_it) hipEventRecord(ctx->ev[0], st_);
     for (const ScStage& st : plan) {
         const int k = st.k;
         const bool final_out = (MODE == 2) && (done + k == rounds);
@@ -1087,12 +1089,14 @@ static int sc_enqueue(zk_ctx* ctx, ScCall& c) {
             rp.first[rp.n + 1] = rp.first[rp.n] + nout;
             rp.n++;
         }
+        if (time_it && done == 0) hipEventRecord(ctx->ev[1], st_);
         cf = fo;
         cg = go;
         m = st.kind == 0 ? m >> k : (size_t)st.G * (st.E >> (k - st.pre));
         done += k;
         flip ^= 1;
     }
+    if (time_it && plan.empty()) hipEventRecord(ctx->ev[1], st_);
     if (done < rounds || MODE != 2) {
         // last stage: the remaining rounds (possibly zero) in one workgroup, which also emits the final
         // table; the other blocks of the launch reduce the partial sums of the earlier stages
@@ -1106,6 +1110,7 @@ static int sc_enqueue(zk_ctx* ctx, ScCall& c) {
     } else if (rounds == 0) {
         ZK_HIP(ctx, hipMemcpyAsync(d_out, c.d_f, len * fr, hipMemcpyDeviceToDevice, st_));
     }
+    if (time_it) hipEventRecord(ctx->ev[2], st_);
     return ZK_OK;
 }
 
@@ -1204,6 +1209,10 @@ int multilinear_run(zk_ctx* ctx, int mode, const void* d_f, const void* d_g, siz
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         hts(false);
         sc_ts_print();
+        if (tuning().sc_ts == 3) {
+            hipEventElapsedTime(&ctx->sc_ms[0], ctx->ev[0], ctx->ev[1]);  // first stage (the first HBM pass of a large table)
+            hipEventElapsedTime(&ctx->sc_ms[1], ctx->ev[0], ctx->ev[2]);  // every launch of the call
+        }
         switch (mode) {
             case 0: sc_collect<0>(c); break;
             case 1: sc_collect<1>(c); break;

@@ -70,6 +70,7 @@ SYMBOLS = [
     ("zk_msm_window", _i, [_sz]),
     ("zk_msm_set_window", _i, [_vp, _i]),
     ("zk_msm_last_timing", _i, [_vp, _vp]),
+    ("zk_sumcheck_last_timing", _i, [_vp, _vp]),
     ("zk_comm_unique_id", _i, [_vp]),
     ("zk_comm_init", _i, [_vp, _i, _i, _vp]),
     ("zk_comm_init_all", _i, [_vp, _i]),

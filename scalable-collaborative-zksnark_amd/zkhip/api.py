@@ -619,6 +619,12 @@ class Ctx:
     def msm_set_window(self, c: int):
         self._check(self.lib.zk_msm_set_window(self.h, c))
 
+    def sumcheck_last_timing(self) -> np.ndarray:
+        """[first stage ms, all launches ms] of the last sumcheck-family call (recorded while dbg_tune("sc_ts", 3))"""
+        t = np.zeros(2, dtype=np.float32)
+        self._check(self.lib.zk_sumcheck_last_timing(self.h, _h(t)))
+        return t
+
     def msm_last_timing(self) -> np.ndarray:
         t = np.zeros(6, dtype=np.float32)
         self._check(self.lib.zk_msm_last_timing(self.h, _h(t)))
