@@ -88,7 +88,6 @@ struct Tuning {
     long sc_pre = 1;          // first round of a full-size local stage straight out of the table
     long sc_pinned_out = 1;   // results written straight into pinned host memory
     long sc_t1_device = 0;    // TEST SWITCH: t1 = sum f_hi g_hi of EVERY round computed on the device (never derived)
-    long sc_flag_sync = 1;    // completion through a flag in pinned memory instead of hipStreamSynchronize
     // MSM (zk_msm.hip)
     long msm_table_dc = 0;    // window-table width delta (sweeps)
     long msm_qstep = 2;       // window-class quantisation step of batches

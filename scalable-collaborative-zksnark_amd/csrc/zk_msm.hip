@@ -63,6 +63,21 @@ struct CvG1 {
     __device__ static __forceinline__ void madd(Xyzz& acc, const Aff& p, bool neg) { xyzz30_madd(acc, p, neg); }
     __device__ static __forceinline__ Xyzz add(const Xyzz& a, const Xyzz& b) { return xyzz30_add(a, b); }
     __device__ static __forceinline__ Xyzz dbl(const Xyzz& a) { return xyzz30_dbl(a); }
+    // the affine image of acc as one record of the window table (canonical coordinates, like every SRS coordinate)
+    __device__ static __forceinline__ void table_store(const Xyzz& acc, void* table, size_t idx) {
+        Aff30 a;
+        if (xyzz30_is_inf(acc)) {
+            a.x = f30_zero();
+            a.y = f30_zero();
+        } else {
+            const Fq30 i3 = f30_inv(acc.zzz);               // 1/Z^3
+            const Fq30 iz = f30_mul(acc.zz, i3);            // Z^2/Z^3 = 1/Z
+            a.x = f30_canon8(f30_mul(acc.x, f30_sqr(iz)));  // X/Z^2
+            a.y = f30_canon8(f30_mul(acc.y, i3));           // Y/Z^3
+        }
+        f30_store(table, idx * 96, a.x);
+        f30_store(table, idx * 96 + 48, a.y);
+    }
     // (X*ZZ, Y*ZZZ, ZZ) is a Jacobian representative; written in the REFERENCE Montgomery form
     __device__ static __forceinline__ void finish(const Xyzz& acc, void* out, size_t t) {
         Fq30 X = f30_zero(), Y = f30_zero(), Z = f30_zero();
@@ -91,6 +106,22 @@ struct CvG2 {
     __device__ static __forceinline__ void madd(Xyzz& acc, const Aff& p, bool neg) { xyzz2_madd(acc, p, neg); }
     __device__ static __forceinline__ Xyzz add(const Xyzz& a, const Xyzz& b) { return xyzz2_add(a, b); }
     __device__ static __forceinline__ Xyzz dbl(const Xyzz& a) { return xyzz2_dbl(a); }
+    __device__ static __forceinline__ void table_store(const Xyzz& acc, void* table, size_t idx) {
+        Fq2x x = f2_zero(), y = f2_zero();
+        if (!xyzz2_is_inf(acc)) {
+            // 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)
+            const Fq30 nrm = f30_mul2add(acc.zzz.c0, acc.zzz.c0, acc.zzz.c1, acc.zzz.c1);  // 2q * 2q * 2 <= 256: < 2q
+            const Fq30 ni = f30_inv(nrm);
+            const Fq2x i3 = Fq2x{f30_mul(acc.zzz.c0, ni), f30_mul(f30_negk<2>(acc.zzz.c1), ni)};  // 1/Z^3, components < 2q
+            const Fq2x iz = f2_mul<2>(acc.zz, i3);                                                    // 1/Z
+            x = f2_canon8(f2_mul<2>(acc.x, f2_sqr<2>(iz)));                                           // 8 * 4
+            y = f2_canon8(f2_mul<2>(acc.y, i3));
+        }
+        f30_store(table, idx * 192, x.c0);
+        f30_store(table, idx * 192 + 48, x.c1);
+        f30_store(table, idx * 192 + 96, y.c0);
+        f30_store(table, idx * 192 + 144, y.c1);
+    }
     __device__ static __forceinline__ void finish(const Xyzz& acc, void* out, size_t t) {
         Fq2x X = f2_zero(), Y = f2_zero(), Z = f2_zero();
         if (!xyzz2_is_inf(acc)) {
@@ -799,31 +830,21 @@ __global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void
     Cv::finish(acc, out, t);
 }
 
-// SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine, packed 96 B), one lane per point.
+// SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine records), one lane per point.
 // With it every window's digit can use the SAME bucket set (the factor 2^{c w} is in the base).
-__global__ void __launch_bounds__(kBlk) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
-                                                   void* __restrict__ table) {
-    const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
+template <class Cv>
+__global__ void __launch_bounds__(Cv::kQuad ? kBlk : 64) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
+                                                                       void* __restrict__ table) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Aff30 p = aff30_load(bases, i);
-    Xyzz30 acc;
-    xyzz30_set_inf(acc);
-    xyzz30_madd(acc, p, false);
+    const typename Cv::Aff p = Cv::aff_load(bases, i);
+    typename Cv::Xyzz acc;
+    Cv::set_inf(acc);
+    Cv::madd(acc, p, false);
     for (int w = 0; w < L.W; w++) {
         if (w > 0)
-            for (int k = 0; k < L.width(w - 1); k++) acc = xyzz30_dbl(acc);
-        Aff30 a;
-        if (xyzz30_is_inf(acc)) {
-            a.x = f30_zero();
-            a.y = f30_zero();
-        } else {
-            Fq30 i3 = f30_inv(acc.zzz);                    // 1/Z^3
-            Fq30 iz = f30_mul(acc.zz, i3);                 // Z^2/Z^3 = 1/Z
-            a.x = f30_canon8(f30_mul(acc.x, f30_sqr(iz)));  // X/Z^2, canonical like every SRS coordinate
-            a.y = f30_canon8(f30_mul(acc.y, i3));           // Y/Z^3
-        }
-        f30_store(table, ((size_t)w * nsr + i) * 96, a.x);
-        f30_store(table, ((size_t)w * nsr + i) * 96 + 48, a.y);
+            for (int k = 0; k < L.width(w - 1); k++) acc = Cv::dbl(acc);
+        Cv::table_store(acc, table, (size_t)w * nsr + i);
     }
 }
 
@@ -1143,7 +1164,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
             run.empty_items.push_back(k);
             continue;
         }
-        const bool shared = Cv::kEndo && it.srs->d_table != nullptr && ctx->msm_window_override <= 0;
+        const bool shared = it.srs->d_table != nullptr && ctx->msm_window_override <= 0;
         int c = ctx->msm_window_override > 0 ? ctx->msm_window_override : msm_pick_window(it.n);
         if (count > 1 && ctx->msm_window_override <= 0) c = quantised_window(c);
         if (shared) c = it.srs->table_c;
@@ -1716,10 +1737,19 @@ int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t 
     return ZK_OK;
 }
 
+// window bits of a G2 level's table: the reduction passes of G2 are one lane per addition (no quad form), so a pass costs
+// ~3x a G1 pass and the optimum sits lower than G1's (tools/g2_time.py sweep on MI355X)
+static int msm_pick_window_full_g2(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg <= 12 ? lg + 2 : (lg <= 17 ? 15 : lg - 2);
+    c += (int)tuning().msm_table_dc;
+    return std::max(4, std::min(20, c));
+}
+
 int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     if (!srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
-    if (srs->g2) return fail(ctx, ZK_ERR_INVALID, "zk_srs_precompute: G1 only");
-    if (c == 0) c = msm_pick_window_full(srs->n ? srs->n : 1);
+    if (c == 0) c = srs->g2 ? msm_pick_window_full_g2(srs->n ? srs->n : 1) : msm_pick_window_full(srs->n ? srs->n : 1);
     if (c < 2 || c > 20) return fail(ctx, ZK_ERR_INVALID, "window bits out of range");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     if (srs->d_table) {
@@ -1730,10 +1760,15 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     if (srs->n == 0) return ZK_OK;
     const WinLayout L = msm_layout(c, kFullBits);
     const size_t nsr = (srs->n + 3) & ~(size_t)3;
-    ZK_HIP(ctx, device_alloc(ctx, &srs->d_table, (size_t)L.W * nsr * 96));
-    ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * 96, ctx->stream));
-    hipLaunchKernelGGL(k_precompute, dim3((unsigned)((srs->n + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream,
-                       (const void*)srs->d_bases, srs->n, nsr, L, srs->d_table);
+    const size_t rec = srs->g2 ? CvG2::kAffBytes : CvG1::kAffBytes;
+    ZK_HIP(ctx, device_alloc(ctx, &srs->d_table, (size_t)L.W * nsr * rec));
+    ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * rec, ctx->stream));
+    if (srs->g2)
+        hipLaunchKernelGGL((k_precompute<CvG2>), dim3((unsigned)((srs->n + 63) / 64)), dim3(64), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr, L,
+                           srs->d_table);
+    else
+        hipLaunchKernelGGL((k_precompute<CvG1>), dim3((unsigned)((srs->n + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr,
+                           L, srs->d_table);
     ZK_HIP(ctx, hipGetLastError());
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     srs->table_c = c;

@@ -123,3 +123,28 @@ def test_msm_g2_batch_and_group_mismatch(ctx):
         ctx.msm_g2(ctx.srs_register(g1), ctx.to_device(scs[2]), 3)
     with pytest.raises(zkhip.ZkError):
         ctx.msm_g1(srs, ctx.to_device(scs[2]), 3)
+
+
+@pytest.mark.parametrize("lg,c", [(6, 0), (11, 0), (14, 0), (14, 9), (15, 16)])
+def test_msm_g2_window_table_matches_table_less_path(ctx, lg, c):
+    """zk_srs_precompute on a G2 level (table of 2^{o_w} P_i over Fq2): same result bits as the table-less path, which the
+    tests above pin to the oracle; offsets and batches included"""
+    n = 1 << lg
+    k0, k1 = 0x7654321 + lg, 0x1F2E3D
+    srs = ctx.srs_register_g2(_seq(n, k0, k1))
+    sc = rand_fr(n, 1200 + lg)
+    sc[0] = 0
+    sc[1] = sc[2]
+    d = ctx.to_device(sc)
+    want = ctx.msm_g2(srs, d, n)
+    want_off = ctx.msm_g2(srs, ctx.to_device(sc[: n // 2]), n // 2, offset=3)
+    srs.precompute(c)
+    assert srs.table_window == (c or srs.table_window) and srs.table_window > 0
+    assert (ctx.msm_g2(srs, d, n) == want).all()
+    assert (ctx.msm_g2(srs, ctx.to_device(sc[: n // 2]), n // 2, offset=3) == want_off).all()
+    e = sum(s * (k0 + i * k1) for i, s in enumerate(_ints(sc))) % po.R_MOD
+    assert _aff(want) == po.g2_mul(po.G2_GEN, e)
+    outs = ctx.msm_g2_batch([srs, srs], [d, d], [n, n // 4])
+    assert (outs[0] == want).all()
+    e4 = sum(s * (k0 + i * k1) for i, s in enumerate(_ints(sc[: n // 4]))) % po.R_MOD
+    assert _aff(outs[1]) == po.g2_mul(po.G2_GEN, e4)

@@ -77,6 +77,46 @@ def test_dhyperplonk_leader_echo_config1():
     assert net.upload > 0 and net.upload == net.download
 
 
+def test_dhyperplonk_leader_echo_config0_at_its_size():
+    """
+    BASELINE.json configs[0] as stated: hack/run-hyperplonk in `leader` mode, l = 1, 2^12 constraints, on the CPU path (the C
+    port behind the same host driver; a few seconds).  Checks: every sumcheck transcript against its verifier chain with both
+    ends pinned by independently computed values (zkhip.verify), the Appendix-B closed forms of the no-comm echo net
+    (d_commit = 8 x the local commitment, d_msm = (4/7) x the plain MSM), the byte counters, and the shapes at n = 12.
+    """
+    import pyoracle as po
+    from helpers import jac_norm_to_affine, pt_ints
+    from zkhip import dist_primitive as dp
+    from zkhip.verify import check_dhyperplonk_transcripts, dhyperplonk_anchors, trace_anchor_values
+
+    n = 12
+    pp = PackedSharingParams(1)
+    be = OracleBackend()
+    pk = PackedProvingParameters.new(n, pp, be, seed=12)
+    net = LeaderEchoNet(8)
+    be.sc_trace = []
+    res, timers = dhyperplonk(n, pk, pp, be, net, seed=13)
+    trace, be.sc_trace = be.sc_trace, None
+    (gate_proofs, gate_comms), (w_proofs, w_commits, w_opens) = res
+    s = 3
+    assert len(gate_proofs) == 6 and len(gate_comms) == 6 and len(w_proofs) == 1 + 3 + 3 * (n - s) + 3
+    assert all(np.asarray(p).shape == (n + 1, 3, 4) for p in gate_proofs)  # n rounds + the closing row at l = 1
+    assert w_opens[0][1].shape == (n + 2, 18)
+    values = trace_anchor_values(be, trace)
+    anchors = dhyperplonk_anchors([values], 0, 8)
+    assert len(anchors) == len(w_proofs) + 6
+    assert check_dhyperplonk_transcripts(n, res, pk, 8, True, True, anchors=anchors) == []
+    # Appendix B: the echo net hands the leader 8 copies of its own message
+    M = 1 << n
+    local = dp.commit(be, pk.d_commitment, pk.tables["ssigma_p"], 4 * M // 8)
+    assert pt_ints(jac_norm_to_affine(w_commits[1])) == po.g1_mul(pt_ints(jac_norm_to_affine(local)), 8)
+    plain = dp.commit(be, pk.c_commitment, pk.tables["a_evals"], M)
+    four_sevenths = 4 * pow(7, -1, po.R_MOD) % po.R_MOD
+    assert pt_ints(jac_norm_to_affine(gate_comms[0][0])) == po.g1_mul(pt_ints(jac_norm_to_affine(plain)), four_sevenths)
+    assert net.upload > 0 and net.upload == net.download
+    assert set(timers) >= {"Commit", "Gate identity", "Wire identity", "Open", "Distributed HyperPlonk"}
+
+
 def test_dhyperplonk_batched_calls_keep_reference_positions():
     """
     the driver batches independent commits / opens; every output must still sit where the reference's

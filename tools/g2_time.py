@@ -1,4 +1,4 @@
-"""time zk_msm_g2 on 2^lg points (bases = an arithmetic sequence built with the oracle-free host arithmetic of zkhip.pairing)"""
+"""python tools/g2_time.py <lg> [table window bits ...]: time zk_msm_g2 on 2^lg points, without and with the window table (bases = an arithmetic sequence built with the oracle-free host arithmetic of zkhip.pairing)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd"))
@@ -14,8 +14,16 @@ for _ in range(n):
     cur = pr.g2_add(cur, step)
 srs = ctx.srs_register_g2(np.array(rows, dtype=np.uint64))
 sc = ctx.to_device(random_fr(n, 5))
-for _ in range(2): ctx.msm_g2(srs, sc, n)
-t0 = time.perf_counter(); R = 5
-for _ in range(R): ctx.msm_g2(srs, sc, n)
-dt = (time.perf_counter() - t0) / R
-print(f"G2 MSM 2^{lg}: {dt*1e3:.2f} ms  {n/dt:.3e} scalar-muls/s  phases(ms) {[round(float(x),2) for x in ctx.msm_last_timing()]}")
+def run(tag):
+    for _ in range(2): out = ctx.msm_g2(srs, sc, n)
+    t0 = time.perf_counter(); R = 5
+    for _ in range(R): ctx.msm_g2(srs, sc, n)
+    dt = (time.perf_counter() - t0) / R
+    print(f"G2 MSM 2^{lg} {tag}: {dt*1e3:.2f} ms  {n/dt:.3e} scalar-muls/s  phases(ms) {[round(float(x),2) for x in ctx.msm_last_timing()]}", flush=True)
+    return out
+ref = run("no table")
+for c in [int(x) for x in sys.argv[2:]] or [0]:  # window bits of the table (0: the library's pick)
+    t0 = time.perf_counter()
+    srs.precompute(c)
+    tb = time.perf_counter() - t0
+    assert (run(f"window table c={srs.table_window} (built in {tb:.2f} s)") == ref).all()
