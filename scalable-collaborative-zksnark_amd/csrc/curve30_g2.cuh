@@ -204,4 +204,86 @@ __device__ __forceinline__ Xyzz2 xyzz2_add(const Xyzz2& a, const Xyzz2& b) {
     return r;
 }
 
+// ---- one G2 XYZZ addition spread over the four lanes of a quad: the rounds of curve30.cuh's xyzz30_add_quad, every
+// operand a pair of Fq30 (an Fq2 multiplication per lane and round).  The late reduction passes and the fix-up of a G2 MSM
+// are chains of single additions: ~3 x the latency of G1's per multiplication, so the quad form matters more here. ----
+template <int R>
+__device__ __forceinline__ Fq2x f2_quad_bcast(const Fq2x& v) {
+    Fq2x r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        r.c0.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)v.c0.l[i], R * 0x55, 0xf, 0xf, true);
+        asm volatile("" : "+v"(r.c0.l[i]));  // (keep it a plain v_mov_b32_dpp: see curve30.cuh)
+        r.c1.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)v.c1.l[i], R * 0x55, 0xf, 0xf, true);
+        asm volatile("" : "+v"(r.c1.l[i]));
+    }
+    return r;
+}
+__device__ __forceinline__ Fq2x f2_sel4(int role, const Fq2x& a0, const Fq2x& a1, const Fq2x& a2, const Fq2x& a3) {
+    Fq2x r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        r.c0.l[i] = (role == 0) ? a0.c0.l[i] : (role == 1) ? a1.c0.l[i] : (role == 2) ? a2.c0.l[i] : a3.c0.l[i];
+        r.c1.l[i] = (role == 0) ? a0.c1.l[i] : (role == 1) ? a1.c1.l[i] : (role == 2) ? a2.c1.l[i] : a3.c1.l[i];
+    }
+    return r;
+}
+// out[io] = in[ia] + in[ib]; all four lanes of a quad call it with identical indices (role = lane & 3).
+// Round 1: U1 = X1*ZZ2 | U2 = X2*ZZ1 | S1 = Y1*ZZZ2 | S2 = Y2*ZZZ1      bounds 8q * (2q + 2q)
+// Round 2: A = ZZ1*ZZ2 | B = ZZZ1*ZZZ2 | PP = P^2 | RR = R^2             4q * (4q + 4q)
+// Round 3: Q = U1*PP   | ZZ3 = A*PP    | PPP = P*PP | -                  4q * (2q + 2q)
+// Round 4: -           | ZZZ3 = B*PPP  | T1 = S1*PPP | T2 = R*(Q + 8q - X3)   4q * (10q + 12q);  Y3 = T2 - T1
+__device__ __forceinline__ void xyzz2_add_quad(const void* __restrict__ in, size_t ia, size_t ib, void* __restrict__ out, size_t io, int role) {
+    const Fq2x opA = f2_load_chunks(in, (role & 1) ? ib : ia, (role & 2) ? 6 : 0);    // a.x | b.x | a.y | b.y
+    const Fq2x opB = f2_load_chunks(in, (role & 1) ? ia : ib, (role & 2) ? 18 : 12);  // b.zz | a.zz | b.zzz | a.zzz
+    const Fq2x zz2 = f2_quad_bcast<0>(opB), zz1 = f2_quad_bcast<1>(opB), zzz2 = f2_quad_bcast<2>(opB), zzz1 = f2_quad_bcast<3>(opB);
+    const bool a_inf = f2_all_zero(zz1), b_inf = f2_all_zero(zz2);  // identical in the four lanes
+    if (a_inf || b_inf) {  // the other operand (or infinity) is the result: lane r copies coordinate r
+        f2_store_chunks(out, io, 6 * role, f2_load_chunks(in, a_inf ? ib : ia, 6 * role));
+        return;
+    }
+    const Fq2x m1 = f2_mul<2>(opA, opB);
+    const Fq2x u1 = f2_quad_bcast<0>(m1), u2 = f2_quad_bcast<1>(m1), s1 = f2_quad_bcast<2>(m1), s2 = f2_quad_bcast<3>(m1);
+    const Fq2x P = f2_sub2(u2, u1);  // < 4q
+    const Fq2x R = f2_sub2(s2, s1);  // < 4q
+    const Fq2x m2 = f2_mul<4>(f2_sel4(role, zz1, zzz1, P, R), f2_sel4(role, zz2, zzz2, P, R));
+    const Fq2x A = f2_quad_bcast<0>(m2), B = f2_quad_bcast<1>(m2), PP = f2_quad_bcast<2>(m2), RR = f2_quad_bcast<3>(m2);
+    const Fq2x m3 = f2_mul<2>(f2_sel4(role, u1, A, P, P), PP);
+    const Fq2x Q = f2_quad_bcast<0>(m3), ZZ3 = f2_quad_bcast<1>(m3), PPP = f2_quad_bcast<2>(m3);
+    if (f2_is_zero_2q(ZZ3)) {  // same x: doubling or cancellation (adversarial inputs only) -- lane 0 redoes it alone
+        if (role == 0) xyzz2_store(out, io, xyzz2_add(xyzz2_load(in, ia), xyzz2_load(in, ib)));
+        return;
+    }
+    const Fq2x X3 = f2_sub6(RR, f2_add2x(PPP, Q));  // < 8q
+    const Fq2x m4 = f2_mul<12>(f2_sel4(role, B, B, s1, R), f2_sel4(role, PPP, PPP, PPP, f2_sub8(Q, X3)));
+    const Fq2x ZZZ3 = f2_quad_bcast<1>(m4), T1 = f2_quad_bcast<2>(m4), T2 = f2_quad_bcast<3>(m4);
+    const Fq2x Y3 = f2_sub2(T2, T1);  // < 4q
+    f2_store_chunks(out, io, 6 * role, f2_sel4(role, X3, Y3, ZZ3, ZZZ3));
+}
+// acc += in[ib], acc replicated in the registers of the four lanes (the fix-up's chain), same rounds
+__device__ __forceinline__ Xyzz2 xyzz2_acc_quad(const Xyzz2& acc, const void* __restrict__ in, size_t ib, int role) {
+    const Fq2x bpart = f2_load_chunks(in, ib, role == 0 ? 12 : role == 1 ? 0 : role == 2 ? 18 : 6);  // b.zz | b.x | b.zzz | b.y
+    const Fq2x zz2 = f2_quad_bcast<0>(bpart);
+    if (f2_all_zero(zz2)) return acc;                    // b is infinity
+    if (xyzz2_is_inf(acc)) return xyzz2_load(in, ib);    // (all lanes load all of b)
+    const Fq2x zzz2 = f2_quad_bcast<2>(bpart);
+    // U1 = X1*ZZ2 | U2 = X2*ZZ1 | S1 = Y1*ZZZ2 | S2 = Y2*ZZZ1: first operand < 8q, second < 2q
+    const Fq2x m1 = f2_mul<2>(f2_sel4(role, acc.x, bpart, acc.y, bpart), f2_sel4(role, bpart, acc.zz, bpart, acc.zzz));
+    const Fq2x u1 = f2_quad_bcast<0>(m1), u2 = f2_quad_bcast<1>(m1), s1 = f2_quad_bcast<2>(m1), s2 = f2_quad_bcast<3>(m1);
+    const Fq2x P = f2_sub2(u2, u1);
+    const Fq2x R = f2_sub2(s2, s1);
+    const Fq2x m2 = f2_mul<4>(f2_sel4(role, acc.zz, acc.zzz, P, R), f2_sel4(role, zz2, zzz2, P, R));
+    const Fq2x A = f2_quad_bcast<0>(m2), B = f2_quad_bcast<1>(m2), PP = f2_quad_bcast<2>(m2), RR = f2_quad_bcast<3>(m2);
+    const Fq2x m3 = f2_mul<2>(f2_sel4(role, u1, A, P, P), PP);
+    const Fq2x Q = f2_quad_bcast<0>(m3), ZZ3 = f2_quad_bcast<1>(m3), PPP = f2_quad_bcast<2>(m3);
+    if (f2_is_zero_2q(ZZ3)) return xyzz2_add(acc, xyzz2_load(in, ib));  // doubling / cancellation: every lane alone, same result
+    Xyzz2 r;
+    r.x = f2_sub6(RR, f2_add2x(PPP, Q));
+    const Fq2x m4 = f2_mul<12>(f2_sel4(role, B, B, s1, R), f2_sel4(role, PPP, PPP, PPP, f2_sub8(Q, r.x)));
+    r.zzz = f2_quad_bcast<1>(m4);
+    r.y = f2_sub2(f2_quad_bcast<3>(m4), f2_quad_bcast<2>(m4));
+    r.zz = ZZ3;
+    return r;
+}
+
 }  // namespace zk

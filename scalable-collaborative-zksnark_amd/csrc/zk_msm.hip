@@ -63,6 +63,16 @@ struct CvG1 {
     __device__ static __forceinline__ void madd(Xyzz& acc, const Aff& p, bool neg) { xyzz30_madd(acc, p, neg); }
     __device__ static __forceinline__ Xyzz add(const Xyzz& a, const Xyzz& b) { return xyzz30_add(a, b); }
     __device__ static __forceinline__ Xyzz dbl(const Xyzz& a) { return xyzz30_dbl(a); }
+    // quad-lane forms (role = lane & 3 owns coordinate `role` of a point)
+    __device__ static __forceinline__ void quad_copy(const void* in, size_t src, void* out, size_t dst, int role) {
+        f30_store_chunks(out, dst, 3 * role, f30_load_chunks(in, src, 3 * role));
+    }
+    __device__ static __forceinline__ void quad_store_inf(void* out, size_t dst, int role) { f30_store_chunks(out, dst, 3 * role, f30_zero()); }
+    __device__ static __forceinline__ void quad_store(void* out, size_t dst, int role, const Xyzz& p) {
+        f30_store_chunks(out, dst, 3 * role, role == 0 ? p.x : role == 1 ? p.y : role == 2 ? p.zz : p.zzz);
+    }
+    __device__ static __forceinline__ void add_quad(const void* in, size_t ia, size_t ib, void* out, size_t io, int role) { xyzz30_add_quad(in, ia, ib, out, io, role); }
+    __device__ static __forceinline__ Xyzz acc_quad(const Xyzz& acc, const void* in, size_t ib, int role) { return xyzz30_acc_quad(acc, in, ib, role); }
     // the affine image of acc as one record of the window table (canonical coordinates, like every SRS coordinate)
     __device__ static __forceinline__ void table_store(const Xyzz& acc, void* table, size_t idx) {
         Aff30 a;
@@ -97,7 +107,7 @@ struct CvG2 {
     typedef zkhost::Fq2 HostF;
     static constexpr size_t kAffBytes = 192, kXyzzBytes = 384, kJacBytes = 288;
     static constexpr bool kEndo = false;
-    static constexpr bool kQuad = false;
+    static constexpr bool kQuad = true;
     __device__ static __forceinline__ Aff aff_load(const void* b, size_t i) { return aff2_load(b, i); }
     __device__ static __forceinline__ Xyzz load(const void* b, size_t i) { return xyzz2_load(b, i); }
     __device__ static __forceinline__ void store(void* b, size_t i, const Xyzz& p) { xyzz2_store(b, i, p); }
@@ -106,6 +116,15 @@ struct CvG2 {
     __device__ static __forceinline__ void madd(Xyzz& acc, const Aff& p, bool neg) { xyzz2_madd(acc, p, neg); }
     __device__ static __forceinline__ Xyzz add(const Xyzz& a, const Xyzz& b) { return xyzz2_add(a, b); }
     __device__ static __forceinline__ Xyzz dbl(const Xyzz& a) { return xyzz2_dbl(a); }
+    __device__ static __forceinline__ void quad_copy(const void* in, size_t src, void* out, size_t dst, int role) {
+        f2_store_chunks(out, dst, 6 * role, f2_load_chunks(in, src, 6 * role));
+    }
+    __device__ static __forceinline__ void quad_store_inf(void* out, size_t dst, int role) { f2_store_chunks(out, dst, 6 * role, f2_zero()); }
+    __device__ static __forceinline__ void quad_store(void* out, size_t dst, int role, const Xyzz& p) {
+        f2_store_chunks(out, dst, 6 * role, role == 0 ? p.x : role == 1 ? p.y : role == 2 ? p.zz : p.zzz);
+    }
+    __device__ static __forceinline__ void add_quad(const void* in, size_t ia, size_t ib, void* out, size_t io, int role) { xyzz2_add_quad(in, ia, ib, out, io, role); }
+    __device__ static __forceinline__ Xyzz acc_quad(const Xyzz& acc, const void* in, size_t ib, int role) { return xyzz2_acc_quad(acc, in, ib, role); }
     __device__ static __forceinline__ void table_store(const Xyzz& acc, void* table, size_t idx) {
         Fq2x x = f2_zero(), y = f2_zero();
         if (!xyzz2_is_inf(acc)) {
@@ -681,6 +700,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const uint2* __restrict__ oc, si
 
 // the same with one bucket per QUAD of lanes (small and mid-size MSMs: the chain of dependent additions
 // is pure latency, a quad runs each in 4 multiplication rounds instead of 13)
+template <class Cv>
 __global__ void __launch_bounds__(kBlk) k_fixup_quad(const uint2* __restrict__ oc, size_t nb, NarrowRows nr, u32 T,
                                                    size_t tiles_per_w, size_t total, void* __restrict__ buckets,
                                                    const void* __restrict__ heads, const void* __restrict__ tails,
@@ -694,7 +714,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup_quad(const uint2* __restrict__ o
     const uint2 ocg = oc[g];
     const u32 s = ocg.x, c = ocg.y;
     if (c == 0) {
-        f30_store_chunks(buckets, g, 3 * role, f30_zero());
+        Cv::quad_store_inf(buckets, g, role);
         return;
     }
     const u32 e = s + c;
@@ -705,9 +725,9 @@ __global__ void __launch_bounds__(kBlk) k_fixup_quad(const uint2* __restrict__ o
         return;
     }
     const size_t base = w * tiles_per_w;
-    Xyzz30 acc = (s == t0 * T) ? xyzz30_load(heads, base + t0) : xyzz30_load(tails, base + t0);
-    for (u32 t = t0 + 1; t <= t1; t++) acc = xyzz30_acc_quad(acc, heads, base + t, role);
-    f30_store_chunks(buckets, g, 3 * role, role == 0 ? acc.x : role == 1 ? acc.y : role == 2 ? acc.zz : acc.zzz);
+    typename Cv::Xyzz acc = (s == t0 * T) ? Cv::load(heads, base + t0) : Cv::load(tails, base + t0);
+    for (u32 t = t0 + 1; t <= t1; t++) acc = Cv::acc_quad(acc, heads, base + t, role);
+    Cv::quad_store(buckets, g, role, acc);
 }
 
 // one workgroup per long bucket: strided partial sums per lane, then an LDS tree
@@ -772,15 +792,17 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
     Cv::store(out, t, res);
 }
 
-// the same pass with one addition per QUAD of lanes (curve30.cuh: xyzz30_add_quad): for the late passes,
-// which are a single dependent addition of pure latency, this cuts the chain from 13 multiplications to 4
-__device__ __forceinline__ void halve_quad_body(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len, const NarrowRows& nr,
-                                                size_t tq) {
+// the same pass with one addition per QUAD of lanes (curve30.cuh: xyzz30_add_quad; curve30_g2.cuh: xyzz2_add_quad): for the
+// late passes, which are a single dependent addition of pure latency, this cuts the chain from 13 multiplications to 4
+template <class Cv>
+__global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len,
+                                                   NarrowRows nr) {
+    const size_t tq = (size_t)blockIdx.x * kBlk + threadIdx.x;
     const size_t half = len >> 1;
     const size_t per_w = (size_t)(rows + 1) * half;
     const size_t t = tq >> 2;
     const int role = (int)(tq & 3);
-    if (t >= per_w * W) return;  // whole quads leave together (callers hand out multiples of 4)
+    if (t >= per_w * W) return;  // whole quads leave together (kBlk is a multiple of 4)
     const size_t w = t / per_w, rem = t % per_w;
     const int r = (int)(rem / half);
     const size_t j = rem % half;
@@ -791,18 +813,15 @@ __device__ __forceinline__ void halve_quad_body(const void* __restrict__ in, voi
     const size_t ib = in_w + src_row * len + 2 * j + 1;
     const bool b_real = 2 * j + 1 < eff;
     if (r == rows - 1) {  // odd elements of L become the new plane row: lane r copies coordinate r
-        f30_store_chunks(out, t, 3 * role, b_real ? f30_load_chunks(in, ib, 3 * role) : f30_zero());
+        if (b_real) Cv::quad_copy(in, ib, out, t, role);
+        else Cv::quad_store_inf(out, t, role);
         return;
     }
     if (!b_real) {  // a + infinity
-        f30_store_chunks(out, t, 3 * role, f30_load_chunks(in, ib - 1, 3 * role));
+        Cv::quad_copy(in, ib - 1, out, t, role);
         return;
     }
-    xyzz30_add_quad(in, ib - 1, ib, out, t, role);
-}
-__global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len,
-                                                   NarrowRows nr) {
-    halve_quad_body(in, out, W, rows, len, nr, (size_t)blockIdx.x * kBlk + threadIdx.x);
+    Cv::add_quad(in, ib - 1, ib, out, t, role);
 }
 
 // last step on the device: the c reduced points of every window row (planes T_0..T_{c-2}, then T_all)
@@ -833,7 +852,7 @@ __global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void
 // SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine records), one lane per point.
 // With it every window's digit can use the SAME bucket set (the factor 2^{c w} is in the base).
 template <class Cv>
-__global__ void __launch_bounds__(Cv::kQuad ? kBlk : 64) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
+__global__ void __launch_bounds__(Cv::kEndo ? kBlk : 64) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
                                                                        void* __restrict__ table) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1427,7 +1446,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         if (t_last) hipEventRecord(ctx->ev[4], st);
         const NarrowRows nrw{cl.rpi, cl.w0, cl.narrow_from};
         if (Cv::kQuad && total <= fixq_max)
-            hipLaunchKernelGGL(k_fixup_quad, dim3((unsigned)((4 * total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const uint2*)oc,
+            hipLaunchKernelGGL((k_fixup_quad<Cv>), dim3((unsigned)((4 * total + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const uint2*)oc,
                                nb, nrw, cl.T, cl.tiles_per_w, total, bufA, (const void*)heads, (const void*)tails, longs,
                                longs + 1);
         else
@@ -1444,7 +1463,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         while (len > 1) {
             size_t threads = cl.rows * (size_t)(rows + 1) * (len >> 1);
             if (Cv::kQuad && threads <= quad_max)  // too few additions to fill the chip: spend four lanes on each
-                hipLaunchKernelGGL(k_halve_quad, dim3((unsigned)((4 * threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
+                hipLaunchKernelGGL((k_halve_quad<Cv>), dim3((unsigned)((4 * threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
                                    (int)cl.rows, rows, len, nrw);
             else
                 hipLaunchKernelGGL((k_halve<Cv>), dim3((unsigned)((threads + kBlk - 1) / kBlk)), dim3(kBlk), 0, st, (const void*)in, out,
@@ -1742,7 +1761,7 @@ int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t 
 static int msm_pick_window_full_g2(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg <= 12 ? lg + 2 : (lg <= 17 ? 15 : lg - 2);
+    int c = lg <= 11 ? 13 : (lg <= 13 ? 15 : 16);  // 16 bits = exactly 16 windows: the optimum from 2^14 to 2^18 points
     c += (int)tuning().msm_table_dc;
     return std::max(4, std::min(20, c));
 }
