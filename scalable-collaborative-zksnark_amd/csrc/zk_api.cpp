@@ -194,7 +194,6 @@ void zk_ctx_destroy(zk_ctx* ctx) {
         if (e) hipEventDestroy(e);
     zk::msm_lanes_destroy(ctx);
     if (ctx->ev_async_in) hipEventDestroy(ctx->ev_async_in);
-    for (auto& pb : ctx->pin_free) hipHostFree(pb.second);
     zk::msm_host_pool_destroy(ctx);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

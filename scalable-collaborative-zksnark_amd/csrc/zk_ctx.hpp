@@ -50,12 +50,16 @@ struct zk_ctx {
         hipEvent_t ev_fork = nullptr, ev_join[kAux] = {}, ev_part[kParts] = {};
         std::vector<hipEvent_t> ev_cls;  // completion event per MSM window class of a batch
         bool ready = false;
+        // async lanes: growable arenas and pinned staging of their own (kept between jobs, like the ctx's scratch), and
+        // whether a job currently owns the lane
+        Arena mem[10];
+        void* pinned = nullptr;
+        size_t pinned_cap = 0;
+        bool busy = false;
     };
-    static constexpr int kLanes = 3;
+    static constexpr int kLanes = 4;  // lane 0 + up to three asynchronous jobs in flight
     MsmLane lanes[kLanes];
-    unsigned async_seq = 0;           // jobs issued so far (lane = 1 + seq % 2)
     hipEvent_t ev_async_in = nullptr;  // ctx stream -> job stream: the scalars of a job are produced on the ctx stream
-    std::vector<std::pair<size_t, void*>> pin_free;  // pinned staging blocks of finished async jobs
     void* host_pool = nullptr;       // worker threads for the per-item host chains (zk_msm.hip)
     // zk_malloc / zk_free block recycling (zk_api.cpp)
     std::unordered_map<size_t, std::vector<void*>> pool_free;

@@ -1110,16 +1110,9 @@ struct MsmRun {
 };
 
 static void msm_release(zk_ctx* ctx, MsmRun& run) {
-    if (!run.own_mem) return;
-    for (void*& b : run.buf)
-        if (b) {
-            zk_free(ctx, b);
-            b = nullptr;
-        }
-    if (run.hpin) {
-        ctx->pin_free.emplace_back(run.pinned_bytes, (void*)run.hpin);
-        run.hpin = nullptr;
-    }
+    if (!run.own_mem || run.lane <= 0) return;
+    ctx->lanes[run.lane].busy = false;  // (the lane keeps its arenas for the next job)
+    run.lane = -1;
 }
 
 static int msm_lane_prepare(zk_ctx* ctx, int lane) {
@@ -1147,6 +1140,9 @@ void msm_lanes_destroy(zk_ctx* ctx) {
             if (e) hipEventDestroy(e);
         for (auto& e : L.ev_cls)
             if (e) hipEventDestroy(e);
+        for (auto& a : L.mem)
+            if (a.p) hipFree(a.p);
+        if (L.pinned) hipHostFree(L.pinned);
         L = zk_ctx::MsmLane();
     }
 }
@@ -1156,12 +1152,6 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
     const MsmItem* items = run.items.data();
     const size_t count = run.count;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
-    {
-        const int rc = msm_lane_prepare(ctx, run.lane);
-        if (rc) return rc;
-    }
-    zk_ctx::MsmLane& L = ctx->lanes[run.lane];
-    const bool timers = run.lane == 0;
     std::vector<MsmClass>& classes = run.classes;
     const Tuning& tn = tuning();
     const u32 T_env = (u32)tn.msm_tile;
@@ -1327,29 +1317,61 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
     void** buf = run.buf;
     run.pinned_bytes = pinned_bytes;
     if (run.own_mem) {
-        for (int i = 0; i < 10; i++) {
-            const int rc = zk_malloc(ctx, std::max<size_t>(need[i], 256), &buf[i]);
-            if (rc) {
-                msm_release(ctx, run);
-                return rc;
-            }
+        // an asynchronous job takes a free lane: the one whose arenas already hold the job with the least slack, else the
+        // roomiest one (its arenas grow once and stay: a prover issues the same batches proof after proof)
+        int pick = -1;
+        size_t pick_cap = 0;
+        bool pick_fits = false;
+        for (int l = 1; l < zk_ctx::kLanes; l++) {
+            const zk_ctx::MsmLane& cand = ctx->lanes[l];
+            if (cand.busy) continue;
+            size_t cap = 0;
+            bool fits = cand.pinned_cap >= pinned_bytes;
+            for (int i = 0; i < 10; i++) cap += cand.mem[i].cap, fits = fits && cand.mem[i].cap >= need[i];
+            const bool better = pick < 0 || (fits && !pick_fits) || (fits == pick_fits && (fits ? cap < pick_cap : cap > pick_cap));
+            if (better) pick = l, pick_cap = cap, pick_fits = fits;
         }
-        for (size_t i = 0; i < ctx->pin_free.size() && !run.hpin; i++)
-            if (ctx->pin_free[i].first >= pinned_bytes) {
-                run.hpin = (char*)ctx->pin_free[i].second;
-                run.pinned_bytes = ctx->pin_free[i].first;
-                ctx->pin_free.erase(ctx->pin_free.begin() + i);
+        if (pick < 0) return fail(ctx, ZK_ERR_INVALID, "too many asynchronous MSM jobs in flight (at most %d): wait for one first", zk_ctx::kLanes - 1);
+        run.lane = pick;
+        {
+            const int rc = msm_lane_prepare(ctx, run.lane);
+            if (rc) return rc;
+        }
+        zk_ctx::MsmLane& LL = ctx->lanes[run.lane];
+        for (int i = 0; i < 10; i++) {
+            zk_ctx::Arena& a = LL.mem[i];
+            if (a.cap < need[i] || !a.p) {
+                if (a.p) hipFree(a.p);  // (the lane is idle: nothing can still use it)
+                a.p = nullptr, a.cap = 0;
+                const size_t want = std::max<size_t>(need[i], 256);
+                const hipError_t e = device_alloc(ctx, &a.p, want);
+                if (e != hipSuccess) {
+                    a.p = nullptr;
+                    return hip_fail(ctx, e, "hipMalloc(msm job arena)");
+                }
+                a.cap = want;
             }
-        if (!run.hpin) {
-            run.pinned_bytes = std::max<size_t>(pinned_bytes, 4096);
-            const hipError_t e = hipHostMalloc((void**)&run.hpin, run.pinned_bytes, hipHostMallocDefault);
+            buf[i] = a.p;
+        }
+        if (LL.pinned_cap < pinned_bytes || !LL.pinned) {
+            if (LL.pinned) hipHostFree(LL.pinned);
+            LL.pinned = nullptr, LL.pinned_cap = 0;
+            const size_t want = std::max<size_t>(pinned_bytes, 4096);
+            const hipError_t e = hipHostMalloc(&LL.pinned, want, hipHostMallocDefault);
             if (e != hipSuccess) {
-                run.hpin = nullptr;
-                msm_release(ctx, run);
+                LL.pinned = nullptr;
                 return hip_fail(ctx, e, "hipHostMalloc(msm job)");
             }
+            LL.pinned_cap = want;
         }
+        run.hpin = (char*)LL.pinned;
+        LL.busy = true;
     } else {
+        run.lane = 0;
+        {
+            const int rc = msm_lane_prepare(ctx, 0);
+            if (rc) return rc;
+        }
         for (int i = 0; i < 10; i++) {
             buf[i] = scratch(ctx, slot[i], need[i]);
             if (!buf[i]) return ZK_ERR_OOM;
@@ -1357,6 +1379,8 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         run.hpin = (char*)pinned(ctx, pinned_bytes);
         if (!run.hpin) return ZK_ERR_OOM;
     }
+    zk_ctx::MsmLane& L = ctx->lanes[run.lane];
+    const bool timers = run.lane == 0;
     char* hpin = run.hpin;
     if (run.lane != 0) {  // the scalars are produced by work on the ctx stream
         hipEventRecord(ctx->ev_async_in, ctx->stream);
@@ -1592,8 +1616,7 @@ int msm_g1_batch_async(zk_ctx* ctx, const MsmItem* items, size_t count, zk_msm_j
     zk_msm_job* j = new zk_msm_job();
     j->run.count = count;
     j->run.items.assign(items, items + count);
-    j->run.lane = 1 + (int)(ctx->async_seq++ & 1u);
-    j->run.own_mem = true;
+    j->run.own_mem = true;  // (the lane is picked inside msm_enqueue, once the job's memory needs are known)
     const int rc = msm_enqueue<CvG1>(ctx, j->run);
     if (rc) {
         delete j;
@@ -1606,7 +1629,7 @@ int msm_job_wait(zk_ctx* ctx, zk_msm_job* job, uint64_t* h_out) {
     if (!job) return fail(ctx, ZK_ERR_INVALID, "null job");
     int rc;
     if (!h_out && job->run.count) {
-        hipStreamSynchronize(ctx->lanes[job->run.lane].main);
+        if (job->run.lane > 0) hipStreamSynchronize(ctx->lanes[job->run.lane].main);
         msm_release(ctx, job->run);
         rc = fail(ctx, ZK_ERR_INVALID, "null argument");
     } else {

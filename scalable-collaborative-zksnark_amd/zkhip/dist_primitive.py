@@ -69,6 +69,23 @@ class MsmQueue:
         self.keep = []
         return self.res
 
+    # the same in two halves: start() enqueues the pass on the GPU and returns (zk_msm_g1_batch_async), finish() collects the
+    # points (zk_msm_wait).  Between the two the caller can enqueue the NEXT step's kernels and do its own host work -- the
+    # exchange closures of a step are host arithmetic on a few hundred points, during which the GPU would otherwise idle.
+    def start(self):
+        self.job = None
+        if self.lens and hasattr(self.be, "msm_g1_batch_async"):
+            self.job = self.be.msm_g1_batch_async(self.srs, self.bufs, self.lens)
+        else:
+            self.run()
+
+    def finish(self):
+        if getattr(self, "job", None) is not None:
+            self.res = self.job.wait()
+            self.job = None
+            self.keep = []
+        return self.res
+
 
 def d_msm_q(be, q: MsmQueue, bases: Sequence, scalars: Sequence, lens: Sequence[int], pp: PackedSharingParams, net: Net, prescale: bool = True):
     """d_msm (dmsm.rs:9-43) with its local MSMs queued; -> closure returning [batch, 18]"""

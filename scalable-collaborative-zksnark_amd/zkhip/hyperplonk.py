@@ -111,6 +111,17 @@ def _at(buf, byte_off):
 
 def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top):
     """step 2 of dhyperplonk (:262-514) == the body of dpermcheck (:992-1245)"""
+    q, finalize = _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top)
+    q.run()
+    return finalize()
+
+
+def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top):
+    """
+    the step up to (not including) its one batched MSM pass: every sumcheck / fold / open-round kernel has run, every MSM of
+    the step sits in the returned queue.  -> (queue, finalize): run (or start / finish) the queue, then finalize() performs the
+    exchanges of the MSM results and returns (wiring_proofs, wiring_commits, wiring_opens) in the reference's order.
+    """
     T, L = pk.tables, pk.lens
     l, npar = pp.l, net.n_parties
     M = 1 << n
@@ -187,16 +198,18 @@ def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s
         top_proofs.append(dp.sumcheck_product(be, eq_top, d1, len(lv1x), chs))
         top_proofs.append(dp.sumcheck_product(be, eq_top, d0, len(lvx0), chs))
         top_proofs.append(dp.sumcheck_product(be, d0, dd1, len(lvx0), chs))
-    q.run()
-    wiring_opens += f_copen()                 # 2.d
-    wiring_commits += list(f_dcommit())       # 2.b, then :363-380
-    wiring_opens += f_dopen()
-    if top is not None:
-        for fc, fo in zip(f_top_commits, f_top_opens()):  # (commit, open) per table, in the reference's order
-            wiring_commits.append(fc())
-            wiring_opens.append(fo)
-        wiring_proofs += top_proofs
-    return wiring_proofs, wiring_commits, wiring_opens
+    def finalize():
+        wiring_opens.extend(f_copen())                 # 2.d
+        wiring_commits.extend(list(f_dcommit()))       # 2.b, then :363-380
+        wiring_opens.extend(f_dopen())
+        if top is not None:
+            for fc, fo in zip(f_top_commits, f_top_opens()):  # (commit, open) per table, in the reference's order
+                wiring_commits.append(fc())
+                wiring_opens.append(fo)
+            wiring_proofs.extend(top_proofs)
+        return wiring_proofs, wiring_commits, wiring_opens
+
+    return q, finalize
 
 
 def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be, net: Net, seed: int = 1, data_parallel: bool = False):
@@ -224,11 +237,20 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     q = dp.MsmQueue(be)  # both commit families in one batched MSM pass
     f_c = dp.c_commit_q(be, q, cc, [T[x] for x in names_c], [L[x] for x in names_c], pp, net)
     f_d = dp.d_commit_many_q(be, q, dc, [T[x] for x in names_d], [L[x] for x in names_d], net)
-    q.run()
-    for name, cm in zip(names_c, f_c()):
-        com[name] = cm
-    for name, cm in zip(names_d, f_d()):
-        com[name] = cm
+    # The MSM pass of a step is STARTED here and collected one step later (MsmQueue.start / finish): nothing consumes a
+    # commitment before the proof is assembled (challenges are pre-sampled, :159-186), and the host part of a step -- the
+    # exchanges of its results and the 8-term point combinations -- then runs while the GPU works on the next step's pass.
+    # The timer labels keep the reference's names; with the overlap "Commit" / "Wire identity" / "Open" each cover the
+    # enqueue of their own pass and the collection of the previous one, only "Distributed HyperPlonk" is a sum.
+    q.start()
+
+    def finish_commit():
+        q.finish()
+        for name, cm in zip(names_c, f_c()):
+            com[name] = cm
+        for name, cm in zip(names_d, f_d()):
+            com[name] = cm
+
     tm.end()
 
     # Step 3: gate identity (:223-260)
@@ -243,7 +265,9 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
 
     # Step 2: wiring identity (shared with dpermcheck)
     tm.start("Wire identity")
-    wiring_proofs, wiring_commits, wiring_opens = _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top)
+    q_w, finalize_wiring = _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top)
+    q_w.start()
+    finish_commit()  # (host: exchange + point combinations of step 1, beside the wiring pass on the GPU)
     tm.end()
 
     # Open (:517-553)
@@ -252,7 +276,10 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     q = dp.MsmQueue(be)
     f_c = dp.c_open_many_q(be, q, cc, [T[x] for x in names_c], [L[x] for x in names_c], [pk.challenge] * 3, pp, net)
     f_d = dp.d_open_many_q(be, q, dc, [T[x] for x in names_d], [L[x] for x in names_d], [pk.challenge] * 3, net)
-    q.run()
+    q.start()
+    q_w.finish()
+    wiring_proofs, wiring_commits, wiring_opens = finalize_wiring()
+    q.finish()
     for name, op in zip(names_c, f_c()):
         gate_commitments.append((com[name], op))
     for name, op in zip(names_d, f_d()):
