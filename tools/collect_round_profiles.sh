@@ -1,0 +1,19 @@
+set -u
+T=r03g
+python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+tools/profile_bench.sh $T > gpurun_out/${T}_profile.log 2>&1
+tools/profile_valu.sh $T >> gpurun_out/${T}_profile.log 2>&1
+tools/sc_prof.sh $T 20 >> gpurun_out/${T}_profile.log 2>&1
+tools/sc_pmc.sh $T 24 >> gpurun_out/${T}_profile.log 2>&1
+tools/sc_pmc.sh $T 26 >> gpurun_out/${T}_profile.log 2>&1
+python tools/sc_time.py 12 16 18 20 22 24 26 > gpurun_out/${T}_sc_sizes.txt 2>&1
+python tools/msm_time.py 12 14 16 18 20 22 24 > gpurun_out/${T}_msm_sizes.txt 2>&1
+tools/trace_one_msm_table.sh 20 > gpurun_out/${T}_msm_2e20_dispatch_timeline.txt 2>&1
+for n in 12 16 20 24; do python tools/hyperplonk_bench.py --n $n --reps 3 | tail -1; done > gpurun_out/${T}_e2e.jsonl 2>&1
+for n in 12 16 20; do python tools/hyperplonk_bench.py --n $n --party-threads | tail -1; done > gpurun_out/${T}_e2e_party_threads.jsonl 2>&1
+python tools/g2_time.py 17 0 > gpurun_out/${T}_g2.txt 2>&1
+python tools/cpermcheck_time.py 20 3 > gpurun_out/${T}_cpermcheck.jsonl 2>&1
+python tools/sc_batch_time.py 18 > gpurun_out/${T}_sc_batch.txt 2>&1
+export ZK_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 ZK_BENCH_DEADLINE_S=600
+for N in 2 8; do python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29610+N)) bench.py --gpus $N --steps 3 --warmup 1 --no-cpu 2>gpurun_out/${T}_gloo$N.err | tail -1; done > gpurun_out/${T}_bench_gloo_ranks_sharing_one_gpu.jsonl
+tail -3 gpurun_out/${T}_e2e.jsonl; cat gpurun_out/${T}_g2.txt
