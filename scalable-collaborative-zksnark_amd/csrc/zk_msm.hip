@@ -1130,6 +1130,10 @@ static int msm_lane_prepare(zk_ctx* ctx, int lane) {
 void msm_lanes_destroy(zk_ctx* ctx) {
     for (int i = 0; i < zk_ctx::kLanes; i++) {
         zk_ctx::MsmLane& L = ctx->lanes[i];
+        // a job nobody waited for may still be running on this lane: drain it before its arenas go
+        if (L.main && i > 0) hipStreamSynchronize(L.main);
+        for (auto& s2 : L.aux)
+            if (s2) hipStreamSynchronize(s2);
         if (i > 0 && L.main) hipStreamDestroy(L.main);
         for (auto& s2 : L.aux)
             if (s2) hipStreamDestroy(s2);
