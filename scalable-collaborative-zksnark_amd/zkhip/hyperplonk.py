@@ -50,13 +50,16 @@ class PackedProvingParameters:
     d_commitment: List = None  # levels 0..n-1          (new_random, dpoly_comm.rs:220-233)
 
     @staticmethod
-    def new(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = None, window_tables: bool = True) -> "PackedProvingParameters":
+    def new(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = None, window_tables: bool = True, table_max_log2: int = 24) -> "PackedProvingParameters":
         """
         dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy().  chal_seed: the
         challenges are public values every party shares (the reference's local mode clones ONE parameter set
         for all parties, mpc-net/src/multi.rs:344); pass the same chal_seed to parties with different table seeds.
-        window_tables: build the MSM window table of every SRS level up to 2^22 points (zk_srs_precompute: setup work like
-        generating the level, 14-16 x its memory; results are bit-identical with and without).
+        window_tables: build the MSM window table of every SRS level up to 2^table_max_log2 points (zk_srs_precompute: setup work
+        like generating the level, 13-16 x its memory; results are bit-identical with and without).  The tables only take
+        memory the proof does not need: a level is skipped when building its table would leave less than 40 % of the device
+        free (the MSM arenas of an n = 24 proof want ~80 GB); at n = 24 on a 288-GB MI355X the levels up to 2^24 points get
+        theirs (n = 24 proof 0.99 -> 0.93 s), the 2^25 / 2^26-point levels of the c-SRS run table-less.
         """
         l, npar = pp.l, pp.n
         M = 1 << n
@@ -90,7 +93,11 @@ class PackedProvingParameters:
         if window_tables:
             # largest levels last: if the device runs out of memory the levels without a table simply use the table-less path
             for lv in sorted(pk.c_commitment + pk.d_commitment, key=len):
-                if hasattr(lv, "precompute") and 64 <= len(lv) <= (1 << 22):
+                if hasattr(lv, "precompute") and 64 <= len(lv) <= (1 << table_max_log2):
+                    if hasattr(be, "mem_info") and len(lv) > (1 << 22):
+                        free, total = be.mem_info()
+                        if free - 16 * 96 * len(lv) < 0.4 * total:
+                            break
                     try:
                         lv.precompute(0)
                     except Exception as e:

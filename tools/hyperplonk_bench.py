@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--net", choices=("rccl", "torch"), default="rccl", help="multi-rank exchanges: the C-ABI communicator (RCCL inside the ctx, device-resident) or torch.distributed")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-window-tables", action="store_true", help="MSMs without the precomputed SRS window tables (zk_srs_precompute)")
+    ap.add_argument("--table-max-log2", type=int, default=24, help="build MSM window tables for SRS levels up to 2^k points (memory: ~14 x 96 B per point)")
     ap.add_argument("--party-threads", action="store_true", help="all 8 parties as threads of this process, one ctx each on GPU 0 (real 8-party exchanges and point combinations, one GPU doing eight GPUs' work)")
     args = ap.parse_args()
     if args.party_threads:
@@ -145,7 +146,7 @@ def main():
 
         net = LeaderEchoNet(pp.n)
     t0 = time.perf_counter()
-    pk = PackedProvingParameters.new(args.n, pp, ctx, seed=0x5CA1AB1E % 1000 + rank, chal_seed=0xC4A1, window_tables=not args.no_window_tables)  # challenges are shared public values
+    pk = PackedProvingParameters.new(args.n, pp, ctx, seed=0x5CA1AB1E % 1000 + rank, chal_seed=0xC4A1, window_tables=not args.no_window_tables, table_max_log2=args.table_max_log2)  # challenges are shared public values
     setup = time.perf_counter() - t0
     best, digests, res = None, [], None
     for r in range(args.reps + 1):
