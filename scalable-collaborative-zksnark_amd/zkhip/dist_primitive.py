@@ -43,6 +43,22 @@ def pss2ss(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
 # ---------------------------------------------------------------------------------------
 # d_msm (dmsm.rs:9-43)
 # ---------------------------------------------------------------------------------------
+DEDUP_MSM = True  # default of MsmQueue(dedup=...): tools switch it off to measure what the sharing is worth
+
+
+def _addr(buf) -> int:
+    """identity of a device buffer / view / raw address (the key of MsmQueue's duplicate detection)"""
+    if isinstance(buf, int):
+        return buf
+    if hasattr(buf, "ptr"):
+        return int(buf.ptr)
+    if hasattr(buf, "data_ptr"):
+        return int(buf.data_ptr())
+    if hasattr(buf, "a"):  # the numpy-backed stand-in of the CPU tests
+        return int(buf.a.__array_interface__["data"][0])
+    return id(buf)
+
+
 class MsmQueue:
     """
     Collects the local MSMs of SEVERAL protocol calls and runs them in ONE pipeline pass (zk_msm_g1_batch).
@@ -53,16 +69,38 @@ class MsmQueue:
     once `run()` has been called; every party must call them, `run()` and the closures in the same order.
     """
 
-    def __init__(self, be):
+    def __init__(self, be, dedup: bool = None):
         self.be, self.srs, self.bufs, self.lens, self.keep, self.res = be, [], [], [], [], None
+        # identical items -- same SRS level, same scalar buffer, same length -- are computed ONCE (the two opens of V in step 2.d,
+        # dhyperplonk.rs:307-320, commit the same first quotient q_0 = V_hi - V_lo: it does not depend on the opening point)
+        self.dedup = DEDUP_MSM if dedup is None else dedup
+        self.index, self.scaled = {}, {}
 
     def add(self, srs_list, bufs, lens, keep=()):
-        a = len(self.lens)
-        self.srs += list(srs_list)
-        self.bufs += list(bufs)
-        self.lens += [int(x) for x in lens]
+        """-> indices of the items' results in `res` (an index array: `q.res[idx]`)"""
+        idx = []
+        for s_, b_, n_ in zip(srs_list, bufs, lens):
+            key = (getattr(s_, "h", None) or id(s_), _addr(b_), int(n_))
+            j = self.index.get(key) if self.dedup else None
+            if j is None:
+                j = len(self.lens)
+                self.srs.append(s_)
+                self.bufs.append(b_)
+                self.lens.append(int(n_))
+                self.index[key] = j
+            idx.append(j)
         self.keep += list(keep)  # buffers that must outlive the batched pass
-        return slice(a, len(self.lens))
+        return np.array(idx, dtype=np.int64)
+
+    def scale(self, buf, lam_m, n: int):
+        """lambda * buf for the pre-scaled d_msm, once per distinct scalar buffer"""
+        key = (_addr(buf), int(n), bytes(np.asarray(lam_m, dtype=np.uint64)))
+        out = self.scaled.get(key) if self.dedup else None
+        if out is None:
+            out = self.be.fr_scale(buf, lam_m, n)
+            self.scaled[key] = out
+            self.keep.append(out)
+        return out
 
     def run(self):
         self.res = self.be.msm_g1_batch(self.srs, self.bufs, self.lens) if self.lens else np.zeros((0, 18), dtype=np.uint64)
@@ -107,8 +145,8 @@ def d_msm_q(be, q: MsmQueue, bases: Sequence, scalars: Sequence, lens: Sequence[
     lam = sum(pp.unpack2_matrix[j][p] for j in range(pp.l)) % R_MOD
     c_p = sum(pp.pack_matrix[p][j] for j in range(pp.l)) % R_MOD
     lam_m = fr_mont(lam)
-    scaled = [be.fr_scale(s, lam_m, m) for s, m in zip(scalars, lens)]
-    sl = q.add(bases, scaled, lens, keep=scaled)
+    scaled = [q.scale(s, lam_m, m) for s, m in zip(scalars, lens)]
+    sl = q.add(bases, scaled, lens)
 
     def fin():
         gathered = net.all_gather(q.res[sl])
@@ -411,14 +449,24 @@ def commit(be, powers_of_g, peval, length: int) -> np.ndarray:
     return be.msm_g1(powers_of_g[level], peval, length)
 
 
-def _open_msm_items(powers_of_g, q, length: int):
+def _first_quotient_sources(pevals, lens, qbufs):
+    """opens of the SAME table share their first quotient q_0 = hi - lo (it does not depend on the point): for every open the
+    buffer whose first len/2 elements serve as its q_0 -- the first open's of that table.  With MsmQueue's duplicate
+    detection the commitment of q_0 is then one MSM for all of them."""
+    first, out = {}, []
+    for pe, length, qb in zip(pevals, lens, qbufs):
+        out.append(first.setdefault((_addr(pe), int(length)), qb))
+    return out
+
+
+def _open_msm_items(powers_of_g, q, length: int, q0=None):
     """the n commitments of one open (:318-321) as MSM items over the quotient buffer q: (srs list, scalar views, lens)"""
     n = length.bit_length() - 1
     srs, bufs, lens, off, m = [], [], [], 0, length
-    for _ in range(n):
+    for i in range(n):
         h = m // 2
         srs.append(powers_of_g[h.bit_length() - 1])
-        bufs.append(q.at(32 * off))
+        bufs.append((q0 if (i == 0 and q0 is not None) else q).at(32 * off))
         lens.append(h)
         off += h
         m = h
@@ -430,8 +478,9 @@ def open_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[i
     vals, cuts = [], []
     pts = [np.asarray(pt, dtype=np.uint64).reshape(-1, 4) for pt in points]
     rounds = _sc_batch(be, [("open", pe, length, pt[: length.bit_length() - 1]) for pe, length, pt in zip(pevals, lens, pts)])  # :309-323, all items at once
-    for (qb, v), length in zip(rounds, lens):
-        s_, b_, l_ = _open_msm_items(powers_of_g, qb, length)
+    q0s = _first_quotient_sources(pevals, lens, [qb for qb, _ in rounds])
+    for (qb, v), length, q0 in zip(rounds, lens, q0s):
+        s_, b_, l_ = _open_msm_items(powers_of_g, qb, length, q0)
         vals.append(v)
         cuts.append(q.add(s_, b_, l_, keep=[qb]))  # the q buffers must outlive the batched MSM
     def fin():
@@ -576,14 +625,15 @@ def c_open_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence
     pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
     vals, bufs, ms, cuts = [], [], [], [0]
     rounds = _sc_batch(be, [("open", pe, length, pt[: length.bit_length() - 1]) for pe, length, pt in zip(pevals, lens, pts)])  # :418-432
-    for (qb, value), length in zip(rounds, lens):
+    q0s = _first_quotient_sources(pevals, lens, [qb for qb, _ in rounds])
+    for (qb, value), length, q0 in zip(rounds, lens, q0s):
         n = length.bit_length() - 1
         q.keep.append(qb)
         vals.append(value)
         off, m = 0, length
-        for _ in range(n):
+        for r_ in range(n):
             h = m // 2
-            bufs.append(qb.at(32 * off))
+            bufs.append((q0 if r_ == 0 else qb).at(32 * off))
             ms.append(h)
             off += h
             m = h

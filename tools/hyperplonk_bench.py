@@ -107,8 +107,13 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-window-tables", action="store_true", help="MSMs without the precomputed SRS window tables (zk_srs_precompute)")
     ap.add_argument("--table-max-log2", type=int, default=24, help="build MSM window tables for SRS levels up to 2^k points (memory: ~14 x 96 B per point)")
+    ap.add_argument("--no-dedup", action="store_true", help="compute identical MSM items of a step separately (the two opens of V share their first quotient's commitment by default)")
     ap.add_argument("--party-threads", action="store_true", help="all 8 parties as threads of this process, one ctx each on GPU 0 (real 8-party exchanges and point combinations, one GPU doing eight GPUs' work)")
     args = ap.parse_args()
+    if args.no_dedup:
+        from zkhip import dist_primitive as _dp
+
+        _dp.DEDUP_MSM = False
     if args.party_threads:
         return party_threads(args)
     import zkhip
