@@ -130,113 +130,95 @@ ZK_F30_SUB(f30_sub4, KQ4)  // a + 4q - b,  b < 4q
 ZK_F30_SUB(f30_sub6, KQ6)  // a + 6q - b,  b < 6q
 ZK_F30_SUB(f30_sub8, KQ8)  // a + 8q - b,  b < 8q
 ZK_F30_SUB(f30_sub12, KQ12)  // a + 12q - b, b < 12q  (the Fq2 formulas of curve30_g2.cuh)
+// ---- column budget of the three multipliers -------------------------------------------------------------------
+// A column of the product scan holds up to 13 limb products a_i b_j and 13 reduction products m_i q_j: 26 x 2^60 would not
+// fit 64 bits, so a column's high part is folded into the next column ("spill": 4 instructions) before it could overflow.
+// WHEN is decided at compile time from an upper bound of the column, in units of 2^50:
+//     a_i b_j < 2^60 = 1024 units;   (2 a_i) a_j < 2^61 = 2048 units;   m_i q_j < 2^30 q_j = at most (q_j >> 20) + 1 units
+// (the limbs of q are constants: together they weigh 6.75 x 2^30, not 13 x 2^30), the carry into a column and the 30 bits kept
+// after a spill are below one unit each.  Counting every product as 2^60 cost 10 spills per multiplication; the weighted budget
+// needs 4.  f30_*_budget_ok() re-run the same schedule with the LARGEST possible limbs in 128-bit arithmetic and are
+// static_assert-ed: no column of any of the three functions can reach 2^64, whatever the (normalised) inputs.
+namespace f30b {
+static constexpr u32 kLim = 16383, kAB = 1024, kDA = 2048;
+__host__ __device__ constexpr u32 mq(int j) { return (Q30::Q(j) >> 20) + 1; }
+__host__ __device__ constexpr bool spill(u32 bnd, u32 units) { return bnd + units > kLim; }
+}  // namespace f30b
+#define ZK_F30_ACC(prod, units)                 \
+    do {                                        \
+        if (f30b::spill(bnd, (units))) {        \
+            nxt += acc >> 30;                   \
+            acc &= Q30::MASK;                   \
+            bnd = 1;                            \
+        }                                       \
+        acc += (prod);                          \
+        bnd += (units);                         \
+    } while (0)
+
 // Montgomery product a*b*2^-390 (mod q) for normalised inputs whose bounds multiply to <= 256 q^2;
-// the result is normalised and < 2q.  Product scanning; a column holds at most 15 limb products
-// (15 * (2^30-1)^2 + carry < 2^64) before its high part is folded into the next column.
+// the result is normalised and < 2q.  Product scanning, one 64-bit column accumulator (see the budget above).
 __device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
     u32 m[13];
     Fq30 t;
     u64 acc = 0;
+    u32 bnd = 0;
 #pragma unroll
     for (int k = 0; k < 25; k++) {
-        int cnt = 0;
         u64 nxt = 0;
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (j >= 0 && j < 13) {
-                acc += (u64)a.l[i] * b.l[j];
-                cnt++;
-            }
+            if (j >= 0 && j < 13) ZK_F30_ACC((u64)a.l[i] * b.l[j], f30b::kAB);
         }
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (i < k && j >= 1 && j < 13) {
-                if (cnt == 15) {
-                    nxt += acc >> 30;
-                    acc &= Q30::MASK;
-                    cnt = 0;
-                }
-                acc += (u64)m[i] * Q30::Q(j);
-                cnt++;
-            }
+            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)m[i] * Q30::Q(j), f30b::mq(j));
         }
         if (k < 13) {
-            if (cnt >= 15) {
-                nxt += acc >> 30;
-                acc &= Q30::MASK;
-            }
-            const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;
+            const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;  // (a spill leaves the low 30 bits of the column in place)
             m[k] = mk;
-            acc += (u64)mk * Q30::Q(0);
+            ZK_F30_ACC((u64)mk * Q30::Q(0), f30b::mq(0));
         } else {
             t.l[k - 13] = (u32)acc & Q30::MASK;
         }
         acc = (acc >> 30) + nxt;
+        bnd = 1;
     }
     t.l[12] = (u32)acc;
     return t;
 }
-// Montgomery square: the 78 off-diagonal products are taken once against the doubled limb (2*a_i < 2^31,
-// product < 2^61 = two "units" of 2^60); a column is folded before it could exceed 15 units.
+// Montgomery square: the 78 off-diagonal products are taken once against the doubled limb (2*a_i < 2^31, product < 2^61).
 __device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
     u32 m[13], d[13];
     Fq30 t;
 #pragma unroll
     for (int i = 0; i < 13; i++) d[i] = a.l[i] << 1;
     u64 acc = 0;
+    u32 bnd = 0;
 #pragma unroll
     for (int k = 0; k < 25; k++) {
-        int units = 0;
         u64 nxt = 0;
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (j > i && j < 13) {
-                if (units + 2 > 15) {
-                    nxt += acc >> 30;
-                    acc &= Q30::MASK;
-                    units = 0;
-                }
-                acc += (u64)d[i] * a.l[j];
-                units += 2;
-            }
+            if (j > i && j < 13) ZK_F30_ACC((u64)d[i] * a.l[j], f30b::kDA);
         }
-        if ((k & 1) == 0) {
-            if (units + 1 > 15) {
-                nxt += acc >> 30;
-                acc &= Q30::MASK;
-                units = 0;
-            }
-            acc += (u64)a.l[k / 2] * a.l[k / 2];
-            units++;
-        }
+        if ((k & 1) == 0) ZK_F30_ACC((u64)a.l[k / 2] * a.l[k / 2], f30b::kAB);
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (i < k && j >= 1 && j < 13) {
-                if (units + 1 > 15) {
-                    nxt += acc >> 30;
-                    acc &= Q30::MASK;
-                    units = 0;
-                }
-                acc += (u64)m[i] * Q30::Q(j);
-                units++;
-            }
+            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)m[i] * Q30::Q(j), f30b::mq(j));
         }
         if (k < 13) {
-            if (units + 1 > 15) {
-                nxt += acc >> 30;
-                acc &= Q30::MASK;
-            }
             const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;
             m[k] = mk;
-            acc += (u64)mk * Q30::Q(0);
+            ZK_F30_ACC((u64)mk * Q30::Q(0), f30b::mq(0));
         } else {
             t.l[k - 13] = (u32)acc & Q30::MASK;
         }
         acc = (acc >> 30) + nxt;
+        bnd = 1;
     }
     t.l[12] = (u32)acc;
     return t;
@@ -250,65 +232,82 @@ __device__ __forceinline__ Fq30 f30_mul2add(const Fq30& a, const Fq30& b, const 
     u32 m[13];
     Fq30 t;
     u64 acc = 0;
+    u32 bnd = 0;
 #pragma unroll
     for (int k = 0; k < 25; k++) {
-        int units = 0;
         u64 nxt = 0;
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (j >= 0 && j < 13) {
-                if (units + 1 > 15) {
-                    nxt += acc >> 30;
-                    acc &= Q30::MASK;
-                    units = 0;
-                }
-                acc += (u64)a.l[i] * b.l[j];
-                units++;
-            }
+            if (j >= 0 && j < 13) ZK_F30_ACC((u64)a.l[i] * b.l[j], f30b::kAB);
         }
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (j >= 0 && j < 13) {
-                if (units + 1 > 15) {
-                    nxt += acc >> 30;
-                    acc &= Q30::MASK;
-                    units = 0;
-                }
-                acc += (u64)c.l[i] * d.l[j];
-                units++;
-            }
+            if (j >= 0 && j < 13) ZK_F30_ACC((u64)c.l[i] * d.l[j], f30b::kAB);
         }
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (i < k && j >= 1 && j < 13) {
-                if (units + 1 > 15) {
-                    nxt += acc >> 30;
-                    acc &= Q30::MASK;
-                    units = 0;
-                }
-                acc += (u64)m[i] * Q30::Q(j);
-                units++;
-            }
+            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)m[i] * Q30::Q(j), f30b::mq(j));
         }
         if (k < 13) {
-            if (units + 1 > 15) {
-                nxt += acc >> 30;
-                acc &= Q30::MASK;
-            }
             const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;
             m[k] = mk;
-            acc += (u64)mk * Q30::Q(0);
+            ZK_F30_ACC((u64)mk * Q30::Q(0), f30b::mq(0));
         } else {
             t.l[k - 13] = (u32)acc & Q30::MASK;
         }
         acc = (acc >> 30) + nxt;
+        bnd = 1;
     }
     t.l[12] = (u32)acc;
     return t;
 }
+#undef ZK_F30_ACC
+
+// The same three schedules on WORST-CASE limbs (every variable limb 2^30 - 1, doubled limbs 2^31 - 2, every m_i 2^30 - 1), exact
+// 128-bit arithmetic: true iff no column accumulator can reach 2^64.  kind 0: mul, 1: sqr, 2: mul2add.
+namespace f30b {
+typedef unsigned __int128 u128;
+__host__ __device__ constexpr bool budget_ok(int kind) {
+    const u128 L = ((u128)1 << 30) - 1, D = 2 * L, LIM64 = (u128)1 << 64;
+    u128 acc = 0;
+    u32 bnd = 0;
+    for (int k = 0; k < 25; k++) {
+        u128 nxt = 0;
+        // one accumulation step of the schedule: the spill decision of the kernels, the largest product
+        auto step = [&](u128 prod, u32 units) {
+            if (spill(bnd, units)) {
+                nxt += acc >> 30;
+                acc = L;  // the 30 bits kept are at most 2^30 - 1
+                bnd = 1;
+            }
+            acc += prod;
+            bnd += units;
+            return acc < LIM64;
+        };
+        for (int rep = 0; rep < (kind == 2 ? 2 : 1); rep++)
+            for (int i = 0; i < 13; i++) {
+                const int j = k - i;
+                if (kind == 1) {
+                    if (j > i && j < 13 && !step(D * L, kDA)) return false;
+                } else if (j >= 0 && j < 13 && !step(L * L, kAB)) return false;
+            }
+        if (kind == 1 && (k & 1) == 0 && !step(L * L, kAB)) return false;
+        for (int i = 0; i < 13; i++) {
+            const int j = k - i;
+            if (i < k && j >= 1 && j < 13 && !step(L * Q30::Q(j), mq(j))) return false;
+        }
+        if (k < 13 && !step(L * Q30::Q(0), mq(0))) return false;
+        acc = (acc >> 30) + nxt;
+        if (!(acc < ((u128)1 << 50))) return false;  // the carry into a column stays below the one unit it is budgeted with
+        bnd = 1;
+    }
+    return true;
+}
+static_assert(budget_ok(0) && budget_ok(1) && budget_ok(2), "a column of f30_mul / f30_sqr / f30_mul2add could overflow 64 bits");
+}  // namespace f30b
 
 // v - c if v >= c else v, for a normalised constant c given by limb accessor
 #define ZK_F30_CSUB(name, C)                                                                         \

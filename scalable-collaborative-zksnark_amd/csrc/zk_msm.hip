@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restric
 template <class Cv>
 __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict__ items, int rows_per_item,
                                                     const u32* __restrict__ sorted, const uint2* __restrict__ oc_all,
-                                                    const u32* __restrict__ tile_b, size_t ns, u32 nsi, size_t nb, u32 T,
+                                                    const u32* __restrict__ tile_b, size_t ns, u32 nsi, int nsi_shift, size_t nb, u32 T,
                                                     size_t tiles_per_w, size_t total_tiles, void* __restrict__ buckets,
                                                     void* __restrict__ heads, void* __restrict__ tails) {
     const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict
     auto pidx = [&](u32 v) -> size_t {
         v &= 0x7fffffffu;
         if (it.pstride == 0) return v;
-        u32 win = v / nsi;
+        const u32 win = nsi_shift >= 0 ? (v >> nsi_shift) : v / nsi;  // (rows of 2^k points: a shift instead of a ~25-instruction division)
         return (size_t)win * it.pstride + (v - win * nsi);
     };
     const uint2* oc = oc_all + w * nb;
@@ -1469,7 +1469,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         if (cl.part > 0) hipStreamWaitEvent(st, L.ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
         hipLaunchKernelGGL((k_accum_tiles<Cv>), dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const uint2*)oc, (const u32*)tile_b, cl.row_len,
-                           (u32)ns, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
+                           (u32)ns, ((ns & (ns - 1)) == 0) ? (int)__builtin_ctzll(ns) : -1, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
         if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(L.ev_part[cl.part % zk_ctx::kParts], st);
         if (t_last) hipEventRecord(ctx->ev[4], st);
         const NarrowRows nrw{cl.rpi, cl.w0, cl.narrow_from};
