@@ -1,5 +1,5 @@
 set -u
-T=r03g
+T=${1:-r03g}
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 tools/profile_bench.sh $T > gpurun_out/${T}_profile.log 2>&1
 tools/profile_valu.sh $T >> gpurun_out/${T}_profile.log 2>&1
