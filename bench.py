@@ -371,6 +371,23 @@ def main():
                     sc["roofline_k_pass"] = kp
                 finally:
                     ctx.dbg_tune("sc_ts", 0)
+                # the same calls timed FROM C (tests/native/sc_latency.c, plain C over include/zkhip.h): the figures above go through
+                # the Python wrapper, which allocates four numpy arrays and converts eight ctypes arguments per call (7 us at 2^20)
+                try:
+                    import subprocess
+
+                    exe = os.path.join(ROOT, "tests", "native", "sc_latency")
+                    if os.path.exists(exe):
+                        ctx.sync()
+                        txt = subprocess.run([exe, str(args.log2n)], capture_output=True, text=True, timeout=120).stdout
+                        cabi = {}
+                        for line in txt.splitlines():
+                            w = line.split()
+                            if len(w) > 6 and w[2] == "mean":
+                                cabi[w[0]] = {"mean_us": float(w[3]), "min_us": float(w[6])}
+                        sc["c_abi_2p%d" % args.log2n] = dict(cabi, note="wall time per call measured from a plain-C caller of the C ABI (200 calls after 5 warm-up calls), own process and ctx")
+                except Exception as ex:
+                    sc["c_abi_error"] = repr(ex)
                 extra["sumcheck"] = sc
             del sf, sg
             ctx.trim()
