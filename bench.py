@@ -31,6 +31,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "scalable-collaborative-zksnark_amd"))
+# multi-process GPU work (RCCL across ranks) needs dmabuf IPC on this driver stack; the launcher normally exports it already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
