@@ -276,7 +276,7 @@ def main():
                 "mixed_additions_per_launch": madds,
                 "kernel_ms": accum_ms,
                 "peak_source": "profiles/r01_ubench_int_alu.txt (v_mad_u64_u32 issue rate measured on this chip, carry to SGPR)",
-                "counters": "profiles/r03j_accum_valu_counters.csv (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES of this kernel)",
+                "counters": "profiles/r03l_accum_valu_counters.csv (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES of this kernel)",
                 "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes, "note": "128 B per (point, scalar) pair / the kernel's HIP-event time (SURVEY.md 8d)"},
             },
