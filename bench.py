@@ -537,7 +537,17 @@ def main():
             acc = po.g1_add(acc, affine_mont_to_ints(pt))
         cpu_mt = time.perf_counter() - t
         assert acc == affine_mont_to_ints(ref), "chunked CPU MSM differs from the single-thread result"
+        # anchor to the reference's own numbers: its sample log times party 0's local MSM inside c_commit -- 1 024 points, single
+        # thread, ark-ec on an unnamed host -- at 18.5-19.5 ms (hack/run-hyperplonk/output.txt:22-23,34-35).  The same size through the port:
+        t = time.perf_counter()
+        for _ in range(20):
+            co.msm_g1(bases_h[:1024], sc_h[:1024])
+        cpu_1k = (time.perf_counter() - t) / 20
         out["cpu_baseline"] = {
+            "reference_log_anchor": {"points": 1024, "port_ms": cpu_1k * 1e3, "reference_ms": [18.5, 19.5], "port_over_reference": cpu_1k * 1e3 / 19.0,
+                                     "note": "the reference's leader log (hack/run-hyperplonk/output.txt:22-23,34-35: 'Local: MSM' of c_commit, one thread, host not named; 2^10 points -- the "
+                                             "log's c_open batches ten commitments, :565, i.e. 2^10-element share tables) beside the C port on this box at the same size: where the ratio is "
+                                             "above 1 the real ark-ec path is that much faster per core than the port, and the CPU baseline figures should be read with that factor"},
             "value": m / cpu_dt,
             "unit": "G1 scalar-muls/s",
             "cores": 1,
