@@ -7,7 +7,7 @@ for p in ("scalable-collaborative-zksnark_amd", "oracle", "tests"):
 import numpy as np, zkhip, coracle as co
 from helpers import jac_norm_to_affine, rand_fr, synthetic_bases
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "12345")))  # STRESS_SEED: another sequence of cases
 ctx = zkhip.Ctx(0)
 NMAX = 1 << 16
 bases, _ = synthetic_bases(NMAX, 4242)
