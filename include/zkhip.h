@@ -300,11 +300,17 @@ int zk_scatter(zk_ctx *ctx, const void *d_send, size_t bytes, int root, void *d_
  * lambda_p = sum_j unpack2[j][p] pass coeffs[i] = c_p for all i (7 additions + one scalar multiplication).
  * h_out: count x 18 u64 normalised Jacobian -- this party's share of every result.
  * Error behaviour: a party whose local MSMs fail (ZK_ERR_LENGTH, ZK_ERR_OOM, ...) still takes part in the exchange and
- * returns its own error; every other party returns ZK_ERR_COMM naming the failed party -- nobody is left blocking. */
+ * returns its own error; every other party returns ZK_ERR_COMM naming the failed party.  The staging memory of the
+ * exchange is taken before the local MSMs, so an out-of-memory party can still publish its status.  A party does NOT
+ * join (its peers wait until its communicator is destroyed) only when: it has no communicator / an empty batch; the
+ * few-KiB staging allocation itself fails; the HIP runtime or RCCL fails while enqueueing the exchange.
+ * The 144-byte results travel pinned host -> device -> all-gather -> pinned host (the last steps of an MSM run on the
+ * host, so the points exist there first): two PCIe hops of count x 144 x world bytes per call, see INTEGRATION.md. */
 int zk_d_msm(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets, const void *const *d_scalars,
              const size_t *n, const uint64_t *h_lambda, const uint64_t *h_coeffs, uint64_t *h_out);
 
-/* ---- test hooks (used by tests/ only; stable but not part of the drop-in surface) --- */
+/* ---- TEST HOOKS, NOT ABI: zk_dbg_* exist for tests/ and tools/ only.  They are not part of the drop-in surface, a
+ * reference-side binding must not bind them, and they may change or disappear between versions. --- */
 /* Process-wide experiment / diagnostics knobs (csrc/zk_ctx.hpp `struct Tuning` lists them; the same keys are read once
  * from ZKHIP_TUNE="key=value,..."): e.g. "sc_t1_device" = 1 makes the product sumcheck compute t1 = sum f_hi g_hi of
  * EVERY round on the device instead of deriving it from the previous round polynomial (the cross-check of

@@ -29,7 +29,8 @@ typedef struct ncclComm* ncclComm_t;
 typedef struct {
     char internal[NCCL_UNIQUE_ID_BYTES];
 } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;  // every other value is an error; the text comes from ncclGetErrorString
+typedef int ncclResult_t;  // (an int, not a one-value enum: RCCL returns codes 1..8 through it)
+enum { ncclSuccess = 0 };  // every other value is an error; the text comes from ncclGetErrorString
 typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
 }
 
@@ -251,6 +252,12 @@ int zk_scatter(zk_ctx* ctx, const void* d_send, size_t bytes, int root, void* d_
 // A party whose LOCAL part fails (length mismatch, out of memory, a HIP error) still joins the exchange: every
 // payload carries a status word, so all parties return an error instead of the healthy ones blocking forever in
 // the collective (the reference's `unwrap()` panic takes the whole job down; a silent distributed hang would not).
+// The staging memory of the exchange (device slot 7 + a pinned block of the ctx's own) is taken BEFORE the local MSMs, so
+// a party that then runs out of memory can still publish its status.  Paths on which a party does NOT join, i.e. the
+// peers keep waiting until its communicator is torn down (zk_comm_destroy / process exit): (1) no communicator, or an
+// empty batch, on this party only; (2) the staging allocation itself fails (count x 144 x (world + 1) bytes: a few
+// KiB); (3) an error of the HIP runtime or of RCCL while enqueueing the exchange itself (the stream or the
+// communicator is unusable then).  All three return an error on this party.
 // The MSM results reach the all-gather through pinned host memory: the last step of an MSM (the ~40-step bit-plane /
 // window chain and the normalisation) runs on the host by design, so the 144-byte points exist on the
 // host first; the payload is count x 144 + 16 bytes.
@@ -262,16 +269,30 @@ int zk_d_msm(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* 
     if (count == 0) return ZK_OK;
     const int w = ctx->comm_world;
     const size_t bytes = count * 144 + 16;  // results + status word (own 16-byte slot keeps the points aligned)
+    // ---- staging of the exchange first: whatever happens below, the status can travel ----
+    const size_t stage = bytes * (size_t)(w + 1);
+    char* d = (char*)scratch(ctx, 7, stage);
+    if (d && ctx->h_comm_cap < stage) {
+        if (ctx->h_comm) hipHostFree(ctx->h_comm);
+        ctx->h_comm = nullptr, ctx->h_comm_cap = 0;
+        if (hipHostMalloc(&ctx->h_comm, std::max<size_t>(stage, 4096), hipHostMallocDefault) == hipSuccess) ctx->h_comm_cap = std::max<size_t>(stage, 4096);
+        else ctx->h_comm = nullptr;
+    }
+    char* hp = d ? (char*)ctx->h_comm : nullptr;
+    if (!d || !hp) return fail(ctx, ZK_ERR_OOM, "zk_d_msm: no staging memory for the exchange (%zu bytes): this party cannot join it", stage);
     // ---- local part; any failure is carried into the exchange as `local_rc` ----
     int local_rc = ZK_OK;
     std::vector<uint64_t> local(count * 18 + 2, 0);
     std::vector<void*> scaled;
     if (!srs || !d_scalars || !n || !h_coeffs || !h_out) local_rc = fail(ctx, ZK_ERR_INVALID, "null argument");
     for (size_t k = 0; k < count && !local_rc; k++) {  // lengths first, before any device work
-        if (!srs[k]) local_rc = fail(ctx, ZK_ERR_INVALID, "null srs");
-        else if ((offsets ? offsets[k] : 0) + n[k] > srs[k]->n)
-            local_rc = fail(ctx, ZK_ERR_LENGTH, "d_msm item %zu: %zu scalars but only %zu bases from offset %zu", k, n[k],
-                            srs[k]->n - std::min(offsets ? offsets[k] : (size_t)0, srs[k]->n), offsets ? offsets[k] : (size_t)0);
+        if (!srs[k]) {
+            local_rc = fail(ctx, ZK_ERR_INVALID, "null srs");
+            continue;
+        }
+        const size_t off = offsets ? offsets[k] : 0, avail = srs[k]->n - std::min(off, srs[k]->n);  // (no sum that could wrap)
+        if (n[k] > avail)
+            local_rc = fail(ctx, ZK_ERR_LENGTH, "d_msm item %zu: %zu scalars but only %zu bases from offset %zu", k, n[k], avail, off);
     }
     if (!local_rc) {
         std::vector<MsmItem> items(count);
@@ -296,13 +317,6 @@ int zk_d_msm(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* 
     if (local_rc) std::fill(local.begin(), local.end(), 0);
     local[count * 18] = (uint64_t)(int64_t)local_rc;
     // ---- exchange (every party, healthy or not) ----
-    char* d = (char*)scratch(ctx, 7, bytes * (size_t)(w + 1));
-    char* hp = d ? (char*)pinned(ctx, bytes * (size_t)(w + 1)) : nullptr;
-    if (!d || !hp) {
-        // no staging memory at all: this party cannot even send its status.  Nothing sensible is left but to report it;
-        // the peers see the failure as a communicator error when this party's ctx is torn down.
-        return local_rc ? local_rc : ZK_ERR_OOM;
-    }
     std::memcpy(hp, local.data(), bytes);
     ZK_HIP(ctx, hipMemcpyAsync(d, hp, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_NCCL(ctx, r, r->AllGather(d, d + bytes, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream));

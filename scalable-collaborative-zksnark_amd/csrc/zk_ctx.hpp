@@ -70,6 +70,8 @@ struct zk_ctx {
     // party exchanges (zk_comm.cpp): an RCCL communicator bound to this ctx's GPU
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    void* h_comm = nullptr;  // pinned staging of zk_d_msm (its own block: the MSM pass may re-allocate h_pinned)
+    size_t h_comm_cap = 0;
 };
 
 namespace zk {

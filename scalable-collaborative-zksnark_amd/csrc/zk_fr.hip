@@ -1271,6 +1271,10 @@ int multilinear_batch(zk_ctx* ctx, const zk_sc_item* items, size_t count) {
         }
     char* hres = (char*)pinned(ctx, std::max<size_t>(res_total, 64));
     if (!hres) return ZK_ERR_OOM;
+    // (knob sc_pinned_out = 0, as in the single calls: results land in device memory and are copied to the host afterwards)
+    const bool pinned_out = tuning().sc_pinned_out != 0;
+    char* dres = pinned_out ? hres : (char*)scratch(ctx, 5, std::max<size_t>(res_total, 64));
+    if (!dres) return ZK_ERR_OOM;
     zk_ctx::MsmLane& L = ctx->lanes[0];
     const int nst = count > 1 ? zk_ctx::kAux : 0;  // streams besides the ctx stream
     if (nst) {
@@ -1287,7 +1291,8 @@ int multilinear_batch(zk_ctx* ctx, const zk_sc_item* items, size_t count) {
         ScCall& c = calls[i];
         for (int b = 0; b < 4; b++) c.bufs[b] = c.buf_bytes[b] ? base[b] + off[i * 5 + b] : nullptr;
         c.d_part = c.part_bytes ? base[4] + off[i * 5 + 4] : nullptr;
-        c.d_res = c.h_res = hres + res_off[i];
+        c.d_res = dres + res_off[i];
+        c.h_res = hres + res_off[i];
         c.st = nst ? (oi % (size_t)(nst + 1) == 0 ? ctx->stream : L.aux[oi % (size_t)(nst + 1) - 1]) : ctx->stream;
         c.want_ts = false;
         rc = ZK_SC_DISPATCH(sc_enqueue, c.mode, ctx, c);
@@ -1298,6 +1303,7 @@ int multilinear_batch(zk_ctx* ctx, const zk_sc_item* items, size_t count) {
             hipStreamWaitEvent(ctx->stream, L.ev_join[k], 0);
         }
     }
+    if (!pinned_out && !rc && res_total) hipMemcpyAsync(hres, dres, res_total, hipMemcpyDeviceToHost, ctx->stream);
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (rc) return rc;
     if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamSynchronize(batch)");

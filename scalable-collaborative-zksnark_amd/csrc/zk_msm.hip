@@ -1578,8 +1578,11 @@ static int msm_finish(zk_ctx* ctx, MsmRun& run, uint64_t* h_out) {
             host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();  // exposed part
         }
     }
-    ZK_HIP(ctx, hipStreamSynchronize(L.main));
-    msm_release(ctx, run);
+    {
+        const hipError_t e = hipStreamSynchronize(L.main);
+        msm_release(ctx, run);  // (also on failure: an async lane must not stay busy for the rest of the ctx's life)
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamSynchronize(msm lane)");
+    }
     if (run.lane != 0) return ZK_OK;  // (the phase timers belong to the blocking calls)
     float ms;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
@@ -1783,8 +1786,8 @@ int dbg_fq(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t 
     return ZK_OK;
 }
 
-// window bits of a G2 level's table: the reduction passes of G2 are one lane per addition (no quad form), so a pass costs
-// ~3x a G1 pass and the optimum sits lower than G1's (tools/g2_time.py sweep on MI355X)
+// window bits of a G2 level's table: an Fq2 addition costs ~3x a G1 one in the reduction passes as well (quad-lane form in
+// both, CvG2::kQuad), so the optimum sits lower than G1's (tools/g2_time.py sweep on MI355X)
 static int msm_pick_window_full_g2(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;

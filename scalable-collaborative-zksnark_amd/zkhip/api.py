@@ -34,7 +34,7 @@ class MsmLengthError(ZkError):
 def _ptr(x) -> int:
     if x is None:
         return 0
-    if isinstance(x, DeviceBuffer):
+    if isinstance(x, (DeviceBuffer, DeviceView)):
         return x.ptr
     if isinstance(x, int):
         return x
@@ -78,8 +78,41 @@ class DeviceBuffer:
         self.ctx._check(self.ctx.lib.zk_memcpy_d2h(self.ctx.h, _h(out), self.ptr + offset, out.nbytes))
         return out
 
-    def at(self, byte_offset: int) -> int:
-        return self.ptr + byte_offset
+    def at(self, byte_offset: int) -> "DeviceView":
+        """a view of this buffer from byte_offset on.  The view REFERENCES its parent: whoever holds the view (a queued MSM
+        item, a traced sumcheck operand) keeps the allocation alive, so its address cannot be handed to another buffer."""
+        return DeviceView(self, byte_offset)
+
+
+class DeviceView:
+    """an address inside a DeviceBuffer that keeps the buffer alive; accepted wherever a device buffer is"""
+
+    __slots__ = ("parent", "offset", "ptr")
+
+    def __init__(self, parent: DeviceBuffer, byte_offset: int):
+        assert 0 <= byte_offset <= parent.nbytes, "view outside its buffer"
+        self.parent, self.offset, self.ptr = parent, byte_offset, parent.ptr + byte_offset
+
+    @property
+    def ctx(self):
+        return self.parent.ctx
+
+    @property
+    def nbytes(self) -> int:
+        return self.parent.nbytes - self.offset
+
+    def at(self, byte_offset: int) -> "DeviceView":
+        return DeviceView(self.parent, self.offset + byte_offset)
+
+    def download(self, shape, dtype=np.uint64, offset: int = 0) -> np.ndarray:
+        return self.parent.download(shape, dtype, self.offset + offset)
+
+    def upload(self, a: np.ndarray, offset: int = 0):
+        self.parent.upload(a, self.offset + offset)
+        return self
+
+    def __int__(self) -> int:
+        return self.ptr
 
 
 class Srs:

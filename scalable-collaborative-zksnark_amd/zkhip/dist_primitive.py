@@ -44,6 +44,7 @@ def pss2ss(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
 # d_msm (dmsm.rs:9-43)
 # ---------------------------------------------------------------------------------------
 DEDUP_MSM = True  # default of MsmQueue(dedup=...): tools switch it off to measure what the sharing is worth
+PIPELINE_MSM = True  # MsmQueue.start() really starts an asynchronous pass; False: start() runs the pass to completion (serial steps)
 
 
 def _addr(buf) -> int:
@@ -80,31 +81,42 @@ class MsmQueue:
         """-> indices of the items' results in `res` (an index array: `q.res[idx]`)"""
         idx = []
         for s_, b_, n_ in zip(srs_list, bufs, lens):
-            key = (getattr(s_, "h", None) or id(s_), _addr(b_), int(n_))
-            j = self.index.get(key) if self.dedup else None
+            # Only items whose OWNER the queue holds can be merged: a buffer / view object in self.bufs keeps its allocation
+            # alive until the pass is over, so one address cannot name two tables while the queue collects.  A raw integer
+            # address carries no owner (it may be freed and handed out again): never merged.
+            key = None if isinstance(b_, int) else (getattr(s_, "h", None) or id(s_), _addr(b_), int(n_))
+            j = self.index.get(key) if (self.dedup and key is not None) else None
             if j is None:
                 j = len(self.lens)
                 self.srs.append(s_)
                 self.bufs.append(b_)
                 self.lens.append(int(n_))
-                self.index[key] = j
+                if key is not None:
+                    self.index[key] = j
             idx.append(j)
         self.keep += list(keep)  # buffers that must outlive the batched pass
         return np.array(idx, dtype=np.int64)
 
     def scale(self, buf, lam_m, n: int):
         """lambda * buf for the pre-scaled d_msm, once per distinct scalar buffer"""
-        key = (_addr(buf), int(n), bytes(np.asarray(lam_m, dtype=np.uint64)))
-        out = self.scaled.get(key) if self.dedup else None
+        key = None if isinstance(buf, int) else (_addr(buf), int(n), bytes(np.asarray(lam_m, dtype=np.uint64)))
+        out = self.scaled.get(key) if (self.dedup and key is not None) else None
         if out is None:
             out = self.be.fr_scale(buf, lam_m, n)
-            self.scaled[key] = out
+            if key is not None:
+                self.scaled[key] = out
+                self.keep.append(buf)  # (the key names its address: hold the owner as long as the key lives)
             self.keep.append(out)
         return out
 
+    def _close(self):
+        """the pass is over: drop the owners and, with them, the keys that named their addresses"""
+        self.keep, self.index, self.scaled = [], {}, {}
+        self.srs, self.bufs, self.lens = [], [], []  # (views in `bufs` reference their parents: let the quotient buffers go now)
+
     def run(self):
         self.res = self.be.msm_g1_batch(self.srs, self.bufs, self.lens) if self.lens else np.zeros((0, 18), dtype=np.uint64)
-        self.keep = []
+        self._close()
         return self.res
 
     # the same in two halves: start() enqueues the pass on the GPU and returns (zk_msm_g1_batch_async), finish() collects the
@@ -112,7 +124,7 @@ class MsmQueue:
     # exchange closures of a step are host arithmetic on a few hundred points, during which the GPU would otherwise idle.
     def start(self):
         self.job = None
-        if self.lens and hasattr(self.be, "msm_g1_batch_async"):
+        if self.lens and PIPELINE_MSM and hasattr(self.be, "msm_g1_batch_async"):
             self.job = self.be.msm_g1_batch_async(self.srs, self.bufs, self.lens)
         else:
             self.run()
@@ -121,7 +133,7 @@ class MsmQueue:
         if getattr(self, "job", None) is not None:
             self.res = self.job.wait()
             self.job = None
-            self.keep = []
+            self._close()
         return self.res
 
 

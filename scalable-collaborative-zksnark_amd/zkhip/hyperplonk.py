@@ -164,6 +164,7 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
     den = be.fr_axpb(T["eq_r1_p"], T["ssigma_p"], pk.alpha, pk.beta, hlen)
     h_p = be.fr_batch_div(num, den, hlen)
     subtree, top = dp.d_acc_product(be, h_p, hlen, net)  # :342
+    q.keep.append(subtree)  # v1x and the layer slices below are views into it; the queued MSMs read them after this function returns
     if getattr(be, "sc_trace", None) is not None:
         be.sc_trace.append(("keepalive", subtree, None, 0, np.zeros((0, 4), dtype=np.uint64)))  # traced slices point into it
     v1x = _at(subtree, 32 * hlen)  # tree[N..]

@@ -129,6 +129,27 @@ def trace_anchor_values(be, trace) -> list:
     return out
 
 
+def check_closing_rows(values, proofs, pp, net) -> bool:
+    """
+    c_sumcheck_product's last row is (0, vf[0] * vg[0], 0) with vf / vg = pss2ss of the last values followed by the log2(l)
+    extra rounds (dsumcheck.rs:224-225,282); at l = 1 that is pss2ss(f_last)[0] * pss2ss(g_last)[0].  f_last / g_last come
+    from `values` (trace_anchor_values: two zk_fold per transcript), not from the sumcheck under test.  COLLECTIVE: every
+    party calls it in lock step with its own values (two pss2ss exchanges per transcript).  l = 1 only.
+    """
+    from . import dist_primitive as dp
+    from .field import fr_mont
+
+    assert pp.l == 1
+    ok = True
+    for (kind, _cl, fr_, gr_, _), pr in zip(values, proofs):
+        assert kind == "c"
+        vf = fr_from_mont(dp.pss2ss(fr_mont(fr_), pp, net)[0])
+        vg = fr_from_mont(dp.pss2ss(fr_mont(gr_), pp, net)[0])
+        last = np.asarray(pr, dtype=np.uint64).reshape(-1, 3, 4)[-1]
+        ok &= fr_from_mont(last[0]) == 0 and fr_from_mont(last[2]) == 0 and fr_from_mont(last[1]) == vf * vg % R_MOD
+    return bool(ok)
+
+
 def dhyperplonk_anchors(values_by_party: list, me: int, n_parties: int) -> dict:
     """
     label -> (claimed, final) for party `me` from the traced values of a dhyperplonk run.  values_by_party: one

@@ -79,16 +79,9 @@ def _leader_run(n, seed=3):
 def _closing_rows_ok(dp, values, proofs, pp, net):
     """c_sumcheck_product's last row is (0, pss2ss(f_last)[0] * pss2ss(g_last)[0], 0) at l = 1 (dsumcheck.rs:224-225,282);
     f_last / g_last here come from zk_fold, not from the sumcheck under test.  Every party calls this in lock step."""
-    from zkhip.field import R_MOD, fr_from_mont, fr_mont
+    from zkhip.verify import check_closing_rows
 
-    ok = True
-    for (kind, _cl, fr_, gr_, _), pr in zip(values, proofs):
-        assert kind == "c"
-        vf = fr_from_mont(dp.pss2ss(fr_mont(fr_), pp, net)[0])
-        vg = fr_from_mont(dp.pss2ss(fr_mont(gr_), pp, net)[0])
-        last = np.asarray(pr, dtype=np.uint64).reshape(-1, 3, 4)[-1]
-        ok &= fr_from_mont(last[0]) == 0 and fr_from_mont(last[2]) == 0 and fr_from_mont(last[1]) == vf * vg % R_MOD
-    return ok
+    return check_closing_rows(values, proofs, pp, net)
 
 
 def _check_leader(n, co, ctx, pk, pp, net, res, run_seed, oracle_open=True):

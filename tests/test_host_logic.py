@@ -251,3 +251,66 @@ def test_c_acc_product_and_share(l):
         for k in range(3):
             buf, cnt = res[p][k]  # device-resident results: (buffer, length)
             assert ints(buf.download((cnt, 4))) == exp[p][k], (p, k)
+
+
+def test_msm_queue_merges_only_items_whose_owner_it_holds():
+    """
+    MsmQueue's duplicate detection names an item by (SRS level, scalar address, length).  An address only identifies a table
+    while its allocation is alive: the queue must hold the owner of every address it uses as a key (buffer / view objects),
+    and must never merge raw integer addresses (no owner: the block may be freed and handed out again for another table).
+    """
+    import gc
+    import weakref
+
+    from zkhip.api import DeviceBuffer, DeviceView
+
+    freed = []
+
+    class FakeLib:
+        def zk_free(self, h, ptr):
+            freed.append(ptr)
+
+    class FakeCtx:
+        lib, h = FakeLib(), 1
+
+    def buf(ptr, nbytes=4096):  # a DeviceBuffer without a device
+        b = DeviceBuffer.__new__(DeviceBuffer)
+        b.ctx, b.nbytes, b.ptr = FakeCtx(), nbytes, ptr
+        return b
+
+    class Be:
+        def msm_g1_batch(self, srs, bufs, lens):
+            return np.zeros((len(lens), 18), dtype=np.uint64)
+
+    srs = OracleSrs(np.zeros((8, 12), dtype=np.uint64))
+    q = dp.MsmQueue(Be(), dedup=True)
+    a = buf(0x1000)
+    ia = q.add([srs], [a.at(64)], [4])
+    wa = weakref.ref(a)
+    del a
+    gc.collect()
+    assert wa() is not None and freed == [], "the queued view must keep its parent allocation alive"
+    assert isinstance(q.bufs[0], DeviceView) and q.bufs[0].ptr == 0x1040
+    # the same address through another live view of the same parent: the same item
+    ib = q.add([srs], [wa().at(64)], [4])
+    assert ia[0] == ib[0] and len(q.lens) == 1
+    # raw integer addresses are never merged, not even with themselves
+    ic, id_ = q.add([srs], [0x1040], [4]), q.add([srs], [0x1040], [4])
+    assert len({int(ia[0]), int(ic[0]), int(id_[0])}) == 3 and len(q.lens) == 3
+    # scale(): the source buffer named by the key is held as well
+    class Be2(Be):
+        def fr_scale(self, b, lam, n):
+            return buf(0x9000)
+    q2 = dp.MsmQueue(Be2(), dedup=True)
+    src = buf(0x2000)
+    lam = np.ones(4, dtype=np.uint64)
+    s1 = q2.scale(src, lam, 4)
+    ws = weakref.ref(src)
+    del src
+    gc.collect()
+    assert ws() is not None and q2.scale(ws(), lam, 4) is s1
+    q2.run()
+    q.run()
+    gc.collect()
+    assert wa() is None and ws() is None and 0x1000 in freed and 0x2000 in freed, "owners are released when the pass is over"
+    assert q.index == {} and q2.scaled == {}

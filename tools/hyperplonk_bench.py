@@ -6,10 +6,13 @@ End-to-end collaborative HyperPlonk (hyperplonk/src/dhyperplonk.rs) on MI355X.
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/hyperplonk_bench.py --nvars 20   # l = 1, 8 parties = 8 GPUs
 
 Prints the reference's timer sections (Commit / Gate identity / Wire identity / Open / total)
-and the Comm: (up, down) byte counters for the leader.  Every run is SELF-CHECKING (unless --no-check):
-all sumcheck transcripts must pass their verifier chains (zkhip.verify, dsumcheck.rs:541-588), sampled
-commits / opens must equal a one-call-at-a-time recomputation, and the timed repetitions must reproduce
-the same transcript bit for bit; a failed check exits non-zero.
+and the Comm: (up, down) byte counters for the leader.  Every run is SELF-CHECKING (unless --no-check), in every mode
+(leader-echo, ranks, party threads): all sumcheck transcripts must pass their verifier chains (zkhip.verify,
+dsumcheck.rs:541-588) ANCHORED at both ends -- the claim sum f g and the final evaluation f(r) g(r) of every chain come from
+kernels the product sumcheck does not use (an extra traced run, outside the timed repetitions; the leader's d_ chains use
+every party's values); the closing rows of the c_sumcheck_products are compared with pss2ss of independently folded values;
+sampled commits / opens must equal a one-call-at-a-time recomputation, and the timed repetitions must reproduce the same
+transcript bit for bit; a failed check exits non-zero.
 """
 import argparse, json, os, sys, time
 
@@ -35,15 +38,52 @@ def digest(res):
     return h.hexdigest()
 
 
-def self_check(n, res, digests, pk, pp, ctx, net, run_seed, world):
+def traced_run(n, pk, pp, ctx, net, run_seed, data_parallel):
+    """one more run with the operands of every product sumcheck recorded -> (result, this party's anchor values, closing rows ok)"""
+    from zkhip.hyperplonk import dhyperplonk
+    from zkhip.verify import check_closing_rows, trace_anchor_values
+
+    ctx.sc_trace = []
+    res, _ = dhyperplonk(n, pk, pp, ctx, net, seed=run_seed, data_parallel=data_parallel)
+    trace, ctx.sc_trace = ctx.sc_trace, None
+    values = trace_anchor_values(ctx, trace)
+    del trace
+    closing = check_closing_rows(values[:7], list(res[0][0]) + [res[1][0][0]], pp, net)
+    return res, values, closing
+
+
+def anchored_failures(n, res_sc, chal, values_by_party, me, n_parties, leader, echo):
+    """verifier chains of one party's transcripts with both ends pinned (zkhip.verify); -> list of failing labels"""
+    from zkhip.verify import check_dhyperplonk_transcripts, dhyperplonk_anchors
+
+    anchors = dhyperplonk_anchors(values_by_party, me, n_parties)
+    want = len(values_by_party[0]) if leader else 7
+    bad = list(check_dhyperplonk_transcripts(n, res_sc, chal, n_parties, leader, echo, anchors=anchors))
+    if len(anchors) != want:
+        bad.append(f"{len(anchors)} anchors instead of {want}")
+    return bad
+
+
+def self_check(n, res, digests, pk, pp, ctx, net, run_seed, world, data_parallel=False):
     """size-independent properties of a finished run (see tests/test_gpu_e2e_fullsize.py); "ok" or the failures"""
     import numpy as np
 
     from zkhip import dist_primitive as dp
     from zkhip.field import random_fr
-    from zkhip.verify import check_dhyperplonk_transcripts
 
-    bad = list(check_dhyperplonk_transcripts(n, res, pk, pp.n, net.is_leader, world == 1))
+    res_t, mine, closing = traced_run(n, pk, pp, ctx, net, run_seed, data_parallel)
+    if world > 1:
+        import torch.distributed as dist
+
+        vals = [None] * world
+        dist.all_gather_object(vals, mine)
+    else:
+        vals = [mine]
+    bad = anchored_failures(n, res_t, pk, vals, net.party_id if world > 1 else 0, pp.n, net.is_leader, world == 1)
+    if not closing:
+        bad.append("closing row of a c_sumcheck_product differs from pss2ss of the folded last values")
+    if digest(res_t) != digests[-1]:
+        bad.append("the traced (anchored) run differs from the timed ones")
     if len(set(digests)) != 1:
         bad.append("repetitions disagree")
     (gate_proofs, gate_comms), (w_proofs, w_commits, w_opens) = res
@@ -69,7 +109,7 @@ def party_threads(args):
     from zkhip.hyperplonk import PackedProvingParameters, dhyperplonk
     from zkhip.net import LocalTestNet
     from zkhip.pss import PackedSharingParams
-    from zkhip.verify import check_dhyperplonk_transcripts
+    from types import SimpleNamespace
 
     pp = PackedSharingParams(1)
 
@@ -83,17 +123,29 @@ def party_threads(args):
                 digests.append(digest(res))
                 if net.is_leader and (r > 0 or args.reps == 0) and (best is None or timers["Distributed HyperPlonk"] < best["Distributed HyperPlonk"]):
                     best = timers
-            bad = [] if args.no_check else list(check_dhyperplonk_transcripts(args.n, res, pk, pp.n, net.is_leader, False))
+            bad, chk = [], None
+            if not args.no_check:
+                res_t, values, closing = traced_run(args.n, pk, pp, ctx, net, 7 + net.party_id, args.data_parallel)
+                if not closing:
+                    bad.append("closing row of a c_sumcheck_product differs from pss2ss of the folded last values")
+                if digest(res_t) != digests[-1]:
+                    bad.append("the traced (anchored) run differs from the timed ones")
+                chk = (((res_t[0][0], None), (res_t[1][0], None, None)), values,
+                       SimpleNamespace(challenge=pk.challenge, challenge_r1=pk.challenge_r1, challenge_r2=pk.challenge_r2))
             if len(set(digests)) != 1:
                 bad.append("repetitions disagree")
-            return best, bad, (net.upload, net.download)
+            return best, bad, (net.upload, net.download), chk
         finally:
             ctx.close()
 
     out = LocalTestNet.simulate_network_round(pp.n, party)
-    bad = [b for _, bs, _ in out for b in bs]
+    bad = [f"party {p}: {b}" for p, (_, bs, _, _) in enumerate(out) for b in bs]
+    if not args.no_check:  # chains anchored with ALL parties' values (the leader's d_ rows are sums over the parties)
+        vals = [o[3][1] for o in out]
+        for p, o in enumerate(out):
+            bad += [f"party {p}: {b}" for b in anchored_failures(args.n, o[3][0], o[3][2], vals, p, pp.n, p == 0, False)]
     print(json.dumps({"n": args.n, "l": 1, "parties": pp.n, "mode": "8 party threads, one ctx each, ALL on GPU 0 (one GPU does the work of eight)", "timers_s": out[0][0],
-                      "comm_bytes": list(out[0][2]), "checks": "ok" if not bad else bad}))
+                      "comm_bytes": list(out[0][2]), "checks": "ok" if not bad else bad, "check_kind": "skipped" if args.no_check else "anchored"}))
     if bad:
         sys.exit(1)
 
@@ -162,10 +214,10 @@ def main():
                 best = timers
     checks = "skipped"
     if not args.no_check:
-        checks = self_check(args.n, res, digests, pk, pp, ctx, net, 7 + rank, world)
+        checks = self_check(args.n, res, digests, pk, pp, ctx, net, 7 + rank, world, args.data_parallel)
     if rank == 0:
         print(json.dumps({"n": args.n, "l": 1, "parties": pp.n, "mode": ("comm(" + os.environ.get("ZK_BENCH_BACKEND", "nccl") + "," + type(net).__name__ + ")") if world > 1 else "leader-echo",
-                          "setup_s": setup, "timers_s": best, "comm_bytes": [net.upload, net.download], "checks": checks}))
+                          "setup_s": setup, "timers_s": best, "comm_bytes": [net.upload, net.download], "checks": checks, "check_kind": "skipped" if args.no_check else "anchored"}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
