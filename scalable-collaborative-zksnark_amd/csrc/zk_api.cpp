@@ -123,7 +123,6 @@ void* scratch(zk_ctx* ctx, int slot, size_t bytes) {
 void* pinned(zk_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->h_pinned_cap && ctx->h_pinned) return ctx->h_pinned;
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
-    if (ctx->h_comm) hipHostFree(ctx->h_comm);
     ctx->h_pinned = nullptr;
     size_t want = bytes < 4096 ? 4096 : bytes;
     hipError_t e = hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault);
@@ -191,6 +190,7 @@ void zk_ctx_destroy(zk_ctx* ctx) {
     for (auto& kv : ctx->pool_free)
         for (void* p : kv.second) hipFree(p);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->h_comm) hipHostFree(ctx->h_comm);
     for (auto& e : ctx->ev)
         if (e) hipEventDestroy(e);
     zk::msm_lanes_destroy(ctx);

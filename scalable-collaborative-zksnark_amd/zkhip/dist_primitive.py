@@ -940,7 +940,10 @@ def c_acc_product_and_share(be, shares, masks, unmask0, unmask1, unmask2, S: int
     # to_share = subtree[.. 2 mlen - num_to_send]; its three views (:118-150) as device buffers
     half = (2 * mlen - num_to_send) // 2
     vx0, vx1 = be.fr_deinterleave(subtree, half)  # to_share[0::2], to_share[1::2]
-    views = ((vx0, half), (vx1, half), (_at(subtree, fr * mlen), mlen - num_to_send))  # v(x,0), v(x,1), v(1,x) = to_share[mlen..]
+    # v(x,0), v(x,1), v(1,x) = to_share[mlen..]: `.skip(subtree.len() / 2)` past the end of to_share yields nothing (:146-150) -- tables
+    # with S l / N_p <= N_p leave v(1,x) entirely to the leader tree (the reference's `transpose` then asserts on the empty matrix,
+    # operator.rs:24; here the view is simply empty)
+    views = ((vx0, half), (vx1, half), (_at(subtree, fr * min(mlen, 2 * mlen - num_to_send)), max(0, mlen - num_to_send)))
     outs = []
     for d_sel, cnt in views:
         k = (cnt + pp.l - 1) // pp.l

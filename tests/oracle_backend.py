@@ -144,6 +144,32 @@ class OracleBackend:
             res[r * out_row_stride : r * out_row_stride + (k - 1) * out_vec_stride + 1 : out_vec_stride] = acc
         return NumpyBuf(res)
 
+    def fr_ntt_map(self, tables, d_in, in_vec_stride, in_comp_stride, k, out_vec_stride, out_row_stride, out=None):
+        """
+        zk_fr_ntt_map's contract restated with python big-ints and DENSE sums (no butterfly code shared with the kernel): per
+        vector j, coefficients c_i = sum_x in[x] winv^(x i) over the n_in inputs (domain size A), y_i = scale_i c_i for
+        i < min(A, B) and 0 above, outputs out[r] = sum_i y_i w^(i r step) for r < take.  The branch of dist_primitive taken
+        from 64 parties up (pss.rs:93-171 as the reference itself runs it: ifft, resize, fft).
+        """
+        t = tables
+        A, B, nin, take, step = t["A"], t["B"], t["n_in"], t["take"], t["step"]
+        dec = lambda a: [po.fr_from_mont_limbs(r) for r in np.asarray(a, dtype=np.uint64).reshape(-1, 4)]
+        root = lambda tab, size: 1 if size == 1 else (po.R_MOD - 1 if size == 2 else tab[1])
+        wi, w, scale = root(dec(t["winv"]), A), root(dec(t["w"]), B), dec(t["scale"])
+        wip = [pow(wi, e, po.R_MOD) for e in range(A)]
+        wp = [pow(w, e, po.R_MOD) for e in range(B)]
+        keep = min(A, B)
+        src = _arr(d_in)
+        span = (k - 1) * out_vec_stride + (take - 1) * out_row_stride + 1 if k else 1
+        res = np.zeros((span, 4), dtype=np.uint64)
+        for j in range(k):
+            x = [po.fr_from_mont_limbs(src[j * in_vec_stride + c * in_comp_stride]) for c in range(nin)]
+            y = [scale[i] * sum(x[c] * wip[(c * i) % A] for c in range(nin)) % po.R_MOD for i in range(keep)]
+            for r in range(take):
+                e = r * step
+                res[j * out_vec_stride + r * out_row_stride] = po.fr_to_mont_limbs(sum(y[i] * wp[(i * e) % B] for i in range(keep)) % po.R_MOD)
+        return NumpyBuf(res)
+
     def fr_deinterleave(self, t, n):
         a = _arr(t)[: 2 * n]
         return NumpyBuf(a[0::2].copy()), NumpyBuf(a[1::2].copy())
