@@ -144,6 +144,26 @@ static constexpr u32 kLim = 16383, kAB = 1024, kDA = 2048;
 __host__ __device__ constexpr u32 mq(int j) { return (Q30::Q(j) >> 20) + 1; }
 __host__ __device__ constexpr bool spill(u32 bnd, u32 units) { return bnd + units > kLim; }
 }  // namespace f30b
+// ---- column order -----------------------------------------------------------------------------------------------------
+// A column must START from the carry of the previous one: then every product of the column is one v_mad_u64_u32 whose addend is the
+// running sum, and the carry costs nothing.  LLVM's Reassociate pass undoes exactly that: it sorts the leaves of an integer sum by
+// "rank" (roughly: how late a value becomes available) and puts the carry -- the end of the previous column's chain -- LAST, so the
+// products run as a chain of their own and meet the carry in a separate 64-bit addition (v_lshl_add_u64: one more multiplier-class
+// instruction per column, 27 of 448 in f30_mul; 341 per mixed addition in k_accum_tiles).  The rank of a value that comes out of a
+// call-like instruction is its POSITION in the block, so the multiplicands of a column are passed through llvm.annotation (returns
+// its argument, generates no code, but counts as a call) after ZK_F30_COLUMN() has advanced the position (12 calls: the carry ranks ~6 above the last product of the previous column; 8 is the measured minimum) past the depth of the
+// previous chain: the products then rank above the carry and the chain is rebuilt carry-first.  Pure scheduling hint: the value
+// computed is the same; tests/test_abi.py checks on the built library that the hint still works with the compiler in use.
+#ifndef ZK_F30_NO_CHAIN_HINT
+#define ZK_F30_LATE(x) ((u32)__builtin_annotation((unsigned)(x), "zk.f30.column"))
+#define ZK_F30_COLUMN()                                                      \
+    do {                                                                     \
+        _Pragma("unroll") for (int z_ = 0; z_ < 12; z_++) (void)ZK_F30_LATE(0); \
+    } while (0)
+#else
+#define ZK_F30_LATE(x) (x)
+#define ZK_F30_COLUMN() do { } while (0)
+#endif
 #define ZK_F30_ACC(prod, units)                 \
     do {                                        \
         if (f30b::spill(bnd, (units))) {        \
@@ -165,15 +185,16 @@ __device__ __forceinline__ Fq30 f30_mul(const Fq30& a, const Fq30& b) {
 #pragma unroll
     for (int k = 0; k < 25; k++) {
         u64 nxt = 0;
+        ZK_F30_COLUMN();
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (j >= 0 && j < 13) ZK_F30_ACC((u64)a.l[i] * b.l[j], f30b::kAB);
+            if (j >= 0 && j < 13) ZK_F30_ACC((u64)ZK_F30_LATE(a.l[i]) * b.l[j], f30b::kAB);
         }
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)m[i] * Q30::Q(j), f30b::mq(j));
+            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)ZK_F30_LATE(m[i]) * Q30::Q(j), f30b::mq(j));
         }
         if (k < 13) {
             const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;  // (a spill leaves the low 30 bits of the column in place)
@@ -199,16 +220,17 @@ __device__ __forceinline__ Fq30 f30_sqr(const Fq30& a) {
 #pragma unroll
     for (int k = 0; k < 25; k++) {
         u64 nxt = 0;
+        ZK_F30_COLUMN();
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (j > i && j < 13) ZK_F30_ACC((u64)d[i] * a.l[j], f30b::kDA);
+            if (j > i && j < 13) ZK_F30_ACC((u64)ZK_F30_LATE(d[i]) * a.l[j], f30b::kDA);
         }
-        if ((k & 1) == 0) ZK_F30_ACC((u64)a.l[k / 2] * a.l[k / 2], f30b::kAB);
+        if ((k & 1) == 0) ZK_F30_ACC((u64)ZK_F30_LATE(a.l[k / 2]) * a.l[k / 2], f30b::kAB);
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)m[i] * Q30::Q(j), f30b::mq(j));
+            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)ZK_F30_LATE(m[i]) * Q30::Q(j), f30b::mq(j));
         }
         if (k < 13) {
             const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;
@@ -236,20 +258,21 @@ __device__ __forceinline__ Fq30 f30_mul2add(const Fq30& a, const Fq30& b, const 
 #pragma unroll
     for (int k = 0; k < 25; k++) {
         u64 nxt = 0;
+        ZK_F30_COLUMN();
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (j >= 0 && j < 13) ZK_F30_ACC((u64)a.l[i] * b.l[j], f30b::kAB);
+            if (j >= 0 && j < 13) ZK_F30_ACC((u64)ZK_F30_LATE(a.l[i]) * b.l[j], f30b::kAB);
         }
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (j >= 0 && j < 13) ZK_F30_ACC((u64)c.l[i] * d.l[j], f30b::kAB);
+            if (j >= 0 && j < 13) ZK_F30_ACC((u64)ZK_F30_LATE(c.l[i]) * d.l[j], f30b::kAB);
         }
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const int j = k - i;
-            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)m[i] * Q30::Q(j), f30b::mq(j));
+            if (i < k && j >= 1 && j < 13) ZK_F30_ACC((u64)ZK_F30_LATE(m[i]) * Q30::Q(j), f30b::mq(j));
         }
         if (k < 13) {
             const u32 mk = ((u32)acc * Q30::QP) & Q30::MASK;
@@ -265,6 +288,8 @@ __device__ __forceinline__ Fq30 f30_mul2add(const Fq30& a, const Fq30& b, const 
     return t;
 }
 #undef ZK_F30_ACC
+#undef ZK_F30_LATE
+#undef ZK_F30_COLUMN
 
 // The same three schedules on WORST-CASE limbs (every variable limb 2^30 - 1, doubled limbs 2^31 - 2, every m_i 2^30 - 1), exact
 // 128-bit arithmetic: true iff no column accumulator can reach 2^64.  kind 0: mul, 1: sqr, 2: mul2add.

@@ -89,3 +89,36 @@ def test_rust_sys_is_in_sync():
     dmsm = " ".join(open(os.path.join(ROOT, "rust", "dmsm_patched.rs")).read().split())
     assert ("pub async fn d_msm<G: CurveGroup, Net: MPCSerializeNet>( bases: &Vec<Vec<G::Affine>>, scalars: &Vec<Vec<G::ScalarField>>, "
             "pp: &PackedSharingParams<G::ScalarField>, net: &Net, sid: MultiplexedStreamID, ) -> Result<Vec<G>, MPCNetError>") in dmsm
+
+
+def test_fq_multiplier_columns_start_from_the_carry(tmp_path):
+    """
+    csrc/fq30.cuh orders every column of the 13 x 30-bit Montgomery multipliers carry-first through a scheduling hint
+    (ZK_F30_LATE / ZK_F30_COLUMN: llvm.annotation raises the reassociation rank of the column's products above the carry).
+    The hint changes no value -- the GPU parity tests cover that -- but it depends on how the compiler in use ranks
+    values, so the BUILT kernel is checked: the bucket accumulation must hold one mixed addition's 3 055 multiplies
+    and only the handful of 64-bit joins the column spills need (341 without the hint, 88 with it).
+    """
+    import re
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "scalable-collaborative-zksnark_amd", "csrc", "zk_msm.o")
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(obj) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("needs the built zk_msm.o and the ROCm LLVM binutils")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "msm.co")
+    subprocess.check_call([tools[0], f"--dump-section=.hip_fatbin={fat}", obj, str(tmp_path / "copy.o")])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+    asm = subprocess.run([tools[2], "-d", co], capture_output=True, text=True, check=True).stdout
+    body = None
+    for fn in re.split(r"\n(?=[0-9a-f]{16} <)", asm):
+        head = fn.split("\n", 1)[0]
+        if "k_accum_tiles" in head and "CvG1" in head:
+            body = fn
+    assert body is not None, "k_accum_tiles<CvG1> not found in the device code"
+    mads = len(re.findall(r"\bv_mad_u64_u32\b", body))
+    joins = len(re.findall(r"\bv_lshl_add_u64\b", body))
+    assert 3055 <= mads <= 3200, mads
+    assert joins <= 120, f"{joins} v_lshl_add_u64 in k_accum_tiles<CvG1>: the carry-first column hint of fq30.cuh no longer takes effect"
