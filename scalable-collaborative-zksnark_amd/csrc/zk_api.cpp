@@ -19,7 +19,7 @@ static const TuneKey kTuneKeys[] = {
     {"sc_pass_wg", &Tuning::sc_pass_wg}, {"sc_local_g", &Tuning::sc_local_g}, {"sc_ts", &Tuning::sc_ts}, {"sc_xcd", &Tuning::sc_xcd},
     {"sc_kf", &Tuning::sc_kf}, {"sc_plain_flat", &Tuning::sc_plain_flat}, {"sc_kp", &Tuning::sc_kp}, {"sc_k0", &Tuning::sc_k0},
     {"sc_flat_wg", &Tuning::sc_flat_wg}, {"sc_plain_wg", &Tuning::sc_plain_wg}, {"sc_pre", &Tuning::sc_pre},
-    {"sc_pinned_out", &Tuning::sc_pinned_out}, {"sc_t1_device", &Tuning::sc_t1_device},
+    {"sc_pinned_out", &Tuning::sc_pinned_out}, {"sc_t1_device", &Tuning::sc_t1_device}, {"sc_handover", &Tuning::sc_handover},
     {"msm_table_dc", &Tuning::msm_table_dc}, {"msm_qstep", &Tuning::msm_qstep}, {"msm_tile", &Tuning::msm_tile}, {"msm_pair", &Tuning::msm_pair},
     {"msm_fixq", &Tuning::msm_fixq}, {"msm_quad", &Tuning::msm_quad}, {"msm_stage", &Tuning::msm_stage}, {"msm_split", &Tuning::msm_split},
     {"msm_np", &Tuning::msm_np}, {"msm_debug", &Tuning::msm_debug}, {"msm_serial", &Tuning::msm_serial}, {"msm_size_classes", &Tuning::msm_size_classes},

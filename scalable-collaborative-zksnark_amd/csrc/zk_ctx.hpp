@@ -93,6 +93,7 @@ struct Tuning {
     long sc_plain_wg = 3;     // workgroups per CU, flat plain pass
     long sc_pre = 1;          // first round of a full-size local stage straight out of the table
     long sc_pinned_out = 1;   // results written straight into pinned host memory
+    long sc_handover = 1;     // the pass before a multi-workgroup local stage stores that stage's slices contiguously
     long sc_t1_device = 0;    // TEST SWITCH: t1 = sum f_hi g_hi of EVERY round computed on the device (never derived)
     // MSM (zk_msm.hip)
     long msm_table_dc = 0;    // window-table width delta (sweeps)

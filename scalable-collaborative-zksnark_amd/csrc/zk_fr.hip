@@ -142,6 +142,28 @@ __device__ __forceinline__ void round_pair_lazy(Fr& flo, const Fr& fhi, Fr& glo,
     flo = fr_add(flo, fr_mul(r, df));
 }
 
+// Hand-over layout between the last HBM pass and the local stage behind it.  A local stage cuts its table CYCLICALLY (workgroup
+// w owns the elements {w + G t}: the round pairs then stay inside the workgroup), so out of a linearly stored table every lane
+// of it gathers 32 bytes from its own 128-byte line -- 10 us of the 2^20 product sumcheck's 31-us first local stage.  The pass
+// that produces the table can just as well store slice w CONTIGUOUSLY (element w + G t at w S + t, S = slice length): it walks
+// its outputs in tiles of 16 slices x 16 positions per workgroup (a wave: 16 x 4), so its reads are 512-byte runs, its stores
+// whole 128-byte lines, and the local stage streams its slice.  Pure re-indexing of an intermediate buffer.
+struct Handover {
+    unsigned G = 0;      // slices (workgroups of the next stage); 0: linear table
+    unsigned S = 0;      // elements per slice
+};
+// work item `idx` of a pass -> (table index j it computes, position it stores to)
+__device__ __forceinline__ void handover_map(const Handover& h, size_t idx, size_t& j, size_t& pos) {
+    if (h.G == 0) {
+        j = pos = idx;
+        return;
+    }
+    const unsigned tile = (unsigned)(idx >> 8), t = (unsigned)idx & 255u, gw = h.G >> 4;
+    const unsigned w = (tile % gw) * 16 + (t & 15u), p = (tile / gw) * 16 + (t >> 4);
+    j = (size_t)w + (size_t)h.G * p;
+    pos = (size_t)w * h.S + p;
+}
+
 template <int MODE>
 struct ModeTraits {
     static constexpr int W = (MODE == 0) ? 2 : (MODE == 1 ? 3 : 0);
@@ -158,7 +180,7 @@ struct ModeTraits {
 template <int K, int MODE, bool FULLT1 = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, ((K == 3 && MODE == 1) || FULLT1) ? 1 : ((K <= 2 && MODE != 1) ? 4 : 2)))) k_pass(const void* __restrict__ f, const void* __restrict__ g, void* __restrict__ fo,
                                                void* __restrict__ go, size_t m, ChalArgs ch, void* __restrict__ partials,
-                                               void* __restrict__ qbase, int t1mode) {
+                                               void* __restrict__ qbase, int t1mode, Handover ho) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     constexpr int E = 1 << K;
@@ -178,7 +200,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
             for (int i = 0; i < 17; i++) wacc[a].l[i] = 0;
     }
 
-    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += (size_t)gridDim.x * kBlock) {
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < q; idx += (size_t)gridDim.x * kBlock) {
+        size_t j, opos;
+        handover_map(ho, idx, j, opos);
         Fr ef[E], eg[TWO ? E : 1];
 #pragma unroll
         for (int s = 0; s < E; s++) {
@@ -209,8 +233,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 
             qoff += mcur >> 1;
             mcur >>= 1;
         }
-        fr_store(fo, j, ef[0]);
-        if (TWO) fr_store(go, j, eg[0]);
+        fr_store(fo, opos, ef[0]);
+        if (TWO) fr_store(go, opos, eg[0]);
     }
     if constexpr (LAZY) {
         // one 544-bit partial per wave and sum: [(round * 3 + kind) * 4 gridDim + 4 block + wave], 80-byte slots
@@ -255,10 +279,12 @@ __device__ __forceinline__ void w9_csub(u32 (&v)[9]) {
     for (int i = 0; i < 9; i++) v[i] = bw ? v[i] : d[i];
 }
 template <int K>
-__global__ void __launch_bounds__(kBlock) k_fold_flat(const void* __restrict__ f, void* __restrict__ fo, size_t m, FlatW w) {
+__global__ void __launch_bounds__(kBlock) k_fold_flat(const void* __restrict__ f, void* __restrict__ fo, size_t m, FlatW w, Handover ho) {
     constexpr int E = 1 << K;
     const size_t q = m >> K;
-    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += (size_t)gridDim.x * kBlock) {
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < q; idx += (size_t)gridDim.x * kBlock) {
+        size_t j, opos;
+        handover_map(ho, idx, j, opos);
         u32 acc[17];
 #pragma unroll
         for (int i = 0; i < 17; i++) acc[i] = 0;
@@ -273,7 +299,7 @@ __global__ void __launch_bounds__(kBlock) k_fold_flat(const void* __restrict__ f
         Fr o;
 #pragma unroll
         for (int i = 0; i < 8; i++) o.l[i] = v[i];
-        fr_store(fo, j, o);
+        fr_store(fo, opos, o);
     }
 }
 
@@ -286,7 +312,7 @@ __global__ void __launch_bounds__(kBlock) k_fold_flat(const void* __restrict__ f
 static constexpr int kW9Bytes = 48;  // 9 limbs + 3 words of padding
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_plain_flat(const void* __restrict__ f, void* __restrict__ fo, size_t m, FlatW w,
-                                                      void* __restrict__ partials) {
+                                                      void* __restrict__ partials, Handover ho) {
     constexpr int E = 1 << K;
     const size_t q = m >> K;
     u32 cs[E][9];
@@ -294,7 +320,9 @@ __global__ void __launch_bounds__(kBlock) k_plain_flat(const void* __restrict__ 
     for (int s = 0; s < E; s++)
 #pragma unroll
         for (int i = 0; i < 9; i++) cs[s][i] = 0;
-    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < q; j += (size_t)gridDim.x * kBlock) {
+    for (size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x; idx < q; idx += (size_t)gridDim.x * kBlock) {
+        size_t j, opos;
+        handover_map(ho, idx, j, opos);
         u32 acc[17];
 #pragma unroll
         for (int i = 0; i < 17; i++) acc[i] = 0;
@@ -316,7 +344,7 @@ __global__ void __launch_bounds__(kBlock) k_plain_flat(const void* __restrict__ 
         Fr o;
 #pragma unroll
         for (int i = 0; i < 8; i++) o.l[i] = v[i];
-        fr_store(fo, j, o);
+        fr_store(fo, opos, o);
     }
     // one 288-bit partial per wave and column: [S * 4 gridDim + 4 block + wave], 48-byte slots
     const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -443,7 +471,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
                                                        int elog, int rounds, TailChal chal, void* __restrict__ sums,
                                                        void* __restrict__ qbase, void* __restrict__ fo, void* __restrict__ go,
                                                        ReducePlan plan, void* __restrict__ red_out, void* __restrict__ red_wide,
-                                                       int t1mode, int xcd_map, int pre, unsigned long long* __restrict__ ts) {
+                                                       int t1mode, int xcd_map, int pre, int tr, unsigned long long* __restrict__ ts) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     extern __shared__ uint4 lds[];
@@ -475,6 +503,9 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
     // pass less per call from 2^18 on).  r0 = rounds of the stage before LDS level 0.
     const int r0 = pre ? 1 : 0;
     const int grp = tid >> 5, l32 = tid & 31;
+    // element t of this workgroup's slice: cyclic in a linear table, contiguous when the pass before stored slices (struct Handover)
+    const size_t sl_base = tr ? (size_t)w * ((size_t)E << r0) : (size_t)w, sl_step = tr ? 1 : (size_t)G;
+#define ZK_SLICE(t) (sl_base + sl_step * (size_t)(t))
     uint4* presc = park + (MODE == 1 ? 6 * (size_t)(E - (E >> rounds)) : 0);  // 64 Fr: group partials of the pre-round
     if (pre) {
         const Fr r = fr_load(chal.c, 0);
@@ -482,8 +513,8 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         if (TWO) {
             const unsigned role = tid >> elog, p = tid & (E - 1);  // role 0: f and t0 (t1), role 1: g and t2
             if (role < 2) {
-                const Fr flo = fr_load(f, w + (size_t)G * p), fhi = fr_load(f, w + (size_t)G * (p + E));
-                const Fr glo = fr_load(g, w + (size_t)G * p), ghi = fr_load(g, w + (size_t)G * (p + E));
+                const Fr flo = fr_load(f, ZK_SLICE(p)), fhi = fr_load(f, ZK_SLICE(p + E));
+                const Fr glo = fr_load(g, ZK_SLICE(p)), ghi = fr_load(g, ZK_SLICE(p + E));
                 if (role == 0) {
                     fr_store(tf, p, fr_add(flo, fr_mul(r, fr_sub(fhi, flo))));
                     pa = fr_mul(flo, glo);
@@ -495,7 +526,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
                 }
             }
         } else if (tid < E) {
-            const Fr lo = fr_load(f, w + (size_t)G * tid), hi = fr_load(f, w + (size_t)G * (tid + E));
+            const Fr lo = fr_load(f, ZK_SLICE(tid)), hi = fr_load(f, ZK_SLICE(tid + E));
             const Fr d = fr_sub(hi, lo);
             if (MODE == 3) fr_store(qbase, w + (size_t)G * tid, d);
             fr_store(tf, tid, fr_add(lo, fr_mul(r, d)));
@@ -515,8 +546,8 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         }
     } else {
         for (unsigned t = tid; t < E; t += kLocalThreads) {
-            fr_store(tf, t, fr_load(f, w + (size_t)G * t));
-            if (TWO) fr_store(tg, t, fr_load(g, w + (size_t)G * t));
+            fr_store(tf, t, fr_load(f, ZK_SLICE(t)));
+            if (TWO) fr_store(tg, t, fr_load(g, ZK_SLICE(t)));
         }
     }
     __syncthreads();
@@ -612,6 +643,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
     ZK_TS();
     if (ts && blockIdx.x == 0 && tid == 0) ts[31] = tsn;
 #undef ZK_TS
+#undef ZK_SLICE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -635,7 +667,7 @@ static size_t pass_blocks(zk_ctx* ctx, size_t m, int k, int mode) {
 }
 template <int K, int MODE>
 static int launch_pass(zk_ctx* ctx, hipStream_t st, const void* f, const void* g, void* fo, void* go, size_t m, const uint64_t* chal, void* partials,
-                       void* qbase, int t1mode) {
+                       void* qbase, int t1mode, Handover ho) {
     constexpr int W = ModeTraits<MODE>::W;
     const size_t blocks = pass_blocks(ctx, m, K, MODE);
     ChalArgs ch;
@@ -646,13 +678,13 @@ static int launch_pass(zk_ctx* ctx, hipStream_t st, const void* f, const void* g
     if constexpr (MODE == 1) {
         if (t1mode == 2) {  // test switch: t1 of every round on the device
             hipLaunchKernelGGL((k_pass<K, MODE, true>), dim3((unsigned)blocks), dim3(kBlock), lds, st, f, g, fo, go, m, ch, partials,
-                               qbase, t1mode);
+                               qbase, t1mode, ho);
             ZK_HIP(ctx, hipGetLastError());
             return ZK_OK;
         }
     }
     hipLaunchKernelGGL((k_pass<K, MODE>), dim3((unsigned)blocks), dim3(kBlock), lds, st, f, g, fo, go, m, ch, partials,
-                       qbase, t1mode);
+                       qbase, t1mode, ho);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -841,7 +873,8 @@ static size_t flat_blocks(zk_ctx* ctx, size_t m, int K, bool plain = false) {
     return blocks > maxb ? maxb : blocks;
 }
 // partials == nullptr: fold only (k_fold_flat); else the plain sumcheck's pass (k_plain_flat, K <= 3)
-static int launch_fold_flat(zk_ctx* ctx, hipStream_t st, const void* f, void* fo, size_t m, int K, const uint64_t* chal, void* partials = nullptr) {
+static int launch_fold_flat(zk_ctx* ctx, hipStream_t st, const void* f, void* fo, size_t m, int K, const uint64_t* chal, void* partials = nullptr,
+                            Handover ho = Handover()) {
     using namespace hfr;
     FlatW fw;
     std::memset(&fw, 0, sizeof(fw));
@@ -862,17 +895,17 @@ static int launch_fold_flat(zk_ctx* ctx, hipStream_t st, const void* f, void* fo
     for (size_t S = 0; S < w.size(); S++) std::memcpy(&fw.w[S], &w[S], 32);
     const size_t blocks = flat_blocks(ctx, m, K, partials != nullptr);
     if (partials) {
-        if (K == 3) hipLaunchKernelGGL((k_plain_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials);
-        else if (K == 2) hipLaunchKernelGGL((k_plain_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials);
-        else if (K == 1) hipLaunchKernelGGL((k_plain_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials);
+        if (K == 3) hipLaunchKernelGGL((k_plain_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials, ho);
+        else if (K == 2) hipLaunchKernelGGL((k_plain_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials, ho);
+        else if (K == 1) hipLaunchKernelGGL((k_plain_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, partials, ho);
         else return fail(ctx, ZK_ERR_INVALID, "internal: flat plain pass of %d rounds", K);
         ZK_HIP(ctx, hipGetLastError());
         return ZK_OK;
     }
-    if (K == 4) hipLaunchKernelGGL((k_fold_flat<4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw);
-    else if (K == 3) hipLaunchKernelGGL((k_fold_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw);
-    else if (K == 2) hipLaunchKernelGGL((k_fold_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw);
-    else hipLaunchKernelGGL((k_fold_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw);
+    if (K == 4) hipLaunchKernelGGL((k_fold_flat<4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, ho);
+    else if (K == 3) hipLaunchKernelGGL((k_fold_flat<3>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, ho);
+    else if (K == 2) hipLaunchKernelGGL((k_fold_flat<2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, ho);
+    else hipLaunchKernelGGL((k_fold_flat<1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, f, fo, m, fw, ho);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -900,7 +933,7 @@ static void derive_t1(uint64_t* sums, const uint64_t* chal, size_t rounds) {
 
 template <int MODE>
 static int launch_local(zk_ctx* ctx, hipStream_t st, const void* f, const void* g, unsigned G, unsigned E, int pre, int rl, const uint64_t* chal, void* sums,
-                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out, void* red_wide, int t1mode, bool want_ts) {
+                        void* qb, void* fo, void* go, const ReducePlan* rp, void* red_out, void* red_wide, int t1mode, bool want_ts, int tr = 0) {
     constexpr int W = ModeTraits<MODE>::W;
     constexpr bool TWO = ModeTraits<MODE>::TWO;
     TailChal tc;
@@ -919,7 +952,7 @@ static int launch_local(zk_ctx* ctx, hipStream_t st, const void* f, const void* 
     // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_local<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(kLocalThreads), lds, st, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
-                       rp ? *rp : none, red_out, red_wide, t1mode, sc_xcd_map(), pre, want_ts ? sc_ts_next() : nullptr);
+                       rp ? *rp : none, red_out, red_wide, t1mode, sc_xcd_map(), pre, tr, want_ts ? sc_ts_next() : nullptr);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -934,6 +967,7 @@ struct ScStage {
     size_t m, blocks, part_off;
     unsigned G, E;
     int pre;
+    Handover ho;  // pass: how it stores its output; local stage: how its input is stored (G == 0: linear)
 };
 struct ScColStage {
     size_t done, k, base;
@@ -1014,6 +1048,16 @@ static int sc_plan(zk_ctx* ctx, ScCall& c) {
         dd += st.k;
     }
     if ((int)c.plan.size() > ReducePlan::kMax) return fail(ctx, ZK_ERR_INVALID, "internal: too many passes");
+    // a pass followed by a multi-workgroup local stage stores that stage's slices contiguously (struct Handover)
+    if (tuning().sc_handover)
+        for (size_t i = 0; i + 1 < c.plan.size(); i++) {
+            ScStage &a = c.plan[i], &b = c.plan[i + 1];
+            const unsigned S = b.E << b.pre;
+            if (a.kind == 0 && b.kind == 1 && b.G >= 16 && (b.G & 15) == 0 && (S & 15) == 0 && (size_t)b.G * S == b.m) {
+                a.ho.G = b.ho.G = b.G;
+                a.ho.S = b.ho.S = S;
+            }
+        }
     c.part_bytes = W != 0 ? part_bytes : 0;
     for (size_t& b : c.buf_bytes) b = 0;
     if (!c.plan.empty()) {
@@ -1066,12 +1110,12 @@ static int sc_enqueue(zk_ctx* ctx, ScCall& c) {
         void* part = d_part ? d_part + st.part_off : nullptr;
         int rc;
         const int t1mode = !derive ? 2 : (done == 0 ? 1 : 0);  // t1 on the device: 2 every round, 1 the stage's first round only, 0 never
-        if (st.kind == 1) rc = launch_local<MODE>(ctx, st_, cf, cg, st.G, st.E, st.pre, k - st.pre, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode, c.want_ts);
-        else if (MODE == 2 && sc_flat_k()) rc = launch_fold_flat(ctx, st_, cf, fo, m, k, h_chal + 4 * done);
-        else if (c.plain_flat) rc = launch_fold_flat(ctx, st_, cf, fo, m, k, h_chal + 4 * done, part);
-        else if (k == 3) rc = launch_pass<3, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
-        else if (k == 2) rc = launch_pass<2, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
-        else rc = launch_pass<1, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode);
+        if (st.kind == 1) rc = launch_local<MODE>(ctx, st_, cf, cg, st.G, st.E, st.pre, k - st.pre, h_chal + 4 * done, part, qb, fo, go, nullptr, nullptr, nullptr, t1mode, c.want_ts, st.ho.G != 0);
+        else if (MODE == 2 && sc_flat_k()) rc = launch_fold_flat(ctx, st_, cf, fo, m, k, h_chal + 4 * done, nullptr, st.ho);
+        else if (c.plain_flat) rc = launch_fold_flat(ctx, st_, cf, fo, m, k, h_chal + 4 * done, part, st.ho);
+        else if (k == 3) rc = launch_pass<3, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode, st.ho);
+        else if (k == 2) rc = launch_pass<2, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode, st.ho);
+        else rc = launch_pass<1, MODE>(ctx, st_, cf, cg, fo, go, m, h_chal + 4 * done, part, qb, t1mode, st.ho);
         if (rc) return rc;
         if (W != 0) {  // outputs of this stage: sums of rounds done .. done+k-1, consecutive in d_res
             const bool wide = MODE == 1 && st.kind == 0;
