@@ -14,6 +14,9 @@ for n in 12 16 20; do python tools/hyperplonk_bench.py --n $n --party-threads | 
 python tools/g2_time.py 17 0 > gpurun_out/${T}_g2.txt 2>&1
 python tools/cpermcheck_time.py 20 3 > gpurun_out/${T}_cpermcheck.jsonl 2>&1
 python tools/sc_batch_time.py 18 > gpurun_out/${T}_sc_batch.txt 2>&1
-export ZK_BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 ZK_BENCH_DEADLINE_S=600
-for N in 2 8; do python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29610+N)) bench.py --gpus $N --steps 3 --warmup 1 --no-cpu 2>gpurun_out/${T}_gloo$N.err | tail -1; done > gpurun_out/${T}_bench_gloo_ranks_sharing_one_gpu.jsonl
+# N > 1 exactly as the driver launches it (`python bench.py --gpus N`, no launcher): functional runs on the one GPU of the box
+export HSA_ENABLE_IPC_MODE_LEGACY=0 ZK_BENCH_DEADLINE_S=600
+for N in 2 8; do ZK_BENCH_BACKEND=gloo python bench.py --gpus $N --steps 3 --warmup 1 --no-cpu 2>gpurun_out/${T}_gloo$N.err | tail -1; done > gpurun_out/${T}_bench_gloo_ranks_sharing_one_gpu.jsonl
+ZK_BENCH_BACKEND=local python bench.py --gpus 8 --party-threads --steps 3 --warmup 1 --no-cpu 2>gpurun_out/${T}_threads8.err | tail -1 > gpurun_out/${T}_bench_party_threads_sharing_one_gpu.jsonl
+python bench.py --gpus 2 --no-cpu 2>/dev/null | tail -1 > gpurun_out/${T}_bench_gpus2_on_a_one_gpu_box_error_line.json
 tail -3 gpurun_out/${T}_e2e.jsonl; cat gpurun_out/${T}_g2.txt
