@@ -37,6 +37,10 @@
 #include <thread>
 #include <vector>
 
+// This file is compiled TWICE (csrc/Makefile): once as it is -- the G1 pipeline and every non-templated entry point -- and once with
+// -DZK_MSM_TU_G2, which keeps only what instantiates the templates over CvG2 (msm_g2_batch, the G2 window-table kernel, the G2
+// test hook).  The two translation units build in parallel (the Fq2 kernels are more than half of the compile time); kernels that
+// are not templates are `static`, so each unit carries its own copy of the few it launches.
 namespace zk {
 
 static constexpr int kBlk = 256;
@@ -164,6 +168,7 @@ static constexpr int kFullBits = 256;  // 255-bit scalar + carry (precomputed-ta
 // measured optimum follows log2(n) - 3, log2(n) - 2 below 2^16 (sweeps in tools/sweep_msm.py); from 2^22 on 19 bits (7 windows
 // instead of 8) saves more bucket additions (10 Fq-mul each, 2n per window) than the ~4x larger bucket
 // reduction (3 x 14 Fq-mul per bucket) costs.
+#ifndef ZK_MSM_TU_G2  // (G1 translation unit only)
 int msm_pick_window(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
@@ -173,6 +178,7 @@ int msm_pick_window(size_t n) {
     if (c > 17) c = 17;
     return c;
 }
+#endif
 // 256-bit layout of the precomputed-table mode: ONE bucket set for all ceil(256 / c) digits of a scalar, so the window
 // can be as wide as the bucket reduction of 2^(c-1) buckets allows.  Measured optimum (tools/sweep_pre.py, MI355X):
 // log2 n + 2 up to 2^15 points, 17 bits for 2^16..2^18 (one more bit doubles the narrow-row fix-up), log2 n - 1 from 2^19.
@@ -330,7 +336,7 @@ __device__ __forceinline__ void recode_windows(u32 (&s)[NL], const WinLayout& L,
 // rows are written for the windows [w0, w0 + wc) only (a class may cover a sub-range of the windows);
 // the lower windows are still walked for the carry of the signed recoding.
 // endo: row = [k1 digits of the ns points | k2 digits of the ns points] (entry ns + i refers to phi(P_i)).
-__global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ items, size_t ns, WinLayout L, int w0, int wc, int endo,
+static __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restrict__ items, size_t ns, WinLayout L, int w0, int wc, int endo,
                                                u32* __restrict__ digits_all) {
     const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (i >= ns) return;
@@ -373,7 +379,7 @@ static constexpr int kSortThreads = 1024;
 static constexpr u32 kMaxParts = 1024;
 static constexpr u32 kMaxLow = 2048;  // buckets per partition (nb / np), nb <= 2^19
 
-__global__ void __launch_bounds__(kSortThreads) k_part_hist(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
+static __global__ void __launch_bounds__(kSortThreads) k_part_hist(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
                                                           u32 np, int low_bits, u32* __restrict__ hist) {
     __shared__ u32 cnt[kMaxParts];
     const u32 chunk = blockIdx.x % nchunks, row = blockIdx.x / nchunks;
@@ -411,7 +417,7 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* sh, u32* total) 
 }
 
 static constexpr int kScanThreads = 1024;  // >= kMaxParts (k_part_bases scans one row's partitions in a block)
-__global__ void __launch_bounds__(kScanThreads) k_part_scan(u32* __restrict__ hist, u32 nchunks, u32* __restrict__ total) {
+static __global__ void __launch_bounds__(kScanThreads) k_part_scan(u32* __restrict__ hist, u32 nchunks, u32* __restrict__ total) {
     __shared__ u32 sh[kScanThreads];
     u32* h = hist + (size_t)blockIdx.x * nchunks;  // blockIdx.x = row * np + p
     u32 carry = 0;
@@ -425,7 +431,7 @@ __global__ void __launch_bounds__(kScanThreads) k_part_scan(u32* __restrict__ hi
     }
     if (threadIdx.x == 0) total[blockIdx.x] = carry;
 }
-__global__ void __launch_bounds__(kScanThreads) k_part_bases(const u32* __restrict__ total, u32 np, u32* __restrict__ base,
+static __global__ void __launch_bounds__(kScanThreads) k_part_bases(const u32* __restrict__ total, u32 np, u32* __restrict__ base,
                                                            u32* __restrict__ rowtot) {
     __shared__ u32 sh[kScanThreads];
     const u32 row = blockIdx.x;
@@ -436,7 +442,7 @@ __global__ void __launch_bounds__(kScanThreads) k_part_bases(const u32* __restri
     if (threadIdx.x == 0) rowtot[row] = all;
 }
 
-__global__ void __launch_bounds__(kSortThreads) k_part_scatter(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
+static __global__ void __launch_bounds__(kSortThreads) k_part_scatter(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
                                                              u32 np, int low_bits, const u32* __restrict__ hist,
                                                              const u32* __restrict__ base, int idx_bits, u32* __restrict__ part_idx,
                                                              unsigned short* __restrict__ part_low) {
@@ -476,7 +482,7 @@ __global__ void __launch_bounds__(kSortThreads) k_part_scatter(const u32* __rest
 // 4-byte store per lane into np different streams.  Used for long rows, where the open store streams of
 // all resident workgroups no longer fit the L2 (measured at 2^24: 4.0 ms -> see DESIGN.md).
 static constexpr u32 kStageChunk = 16384;
-__global__ void __launch_bounds__(kSortThreads) k_part_scatter_staged(const u32* __restrict__ digits, size_t row_len, size_t chunk_len,
+static __global__ void __launch_bounds__(kSortThreads) k_part_scatter_staged(const u32* __restrict__ digits, size_t row_len, size_t chunk_len,
                                                                     u32 nchunks, u32 np, int low_bits, const u32* __restrict__ hist,
                                                                     const u32* __restrict__ base, int idx_bits,
                                                                     u32* __restrict__ part_idx, unsigned short* __restrict__ part_low) {
@@ -539,7 +545,7 @@ __global__ void __launch_bounds__(kSortThreads) k_part_scatter_staged(const u32*
 }
 
 // launched with 1024 threads for long partitions, 256 for short ones (fewer barrier steps in the scan)
-__global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restrict__ part_idx, const unsigned short* __restrict__ part_low,
+static __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restrict__ part_idx, const unsigned short* __restrict__ part_low,
                                                               size_t row_len, u32 np, int low_bits, int idx_bits, size_t nb,
                                                               const u32* __restrict__ base, const u32* __restrict__ rowtot,
                                                               uint2* __restrict__ oc, u32 T, size_t tiles_per_w, u32* __restrict__ tile_b,
@@ -597,7 +603,7 @@ __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __restric
 // the tile boundary go to heads[] / tails[] and are stitched by k_fixup.
 // ---------------------------------------------------------------------------------------
 template <class Cv>
-__global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict__ items, int rows_per_item,
+static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __restrict__ items, int rows_per_item,
                                                     const u32* __restrict__ sorted, const uint2* __restrict__ oc_all,
                                                     const u32* __restrict__ tile_b, size_t ns, u32 nsi, int nsi_shift, size_t nb, u32 T,
                                                     size_t tiles_per_w, size_t total_tiles, void* __restrict__ buckets,
@@ -669,7 +675,7 @@ struct NarrowRows {
 // span more than kLongSpan tiles (skewed scalars: many equal digits) are queued for k_fixup_long.
 static constexpr u32 kLongSpan = 24;
 template <class Cv>
-__global__ void __launch_bounds__(kBlk) k_fixup(const uint2* __restrict__ oc, size_t nb, NarrowRows nr, u32 T,
+static __global__ void __launch_bounds__(kBlk) k_fixup(const uint2* __restrict__ oc, size_t nb, NarrowRows nr, u32 T,
                                               size_t tiles_per_w, size_t total, void* __restrict__ buckets,
                                               const void* __restrict__ heads, const void* __restrict__ tails,
                                               u32* __restrict__ long_count, u32* __restrict__ long_list) {
@@ -701,7 +707,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup(const uint2* __restrict__ oc, si
 // the same with one bucket per QUAD of lanes (small and mid-size MSMs: the chain of dependent additions
 // is pure latency, a quad runs each in 4 multiplication rounds instead of 13)
 template <class Cv>
-__global__ void __launch_bounds__(kBlk) k_fixup_quad(const uint2* __restrict__ oc, size_t nb, NarrowRows nr, u32 T,
+static __global__ void __launch_bounds__(kBlk) k_fixup_quad(const uint2* __restrict__ oc, size_t nb, NarrowRows nr, u32 T,
                                                    size_t tiles_per_w, size_t total, void* __restrict__ buckets,
                                                    const void* __restrict__ heads, const void* __restrict__ tails,
                                                    u32* __restrict__ long_count, u32* __restrict__ long_list) {
@@ -732,7 +738,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup_quad(const uint2* __restrict__ o
 
 // one workgroup per long bucket: strided partial sums per lane, then an LDS tree
 template <class Cv>
-__global__ void __launch_bounds__(kBlk) k_fixup_long(const uint2* __restrict__ oc, size_t nb, u32 T,
+static __global__ void __launch_bounds__(kBlk) k_fixup_long(const uint2* __restrict__ oc, size_t nb, u32 T,
                                                    size_t tiles_per_w, void* __restrict__ buckets, const void* __restrict__ heads,
                                                    const void* __restrict__ tails, const u32* __restrict__ long_count,
                                                    const u32* __restrict__ long_list) {
@@ -767,7 +773,7 @@ __global__ void __launch_bounds__(kBlk) k_fixup_long(const uint2* __restrict__ o
 
 // one bit-plane pass of the bucket reduction.  in: [W][rows][len], out: [W][rows+1][len/2]
 template <class Cv>
-__global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len, NarrowRows nr) {
+static __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len, NarrowRows nr) {
     const size_t half = len >> 1;
     const size_t per_w = (size_t)(rows + 1) * half;
     const size_t t = (size_t)blockIdx.x * kBlk + threadIdx.x;
@@ -795,7 +801,7 @@ __global__ void __launch_bounds__(kBlk) k_halve(const void* __restrict__ in, voi
 // the same pass with one addition per QUAD of lanes (curve30.cuh: xyzz30_add_quad; curve30_g2.cuh: xyzz2_add_quad): for the
 // late passes, which are a single dependent addition of pure latency, this cuts the chain from 13 multiplications to 4
 template <class Cv>
-__global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len,
+static __global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in, void* __restrict__ out, int W, int rows, size_t len,
                                                    NarrowRows nr) {
     const size_t tq = (size_t)blockIdx.x * kBlk + threadIdx.x;
     const size_t half = len >> 1;
@@ -831,7 +837,7 @@ __global__ void __launch_bounds__(kBlk) k_halve_quad(const void* __restrict__ in
 // device chain (measured: a wash at 2^20).
 // in: [rows][c] XYZZ, out: [rows][nout] Jacobian; nout = c, or max(1, c/2) when pairing.
 template <class Cv>
-__global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void* __restrict__ out, size_t rows, int c, int nout, int pair) {
+static __global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void* __restrict__ out, size_t rows, int c, int nout, int pair) {
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= rows * (size_t)nout) return;
     const size_t row = t / nout;
@@ -852,7 +858,7 @@ __global__ void __launch_bounds__(64) k_finish(const void* __restrict__ in, void
 // SRS precomputation: table[w][i] = 2^{bit_offset(w)} * P_i (affine records), one lane per point.
 // With it every window's digit can use the SAME bucket set (the factor 2^{c w} is in the base).
 template <class Cv>
-__global__ void __launch_bounds__(Cv::kEndo ? kBlk : 64) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
+static __global__ void __launch_bounds__(Cv::kEndo ? kBlk : 64) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
                                                                        void* __restrict__ table) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -868,7 +874,7 @@ __global__ void __launch_bounds__(Cv::kEndo ? kBlk : 64) k_precompute(const void
 }
 
 // SRS format conversion: reference Montgomery form (x * 2^384) <-> internal (x * 2^390), in place or copy
-__global__ void __launch_bounds__(kBlk) k_srs_convert(const void* __restrict__ in, void* __restrict__ out, size_t ncoord, int to_internal) {
+static __global__ void __launch_bounds__(kBlk) k_srs_convert(const void* __restrict__ in, void* __restrict__ out, size_t ncoord, int to_internal) {
     for (size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x; i < ncoord; i += (size_t)gridDim.x * kBlk) {
         Fq30 v = f30_load(in, i * 48);
         f30_store(out, i * 48, to_internal ? f30_from_ref(v) : f30_to_ref(v));
@@ -876,7 +882,7 @@ __global__ void __launch_bounds__(kBlk) k_srs_convert(const void* __restrict__ i
 }
 
 // second half of the device SRS: phi(P_i) = (beta * x_i, y_i) (infinity stays infinity: beta * 0 = 0)
-__global__ void __launch_bounds__(kBlk) k_srs_endo(void* __restrict__ bases, size_t n) {
+static __global__ void __launch_bounds__(kBlk) k_srs_endo(void* __restrict__ bases, size_t n) {
     Fq30 beta;
     {
         constexpr u32 t[13] = {0x1c907181u, 0x3cbde486u, 0x26574c3eu, 0x332475ecu, 0x1c3ebc1bu, 0x39ee6864u, 0x16ffa856u,
@@ -891,8 +897,9 @@ __global__ void __launch_bounds__(kBlk) k_srs_endo(void* __restrict__ bases, siz
     }
 }
 
+#ifndef ZK_MSM_TU_G2  // (G1 translation unit only)
 // test hooks: field ops on reference-form Fq vectors through the production (unsaturated) arithmetic
-__global__ void __launch_bounds__(kBlk) k_dbg_fq(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ out, size_t n,
+static __global__ void __launch_bounds__(kBlk) k_dbg_fq(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ out, size_t n,
                                                int op) {
     for (size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlk) {
         Fq30 x = f30_from_ref(f30_load(a, i * 48)), y = f30_from_ref(f30_load(b, i * 48));
@@ -902,7 +909,7 @@ __global__ void __launch_bounds__(kBlk) k_dbg_fq(const void* __restrict__ a, con
 }
 
 // test hook: XYZZ arithmetic on pairs of affine points
-__global__ void __launch_bounds__(kBlk) k_dbg_g1(const void* __restrict__ p, const void* __restrict__ q, void* __restrict__ out,
+static __global__ void __launch_bounds__(kBlk) k_dbg_g1(const void* __restrict__ p, const void* __restrict__ q, void* __restrict__ out,
                                                size_t n, int mode) {
     const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
     if (i >= n) return;
@@ -927,9 +934,11 @@ __global__ void __launch_bounds__(kBlk) k_dbg_g1(const void* __restrict__ p, con
     xyzz30_store_flat(out, i, r);
 }
 
+#endif
+#ifdef ZK_MSM_TU_G2  // (G2 translation unit only)
 // test hook: the G2 formulas on pairs of affine points (reference form, 192 B); output through CvG2::finish (288 B Jacobian)
 // mode 0: p + q   1: (p + q) + p   2: (p + q) + (p + q)   3: p - q   4: 2 (p + q) by the doubling   5: (p + q) - (p + q)
-__global__ void __launch_bounds__(64) k_dbg_g2(const void* __restrict__ p, const void* __restrict__ q, void* __restrict__ out, size_t n, int mode) {
+static __global__ void __launch_bounds__(64) k_dbg_g2(const void* __restrict__ p, const void* __restrict__ q, void* __restrict__ out, size_t n, int mode) {
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     Aff2 a, b;
@@ -959,6 +968,7 @@ __global__ void __launch_bounds__(64) k_dbg_g2(const void* __restrict__ p, const
     CvG2::finish(r, out, i);
 }
 
+#endif
 // ---------------------------------------------------------------------------------------
 // device XYZZ (internal Montgomery form 2^390, coordinates < 8q) -> host Jacobian in the reference form:
 // one host multiplication by 2^-6 per coordinate (K = 2^378 mod q = the 2^384-form of 2^-6)
@@ -1058,11 +1068,13 @@ static HostPool* host_pool(zk_ctx* ctx) {
     if (!ctx->host_pool) ctx->host_pool = new HostPool(std::min(64u, std::max(2u, std::thread::hardware_concurrency() / 2)));
     return (HostPool*)ctx->host_pool;
 }
+#ifndef ZK_MSM_TU_G2  // (G1 translation unit only)
 void msm_host_pool_destroy(zk_ctx* ctx) {
     delete (HostPool*)ctx->host_pool;
     ctx->host_pool = nullptr;
 }
 
+#endif
 struct MsmClass {
     bool shared = false;  // precomputed-table mode: one bucket row per item spanning all windows
     int rpi = 0;          // bucket rows per item (the class's windows, or 1 when shared)
@@ -1127,6 +1139,7 @@ static int msm_lane_prepare(zk_ctx* ctx, int lane) {
     L.ready = true;
     return ZK_OK;
 }
+#ifndef ZK_MSM_TU_G2  // (G1 translation unit only)
 void msm_lanes_destroy(zk_ctx* ctx) {
     for (int i = 0; i < zk_ctx::kLanes; i++) {
         zk_ctx::MsmLane& L = ctx->lanes[i];
@@ -1151,6 +1164,7 @@ void msm_lanes_destroy(zk_ctx* ctx) {
     }
 }
 
+#endif
 template <class Cv>
 static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
     const MsmItem* items = run.items.data();
@@ -1609,10 +1623,21 @@ static int msm_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* 
     return msm_finish<Cv>(ctx, run, h_out);
 }
 
+#ifndef ZK_MSM_TU_G2
 int msm_g1_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) { return msm_batch<CvG1>(ctx, items, count, h_out); }
+#else
 int msm_g2_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_out) { return msm_batch<CvG2>(ctx, items, count, h_out); }
+// the G2 half of srs_precompute: table[w][i] = 2^{bit_offset(w)} P_i for a G2 level
+int srs_precompute_table_g2(zk_ctx* ctx, const zk_srs* srs, int c, size_t nsr, void* d_table) {
+    const WinLayout L = msm_layout(c, kFullBits);
+    hipLaunchKernelGGL((k_precompute<CvG2>), dim3((unsigned)((srs->n + 63) / 64)), dim3(64), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr, L, d_table);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+#endif
 
 }  // namespace zk
+#ifndef ZK_MSM_TU_G2  // (G1 translation unit only: asynchronous jobs, SRS handling, host combinations, G1 test hooks)
 struct zk_msm_job {
     zk::MsmRun run;
 };
@@ -1796,6 +1821,7 @@ static int msm_pick_window_full_g2(size_t n) {
     return std::max(4, std::min(20, c));
 }
 
+int srs_precompute_table_g2(zk_ctx* ctx, const zk_srs* srs, int c, size_t nsr, void* d_table);  // zk_msm.hip built with -DZK_MSM_TU_G2
 int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     if (!srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
     if (c == 0) c = srs->g2 ? msm_pick_window_full_g2(srs->n ? srs->n : 1) : msm_pick_window_full(srs->n ? srs->n : 1);
@@ -1812,12 +1838,13 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     const size_t rec = srs->g2 ? CvG2::kAffBytes : CvG1::kAffBytes;
     ZK_HIP(ctx, device_alloc(ctx, &srs->d_table, (size_t)L.W * nsr * rec));
     ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * rec, ctx->stream));
-    if (srs->g2)
-        hipLaunchKernelGGL((k_precompute<CvG2>), dim3((unsigned)((srs->n + 63) / 64)), dim3(64), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr, L,
-                           srs->d_table);
-    else
+    if (srs->g2) {
+        const int rc = srs_precompute_table_g2(ctx, srs, c, nsr, srs->d_table);  // (the other translation unit)
+        if (rc) return rc;
+    } else {
         hipLaunchKernelGGL((k_precompute<CvG1>), dim3((unsigned)((srs->n + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr,
                            L, srs->d_table);
+    }
     ZK_HIP(ctx, hipGetLastError());
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     srs->table_c = c;
@@ -1995,6 +2022,8 @@ int dbg_g1_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, 
     return ZK_OK;
 }
 
+#else
+namespace zk {
 int dbg_g2_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, size_t n) {
     if (n == 0) return ZK_OK;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
@@ -2014,5 +2043,6 @@ int dbg_g2_op(zk_ctx* ctx, int mode, const void* p, const void* q, void* h_out, 
     }
     return ZK_OK;
 }
+#endif
 
 }  // namespace zk
