@@ -1009,7 +1009,21 @@ static int sc_plan(zk_ctx* ctx, ScCall& c) {
     const size_t len = c.len, rounds = c.rounds;
     const size_t emax = TWO ? kLocalMaxE / 2 : kLocalMaxE;  // table elements a workgroup holds in LDS
     c.emax = emax;
-    const int use_pre = tuning().sc_pre != 0;
+    int use_pre = tuning().sc_pre != 0;
+    // Single-table modes: the pre-round of the first local stage (its first round straight out of the table) saves a round of the
+    // HBM passes but is the dearer place for it when the passes are cheap flat sweeps: it pays when it spares a whole pass (or
+    // all of them), not when the round it takes over would ride in a pass that runs anyway.  Measured on MI355X (C ABI, us, pre /
+    // no pre): fold 2^20 53.9 / 50.9, 2^22 70.6 / 66.8, 2^24 162 / 157 but 2^19 40.4 / 47.3; plain 2^20 64.6 / 61.1 but 2^21
+    // 73.4 / 77.6, 2^24 222 / 228; open 2^20 58.0 / 54.4, 2^21 68.7 / 70.8.  Rule: no pre-round when the passes needed without it
+    // are as many as with it and the extra round lands in a fold pass (up to 4 rounds each) or in a pass of at most 2 rounds.
+    if (use_pre && MODE != 1 && tuning().sc_pre == 1 && rounds == (size_t)ilog2(len)) {
+        const int kmax = sc_pass_k(MODE);
+        const int lg = ilog2(len), base = ilog2(emax * sc_local_g());
+        const int need_pre = std::max(0, lg - (base + 1)), need_no = std::max(0, lg - base);  // rounds the passes must take
+        const int cnt_pre = (need_pre + kmax - 1) / kmax, cnt_no = (need_no + kmax - 1) / kmax;
+        const int last_no = need_no - (cnt_no - 1) * kmax;
+        if (need_pre > 0 && cnt_no == cnt_pre && (MODE == 2 || last_no <= 2)) use_pre = 0;
+    }
     const size_t local_max = emax * sc_local_g() * (use_pre ? 2 : 1);  // longest table handed to a local stage (x2: its pre-round)
     const size_t fr = 32;
     // result block: [sums rounds*W][last_f][last_g]
