@@ -346,37 +346,49 @@ def d_sumcheck_product(be, partial_f, partial_g, length: int, challenge: np.ndar
     return np.concatenate([head.reshape(-1, 3, 4), _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)])
 
 
-def d_sumcheck_product_many(be, items: Sequence, net: Net) -> List[np.ndarray]:
+def d_sumcheck_product_many_q(be, items: Sequence, net: Net):
     """
     several independent d_sumcheck_product (dsumcheck.rs:359-512); items = [(partial_f, partial_g, length, challenge)].
-    The local phases run as ONE batched call; the per-item gathers of the round tuples (:437) travel as ONE all-gather of
-    the concatenated payloads (same bytes, one exchange instead of len(items)); the leader part is unchanged per item.
+    The local phases run NOW as ONE batched call; -> closure that performs the exchange and the leader part: the per-item
+    gathers of the round tuples (:437) travel as ONE all-gather of the concatenated payloads (same bytes, one exchange instead
+    of len(items)), the leader rounds (:440-507, host arithmetic on a few hundred field elements) are unchanged per item.  A
+    protocol step calls the closure after it has started its MSM pass: the host work then runs beside the GPU's.
     """
     if not len(items):
-        return []
+        return lambda: []
     s = net.n_parties.bit_length() - 1
     ns = [length.bit_length() - 1 for _, _, length, _ in items]
     for (f, g, length, ch), n in zip(items, ns):
         _trace(be, "d", f, g, length, ch[: n + s])
     phase1 = _sc_batch(be, [("product", f, g, length, ch[:n]) for (f, g, length, ch), n in zip(items, ns)])
-    locals_ = [np.concatenate([tr, np.stack([lg, lf, ZERO])[None]]) for tr, lf, lg in phase1]  # marker (g, f, 0)  :433
-    cuts = np.cumsum([0] + [len(x) for x in locals_])
-    allp = net.all_gather(np.concatenate(locals_))  # [party][sum(n_i + 1), 3, 4]
-    if not net.is_leader:
-        return [np.zeros((0, 3, 4), dtype=np.uint64) for _ in items]
-    out = []
-    for k, ((_, _, _, challenge), n) in enumerate(zip(items, ns)):
-        mine = [np.asarray(allp[p])[cuts[k] : cuts[k + 1]] for p in range(net.n_parties)]
-        head = fr_sum_mont([m[:n] for m in mine])  # per-round sums (:440-447)
-        f = [fr_from_mont(m[n][1]) for m in mine]  # :448
-        g = [fr_from_mont(m[n][0]) for m in mine]  # :449
-        ch = _fr_vec_to_ints(challenge[n : n + s])
-        res = []
-        for i in range(s):
-            t, f, g = _round_product(f, g, ch[i])
-            res.append(t)
-        out.append(np.concatenate([head.reshape(-1, 3, 4), _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)]))
-    return out
+    chals = [np.array(ch, copy=True) for _, _, _, ch in items]
+
+    def fin():
+        locals_ = [np.concatenate([tr, np.stack([lg, lf, ZERO])[None]]) for tr, lf, lg in phase1]  # marker (g, f, 0)  :433
+        cuts = np.cumsum([0] + [len(x) for x in locals_])
+        allp = net.all_gather(np.concatenate(locals_))  # [party][sum(n_i + 1), 3, 4]
+        if not net.is_leader:
+            return [np.zeros((0, 3, 4), dtype=np.uint64) for _ in chals]
+        out = []
+        for k, (challenge, n) in enumerate(zip(chals, ns)):
+            mine = [np.asarray(allp[p])[cuts[k] : cuts[k + 1]] for p in range(net.n_parties)]
+            head = fr_sum_mont([m[:n] for m in mine])  # per-round sums (:440-447)
+            f = [fr_from_mont(m[n][1]) for m in mine]  # :448
+            g = [fr_from_mont(m[n][0]) for m in mine]  # :449
+            ch = _fr_vec_to_ints(challenge[n : n + s])
+            res = []
+            for i in range(s):
+                t, f, g = _round_product(f, g, ch[i])
+                res.append(t)
+            out.append(np.concatenate([head.reshape(-1, 3, 4), _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)]))
+        return out
+
+    return fin
+
+
+def d_sumcheck_product_many(be, items: Sequence, net: Net) -> List[np.ndarray]:
+    """several independent d_sumcheck_product (dsumcheck.rs:359-512) at once: the local phases as one batched call, one exchange"""
+    return d_sumcheck_product_many_q(be, items, net)()
 
 
 # ---------------------------------------------------------------------------------------

@@ -189,7 +189,8 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
         for k in cur:  # current = current[len/2..]
             cur[k] = _at(cur[k], 32 * (clen // 2))
         clen //= 2
-    wiring_proofs += dp.d_sumcheck_product_many(be, dsp_items, net)
+    # (local phases now; the exchange and the leader rounds -- host arithmetic -- in finalize(), beside the step's MSM pass)
+    f_dsp = dp.d_sumcheck_product_many_q(be, dsp_items, net)
     # the opens of local_s, of the five tables and of all layers are independent of each other
     f_dopen = dp.d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net)
     f_top_commits, f_top_opens, top_proofs = [], None, []
@@ -207,6 +208,7 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
         top_proofs.append(dp.sumcheck_product(be, eq_top, d0, len(lvx0), chs))
         top_proofs.append(dp.sumcheck_product(be, d0, dd1, len(lvx0), chs))
     def finalize():
+        wiring_proofs.extend(f_dsp())                  # 2.e: after 2.c, before the leader-tree sumchecks (the reference's order)
         wiring_opens.extend(f_copen())                 # 2.d
         wiring_commits.extend(list(f_dcommit()))       # 2.b, then :363-380
         wiring_opens.extend(f_dopen())

@@ -18,6 +18,9 @@ for r in rows[1:]:
     cur.append(r); end = max(end, r[1])
 segs.append(cur)
 print("segments (ms):", [round((max(x[1] for x in s) - s[0][0]) / 1e6, 1) for s in segs])
+for i in range(max(1, len(segs) - 4), len(segs)):
+    pe = max(x[1] for x in segs[i - 1])
+    print(f"   segment {i}: starts {(segs[i][0][0] - pe) / 1e6:.2f} ms after the previous one ended; previous ends with {[x[2][:24] for x in segs[i - 1][-3:]]}, this one starts with {[x[2][:24] for x in segs[i][:4]]}")
 s = segs[-1]
 t0, t1 = s[0][0], max(x[1] for x in s)
 busy, ce = 0, t0
@@ -25,6 +28,10 @@ gaps = []
 for a, b, nm in s:
     if a > ce: gaps.append((a - ce, nm))
     busy += max(0, b - max(a, ce)); ce = max(ce, b)
+ce2 = t0; prev = ''
+for a, b, nm in s:
+    if a > ce2 + 150e3: print(f"   gap {(a - ce2) / 1e3:7.0f} us at +{(ce2 - t0) / 1e6:6.2f} ms   after {prev[:34]:34s} before {nm[:34]}")
+    if b > ce2: ce2, prev = b, nm
 print(f"last proof: span {(t1 - t0) / 1e6:.2f} ms, GPU busy {busy / 1e6:.2f} ms ({100 * busy / (t1 - t0):.1f} %), {len(gaps)} gaps, largest:", [(round(g / 1e3), n[:30]) for g, n in sorted(gaps, reverse=True)[:8]])
 tot = defaultdict(float)
 for a, b, nm in s: tot[nm.split('<')[0]] += (b - a) / 1e6
