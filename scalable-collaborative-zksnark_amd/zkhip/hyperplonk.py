@@ -250,8 +250,9 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     # The MSM pass of a step is STARTED here and collected one step later (MsmQueue.start / finish): nothing consumes a
     # commitment before the proof is assembled (challenges are pre-sampled, :159-186), and the host part of a step -- the
     # exchanges of its results and the 8-term point combinations -- then runs while the GPU works on the next step's pass.
-    # The timer labels keep the reference's names; with the overlap "Commit" / "Wire identity" / "Open" each cover the
-    # enqueue of their own pass and the collection of the previous one, only "Distributed HyperPlonk" is a sum.
+    # The timer labels keep the reference's names; with the overlap "Commit" / "Wire identity" / "Open" no longer cover the reference's
+    # steps ("Wire identity" = the kernel phases of steps 2 and 4 and the enqueue of their passes, "Open" = the collection of both),
+    # only "Distributed HyperPlonk" is comparable.
     q.start()
 
     def finish_commit():
@@ -276,23 +277,27 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     # Step 2: wiring identity (shared with dpermcheck)
     tm.start("Wire identity")
     q_w, finalize_wiring = _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top)
+    # The kernel phase of the Open step (:517-553: fold rounds and quotients of a, b, c, I, S1, S2) depends on nothing the wiring step
+    # produces, so it runs BEFORE the wiring pass is started: behind a running pass its ~0.5 ms of kernels would wait for the pass to
+    # drain (they share the runtime's hardware queues), the Open pass could only be enqueued after that, and the GPU would idle between
+    # the two passes while the host prepares the second.  Both passes are now in flight back to back; outputs keep their positions.
+    gate_commitments = []
+    q_o = dp.MsmQueue(be)
+    f_co = dp.c_open_many_q(be, q_o, cc, [T[x] for x in names_c], [L[x] for x in names_c], [pk.challenge] * 3, pp, net)
+    f_do = dp.d_open_many_q(be, q_o, dc, [T[x] for x in names_d], [L[x] for x in names_d], [pk.challenge] * 3, net)
     q_w.start()
-    finish_commit()  # (host: exchange + point combinations of step 1, beside the wiring pass on the GPU)
+    q_o.start()
+    finish_commit()  # (host: exchange + point combinations of step 1, beside the passes on the GPU)
     tm.end()
 
-    # Open (:517-553)
+    # Open (:517-553): collection of both passes
     tm.start("Open")
-    gate_commitments = []
-    q = dp.MsmQueue(be)
-    f_c = dp.c_open_many_q(be, q, cc, [T[x] for x in names_c], [L[x] for x in names_c], [pk.challenge] * 3, pp, net)
-    f_d = dp.d_open_many_q(be, q, dc, [T[x] for x in names_d], [L[x] for x in names_d], [pk.challenge] * 3, net)
-    q.start()
     q_w.finish()
     wiring_proofs, wiring_commits, wiring_opens = finalize_wiring()
-    q.finish()
-    for name, op in zip(names_c, f_c()):
+    q_o.finish()
+    for name, op in zip(names_c, f_co()):
         gate_commitments.append((com[name], op))
-    for name, op in zip(names_d, f_d()):
+    for name, op in zip(names_d, f_do()):
         gate_commitments.append((com[name], op))
     tm.end()
     tm.end()
