@@ -709,8 +709,9 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 computed = (ref_count - (1 << (e_n + 1))) if ref_count else None
                 extra["e2e"] = {"n": e_n, "l": 1, "parties": 8, "mode": "leader (party 0's full work, no-comm echo net)" if world == 1 else f"8 parties = 8 ranks, exchanges: {type(e_net).__name__} ({backend})",
                                 "setup_s": setup_s, "timers_s": best,
-                                "timers_note": "the MSM pass of a step is started in its step and collected one step later (MsmQueue.start / finish): 'Commit' / 'Wire identity' / 'Open' "
-                                               "are OVERLAPPED sections, only the total is comparable with the reference's log; timers_s_serial_steps runs every pass inside its own step",
+                                "timers_note": "the MSM pass of a step is started asynchronously and collected later (MsmQueue.start / finish); the kernel phase of the Open step runs before the wiring "
+                                               "pass is started so that both passes are in flight back to back: 'Commit' / 'Wire identity' / 'Open' are OVERLAPPED sections that no longer cover the "
+                                               "reference's steps, only the total is comparable with the reference's log; timers_s_serial_steps runs every pass to completion where it is started",
                                 "timers_s_serial_steps": serial,
                                 "scalar_muls_per_proof_reference_count": ref_count,
                                 "scalar_muls_computed": computed,
