@@ -314,3 +314,43 @@ def test_msm_queue_merges_only_items_whose_owner_it_holds():
     gc.collect()
     assert wa() is None and ws() is None and 0x1000 in freed and 0x2000 in freed, "owners are released when the pass is over"
     assert q.index == {} and q2.scaled == {}
+
+
+def test_sumcheck_product_many_forms_equal_the_single_calls():
+    """c_sumcheck_product_many / d_sumcheck_product_many(_q) batch the local phases and (d_) defer the exchange to a closure: the
+    transcripts must be those of one call per item, i.e. of the all-parties restatement (dsumcheck.rs:148-285, 359-512)"""
+    pp, opp = PackedSharingParams(1), po.PackedSharingParams(1)
+    rng = po.SplitMix64(333)
+    W, s = pp.n, 3
+    items = [(3, rng.fr_vec(3 + s)), (2, rng.fr_vec(2 + s)), (3, rng.fr_vec(3 + s)), (0, rng.fr_vec(0 + s))]  # (log2 length, challenges)
+    pf = [[rng.fr_vec(1 << lg) for _ in range(W)] for lg, _ in items]
+    pg = [[rng.fr_vec(1 << lg) for _ in range(W)] for lg, _ in items]
+    cf = [rng.fr_vec(8) for _ in range(W)]
+    cg = [[rng.fr_vec(8) for _ in range(W)] for _ in range(2)]
+    cch = rng.fr_vec(3)
+    be = OracleBackend()
+
+    def party(net):
+        p = net.party_id
+        dev = lambda v: be.to_device(to_m(v))
+        d_items = [(dev(pf[k][p]), dev(pg[k][p]), 1 << lg, to_m(ch)) for k, (lg, ch) in enumerate(items)]
+        fin = dp.d_sumcheck_product_many_q(be, d_items, net)
+        many_c = dp.c_sumcheck_product_many(be, [(dev(cf[p]), dev(cg[0][p])), (dev(cf[p]), dev(cg[1][p]))], 8, to_m(cch), pp, net)  # another exchange in between
+        many_d = fin()
+        single_d = [dp.d_sumcheck_product(be, f, g, length, ch, net) for f, g, length, ch in d_items]
+        single_c = [dp.c_sumcheck_product(be, dev(cf[p]), dev(cg[k][p]), 8, to_m(cch), pp, net) for k in range(2)]
+        return many_d, single_d, many_c, single_c
+
+    res = LocalTestNet.simulate_network_round(W, party)
+    for p in range(W):
+        many_d, single_d, many_c, single_c = res[p]
+        for a, b in zip(many_d, single_d):
+            assert a.shape == b.shape and (a == b).all()
+        for a, b in zip(many_c, single_c):
+            assert (a == b).all()
+    for k, (lg, ch) in enumerate(items):
+        assert [tuple(ints(t)) for t in res[0][0][k]] == po.d_sumcheck_product_all(pf[k], pg[k], ch)
+    for k in range(2):
+        exp = po.c_sumcheck_product_all(cf, cg[k], cch, opp)
+        for p in range(W):
+            assert [tuple(ints(t)) for t in res[p][2][k]] == exp[p]
