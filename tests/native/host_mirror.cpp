@@ -1,0 +1,264 @@
+// Test driver of the C++ host mirror (scalable-collaborative-zksnark_amd/host/zkhost): runs every `dist-primitive` function
+// of the mirror on inputs written by pytest and writes the outputs back; tests/test_host_cpp.py runs the same sequence
+// through the Python host layer (and, on the CPU, the oracle) and compares the two record files bit for bit.
+//
+//   host_mirror host <in> <out>     no GPU: field arithmetic, PackedSharingParams, the leader rounds, merge / transpose / sub_index
+//   host_mirror gpu  <in> <out>     all parties as threads of this process, one ctx each on GPU 0 (LocalTestNet), or party 0 on
+//                                   the leader-echo net; every collaborative primitive once
+// Record file: { char name[24]; u64 party; u64 nbytes; payload } ...
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "zkhost/dist_primitive.hpp"
+
+using namespace zkhost;
+
+struct Records {
+    std::map<std::pair<std::string, uint64_t>, Bytes> rec;
+    std::vector<std::pair<std::string, uint64_t>> order;
+    std::mutex m;
+
+    void put(const std::string &name, uint64_t party, const void *data, size_t bytes) {
+        std::lock_guard<std::mutex> lk(m);
+        auto key = std::make_pair(name, party);
+        if (!rec.count(key)) order.push_back(key);
+        Bytes &b = rec[key];
+        b.insert(b.end(), (const uint8_t *)data, (const uint8_t *)data + bytes);
+    }
+    void put(const std::string &n, uint64_t p, const FrVec &v) { put(n, p, v.data(), 32 * v.size()); }
+    void put(const std::string &n, uint64_t p, const Fr &v) { put(n, p, v.v, 32); }
+    void put(const std::string &n, uint64_t p, const G1Vec &v) { put(n, p, v.data(), 144 * v.size()); }
+    void put(const std::string &n, uint64_t p, const G1 &v) { put(n, p, v.data(), 144); }
+    void put(const std::string &n, uint64_t p, const std::vector<Pair> &v) { put(n, p, v.data(), 64 * v.size()); }
+    void put(const std::string &n, uint64_t p, const std::vector<Triple> &v) { put(n, p, v.data(), 96 * v.size()); }
+    void put(const std::string &n, uint64_t p, const Opening &o) {
+        put(n, p, o.value);
+        put(n, p, o.proofs);
+    }
+    void put_u64(const std::string &n, uint64_t p, uint64_t x) { put(n, p, &x, 8); }
+
+    bool load(const char *path) {
+        FILE *f = std::fopen(path, "rb");
+        if (!f) return false;
+        char name[24];
+        uint64_t hdr[2];
+        while (std::fread(name, 1, 24, f) == 24 && std::fread(hdr, 8, 2, f) == 2) {
+            Bytes b(hdr[1]);
+            if (hdr[1] && std::fread(b.data(), 1, hdr[1], f) != hdr[1]) break;
+            name[23] = 0;
+            rec[{name, hdr[0]}] = b;
+        }
+        std::fclose(f);
+        return true;
+    }
+    bool save(const char *path) {
+        FILE *f = std::fopen(path, "wb");
+        if (!f) return false;
+        for (auto &key : order) {
+            char name[24] = {0};
+            std::strncpy(name, key.first.c_str(), 23);
+            const Bytes &b = rec[key];
+            uint64_t hdr[2] = {key.second, b.size()};
+            std::fwrite(name, 1, 24, f);
+            std::fwrite(hdr, 8, 2, f);
+            if (!b.empty()) std::fwrite(b.data(), 1, b.size(), f);
+        }
+        std::fclose(f);
+        return true;
+    }
+    FrVec fr(const std::string &name, uint64_t party = 0) const {
+        auto it = rec.find({name, party});
+        if (it == rec.end()) throw std::runtime_error("input record missing: " + name);
+        FrVec v(it->second.size() / 32);
+        std::memcpy(v.data(), it->second.data(), 32 * v.size());
+        return v;
+    }
+    uint64_t u64(const std::string &name, size_t i = 0) const {
+        auto it = rec.find({name, 0});
+        if (it == rec.end()) throw std::runtime_error("input record missing: " + name);
+        uint64_t x;
+        std::memcpy(&x, it->second.data() + 8 * i, 8);
+        return x;
+    }
+};
+
+static FrVec flatten(const std::vector<FrVec> &m) {
+    FrVec f;
+    for (auto &r : m) f.insert(f.end(), r.begin(), r.end());
+    return f;
+}
+
+// ---- no GPU: everything of the mirror that is plain host code ----
+static void run_host(const Records &in, Records &out) {
+    FrVec a = in.fr("a"), b = in.fr("b");
+    FrVec sum, dif, prod, inv, canon;
+    for (size_t i = 0; i < a.size(); ++i) {
+        sum.push_back(a[i] + b[i]);
+        dif.push_back(a[i] - b[i]);
+        prod.push_back(a[i] * b[i]);
+        inv.push_back(a[i].is_zero() ? Fr::zero() : a[i].inverse());
+        canon.push_back(a[i].to_canonical());
+    }
+    out.put("add", 0, sum), out.put("sub", 0, dif), out.put("mul", 0, prod), out.put("inv", 0, inv), out.put("canonical", 0, canon);
+    out.put("root_of_unity", 0, fr_two_adic_root());
+    size_t nl = in.rec.at({"ls", 0}).size() / 8;
+    for (size_t i = 0; i < nl; ++i) {
+        size_t l = in.u64("ls", i);
+        PackedSharingParams pp(l);
+        out.put("pack_matrix", l, flatten(pp.pack_matrix));
+        out.put("unpack_matrix", l, flatten(pp.unpack_matrix));
+        out.put("unpack2_matrix", l, flatten(pp.unpack2_matrix));
+        FrVec secrets(a.begin(), a.begin() + l), shares(b.begin(), b.begin() + pp.n);
+        out.put("pack_from_public", l, pp.pack_from_public(secrets));
+        out.put("pack_single", l, pp.pack_single(a[0]));
+        out.put("unpack", l, pp.unpack(shares));
+        out.put("unpack2", l, pp.unpack2(shares));
+        out.put("dmsm_coeffs", l, pp.dmsm_coeffs(pp.n - 1));
+        out.put("degree_reduce_row", l, pp.degree_reduce_row(1));
+        for (auto kind : {PackedSharingParams::Map::Pack, PackedSharingParams::Map::Unpack, PackedSharingParams::Map::Unpack2}) {
+            NttTables t = pp.ntt_tables(kind);
+            out.put("ntt_winv", l, t.winv), out.put("ntt_w", l, t.w), out.put("ntt_scale", l, t.scale);
+        }
+        // all parties as threads: pss2ss, degree_reduce and the d_unpack family need no device
+        std::vector<FrVec> r_pss(pp.n), r_un(pp.n), r_un2(pp.n);
+        FrVec r_dr(pp.n), r_u0(pp.n);
+        std::vector<std::array<uint64_t, 2>> comm(pp.n);
+        LocalTestNet::simulate_network_round(pp.n, [&](size_t p, LocalTestNet &net) {
+            r_pss[p] = pss2ss(b[p], pp, net);
+            r_dr[p] = degree_reduce(b[p], pp, net);
+            r_u0[p] = d_unpack_0(b[p], pp, net);
+            r_un[p] = d_unpack(b[p], 2, pp, net);
+            r_un2[p] = d_unpack2(b[p], 3, pp, net);
+            comm[p] = {net.upload, net.download};
+        });
+        out.put("pss2ss", l, flatten(r_pss)), out.put("degree_reduce", l, r_dr), out.put("d_unpack_0", l, r_u0);
+        out.put("d_unpack", l, flatten(r_un)), out.put("d_unpack2", l, flatten(r_un2));
+        out.put("comm", l, comm.data(), 16 * comm.size());
+        LeaderEchoNet echo(pp.n);
+        out.put("pss2ss_echo", l, pss2ss(b[0], pp, echo));
+    }
+    // the leader rounds of the collaborative sumchecks on host vectors
+    FrVec f(a.begin(), a.begin() + 8), g(b.begin(), b.begin() + 8);
+    for (size_t i = 0; i < 3; ++i) {
+        Triple t = detail::round_product(f, g, a[8 + i]);
+        out.put("round_product", 0, t.data(), 96);
+    }
+    FrVec v(a.begin(), a.begin() + 8);
+    for (size_t i = 0; i < 3; ++i) {
+        Pair s = detail::round_plain(v, b[8 + i]);
+        out.put("round_plain", 0, s.data(), 64);
+    }
+    out.put("round_last", 0, FrVec{f[0], g[0], v[0]});
+    // merge (dacc_product.rs:416-428) of 3 vectors of 7, sub_index (:18-23; KAT :442-448), transpose (operator.rs:42-49)
+    std::vector<FrVec> parts;
+    for (size_t q = 0; q < 3; ++q) parts.emplace_back(a.begin() + 7 * q, a.begin() + 7 * q + 7);
+    out.put("merge", 0, merge(parts));
+    for (size_t i = 1; i < 16; ++i) {
+        auto ab = sub_index(i);
+        out.put_u64("sub_index", 0, ab.first), out.put_u64("sub_index", 0, ab.second);
+    }
+    std::vector<std::vector<uint64_t>> m = {{1, 2, 3}, {4, 5, 6}};
+    for (auto &row : transpose(m))
+        for (uint64_t x : row) out.put_u64("transpose", 0, x);
+}
+
+// ---- one party's pass over every collaborative primitive ----
+static void run_party(const Records &in, Records &out, size_t p, Net &net, const PackedSharingParams &pp) {
+    size_t m = in.u64("params", 1), M = size_t(1) << m, P = pp.n, logP = log2_floor(P), logl = log2_floor(pp.l);
+    Ctx be(0);
+    FrVec chal = in.fr("chal"), point = in.fr("point");
+    DevPtr f = be.to_device(in.fr("f", p)), g = be.to_device(in.fr("g", p));
+    DevPtr h0 = be.to_device(in.fr("h0", p)), h1 = be.to_device(in.fr("h1", p)), h2 = be.to_device(in.fr("h2", p));
+    PolynomialCommitmentCub pc_d = PolynomialCommitmentCub::new_random(be, m + logP, P, 3);
+    PolynomialCommitmentCub pc_c = PolynomialCommitmentCub::new_single(be, m + logl, pp, 5);
+    const PowersOfG &gd = pc_d.mature(), &gc = pc_c.mature();
+    Fr share = in.fr("f", p)[0];
+
+    out.put("sumcheck", p, sumcheck(be, f, M, chal));
+    out.put("sumcheck_product", p, sumcheck_product(be, f, g, M, chal));
+    out.put("pss2ss", p, pss2ss(share, pp, net));
+    out.put("c_sumcheck", p, c_sumcheck(be, f, M, chal, pp, net));
+    out.put("c_sumcheck_product", p, c_sumcheck_product(be, f, g, M, chal, pp, net));
+    out.put("d_sumcheck", p, d_sumcheck(be, f, M, chal, net));
+    out.put("d_sumcheck_product", p, d_sumcheck_product(be, f, g, M, chal, net));
+
+    std::vector<SrsPtr> bases = {gc[m + logl], gc[m - 1 + logl]};
+    out.put("d_msm", p, d_msm(be, bases, {f, g}, {M, M / 2}, pp, net));
+    out.put("d_msm_unscaled", p, d_msm(be, bases, {f, g}, {M, M / 2}, pp, net, false));
+    out.put("commit", p, commit(be, gd, f, M));
+    out.put("open", p, open(be, gd, f, M, point));
+    out.put("d_commit", p, d_commit(be, gd, f, M, net));
+    out.put("d_open", p, d_open(be, gd, f, M, point, net));
+    out.put("c_commit", p, c_commit(be, gc, {f, g.fr(M / 2)}, {M, M / 2}, pp, net));
+    out.put("c_open", p, c_open(be, gc, f, M, point, pp, net));
+
+    ProductTree tree = acc_product(be, f, M);
+    out.put("acc_product", p, be.to_host(tree.tree, 2 * M));
+    auto views = tree.views(be);
+    for (auto &v : views) out.put("acc_product_views", p, be.to_host(v, M));
+    auto dap = d_acc_product(be, g, M, net);
+    out.put("d_acc_product", p, be.to_host(dap.first.tree, 2 * M));
+    out.put("d_acc_product_top", p, dap.second ? *dap.second : FrVec{});
+    auto cap = c_acc_product(be, g, M, pp, net);
+    out.put("c_acc_product", p, be.to_host(cap.first.tree, 2 * M));
+    out.put("c_acc_product_top", p, cap.second ? *cap.second : FrVec{});
+
+    out.put("fix_variable", p, be.to_host(fix_variable(be, f, M, FrVec(point.begin(), point.begin() + 3)), M >> 3));
+    FixedVariable fv = d_fix_variable(be, f, M, FrVec(point.begin(), point.begin() + m + logl), pp, net);
+    out.put("d_fix_variable", p, fv.value ? *fv.value : be.to_host(fv.table, fv.len)[0]);
+    FixedVariable fv2 = d_fix_variable(be, f, M, FrVec(point.begin(), point.begin() + 2), pp, net);
+    out.put("d_fix_variable_short", p, be.to_host(fv2.table, fv2.len));
+
+    FrVec g_host = in.fr("g", p), few(g_host.begin(), g_host.begin() + 5);
+    out.put("degree_reduce", p, degree_reduce(share, pp, net));
+    out.put("degree_reduce_many", p, degree_reduce_many(be, few, pp, net));
+    out.put("d_unpack_0", p, d_unpack_0(share, pp, net));
+    out.put("d_unpack", p, d_unpack(share, P - 1, pp, net));
+    out.put("d_unpack2", p, d_unpack2(share, 1 % P, pp, net));
+    out.put("d_unpack2_many", p, d_unpack2_many(be, few, 0, pp, net));
+
+    auto sh = c_acc_product_and_share(be, f, g, h0, h1, h2, M, pp, net);
+    for (auto &s : sh) {
+        out.put_u64("c_acc_share_len", p, s.len);
+        out.put("c_acc_product_and_share", p, be.to_host(s.buf, s.len));
+    }
+    out.put_u64("comm", p, net.upload), out.put_u64("comm", p, net.download);
+}
+
+int main(int argc, char **argv) {
+    if (argc != 4) {
+        std::fprintf(stderr, "usage: host_mirror host|gpu <in> <out>\n");
+        return 64;
+    }
+    Records in, out;
+    if (!in.load(argv[2])) {
+        std::fprintf(stderr, "host_mirror: cannot read %s\n", argv[2]);
+        return 66;
+    }
+    try {
+        if (!std::strcmp(argv[1], "host")) {
+            run_host(in, out);
+        } else {
+            if (zk_device_count() <= 0) {
+                std::fprintf(stderr, "host_mirror: no GPU visible -- the host mirror has no CPU fallback (zk_device_count = %d)\n", zk_device_count());
+                return 2;
+            }
+            PackedSharingParams pp(in.u64("params", 0));
+            if (in.u64("params", 2)) {  // the no-`comm` fake: party 0 alone
+                LeaderEchoNet net(pp.n);
+                run_party(in, out, 0, net, pp);
+            } else {
+                LocalTestNet::simulate_network_round(pp.n, [&](size_t p, LocalTestNet &net) { run_party(in, out, p, net, pp); });
+            }
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "host_mirror: %s\n", e.what());
+        return 1;
+    }
+    if (!out.save(argv[3])) return 73;
+    std::printf("host_mirror ok: %zu records\n", out.order.size());
+    return 0;
+}
