@@ -269,6 +269,51 @@ class Ctx {
         check(zk_msm_g1_batch(h_, count, h.data(), nullptr, sp.data(), lens.data(), out[0].data()));
         return out;
     }
+    // asynchronous form: the pass runs on the ctx's job lanes while the caller enqueues other work; wait() collects the points.
+    // The scalar buffers must stay alive and unmodified until then (MsmJob holds them).
+    struct MsmJob {
+        zk_ctx *ctx = nullptr;
+        zk_msm_job *job = nullptr;
+        size_t count = 0;
+        std::vector<DevPtr> keep;
+        MsmJob() {}
+        MsmJob(const MsmJob &) = delete;
+        MsmJob(MsmJob &&o) noexcept { *this = std::move(o); }
+        MsmJob &operator=(MsmJob &&o) noexcept {
+            drain();
+            ctx = o.ctx, job = o.job, count = o.count, keep = std::move(o.keep);
+            o.job = nullptr;
+            return *this;
+        }
+        ~MsmJob() { drain(); }
+        bool pending() const { return job != nullptr; }
+        void drain() {  // never waited for: let it finish and release it
+            if (job) {
+                G1Vec tmp(count);
+                zk_msm_wait(ctx, job, tmp[0].data());
+                job = nullptr;
+            }
+        }
+    };
+    MsmJob msm_g1_batch_async(const std::vector<const Srs *> &srs, const std::vector<DevPtr> &scalars, const std::vector<size_t> &lens) {
+        size_t count = lens.size();
+        need(srs.size() == count && scalars.size() == count && count > 0, "msm batch: list lengths differ / empty");
+        std::vector<const zk_srs *> h(count);
+        std::vector<const void *> sp(count);
+        for (size_t i = 0; i < count; ++i) h[i] = srs[i]->handle(), sp[i] = scalars[i].get();
+        MsmJob j;
+        j.ctx = h_, j.count = count, j.keep = scalars;
+        check(zk_msm_g1_batch_async(h_, count, h.data(), nullptr, sp.data(), lens.data(), &j.job));
+        return j;
+    }
+    G1Vec msm_wait(MsmJob &j) {
+        G1Vec out(j.count);
+        zk_msm_job *job = j.job;
+        j.job = nullptr;  // (zk_msm_wait releases the job also on error)
+        j.keep.clear();
+        if (job) check(zk_msm_wait(h_, job, out[0].data()));
+        return out;
+    }
     // the whole of d_msm in one call over the ctx's communicator (zk_d_msm)
     G1Vec d_msm(const std::vector<const Srs *> &srs, const std::vector<DevPtr> &scalars, const std::vector<size_t> &lens, const Fr *lambda_mont,
                 const FrVec &coeffs_canonical) {

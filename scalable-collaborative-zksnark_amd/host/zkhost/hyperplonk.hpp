@@ -1,0 +1,332 @@
+// Collaborative HyperPlonk call sequence -- C++ host mirror of hyperplonk/src/dhyperplonk.rs (`PackedProvingParameters::new`
+// :65-156, `dhyperplonk` :159-571, `dhyperplonk_data_parallel` :573-960, `dpermcheck` :962-1247, `cpermcheck` :1249-1385).
+// Like the reference it is a FIXED sequence of dist-primitive calls on synthetic (random) tables: there is no circuit and no
+// Fiat-Shamir, every challenge is pre-sampled.  All tables and SRS levels are resident in HBM; every primitive runs through
+// libzkhip.so.  The MSM pass of a step is started asynchronously and collected one step later (pipeline.hpp): the outputs
+// keep the reference's positions, the timers keep its labels (only the total is comparable once steps overlap).
+#pragma once
+#include <chrono>
+#include <map>
+#include <string>
+
+#include "pipeline.hpp"
+
+namespace zkhost {
+
+// SplitMix64 -> uniform Fr limbs by rejection (SURVEY.md 8(d) "Synthetic inputs"): any canonical limb pattern is the Montgomery
+// form of a uniform element, which is what `random_evaluations` (dist-primitive/src/lib.rs:13-18) produces
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    }
+    Fr fr() {
+        for (;;) {
+            Fr x{{next(), next(), next(), next() & 0x7fffffffffffffffull}};
+            if (!Fr::geq_mod(x.v)) return x;
+        }
+    }
+    FrVec fr_vec(size_t n) {
+        FrVec v(n);
+        for (auto &x : v) x = fr();
+        return v;
+    }
+};
+
+class Timers {  // wall-clock sections with the reference's labels (mpc-net/src/utils/timer.rs)
+  public:
+    std::map<std::string, double> t;
+    void start(const std::string &label) { stack_.push_back({label, std::chrono::steady_clock::now()}); }
+    void end() {
+        auto [label, t0] = stack_.back();
+        stack_.pop_back();
+        t[label] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+  private:
+    std::vector<std::pair<std::string, std::chrono::steady_clock::time_point>> stack_;
+};
+
+// hyperplonk/src/dhyperplonk.rs:19-63; every table is a device buffer of Fr
+struct PackedProvingParameters {
+    size_t n = 0;
+    std::map<std::string, DevPtr> tables;
+    std::map<std::string, size_t> lens;
+    FrVec challenge, challenge_r1, challenge_r2;
+    Fr alpha, beta, gamma;
+    PowersOfG c_commitment;  // levels 0 .. n+2 (new_single, dpoly_comm.rs:197-219)
+    PowersOfG d_commitment;  // levels 0 .. n - log2(N_p) + 2 (new_random, dpoly_comm.rs:220-233)
+
+    const DevPtr &T(const std::string &name) const {
+        auto it = tables.find(name);
+        if (it == tables.end()) throw ZkError(ZK_ERR_INVALID, "PackedProvingParameters: no table " + name);
+        return it->second;
+    }
+    size_t L(const std::string &name) const { return lens.at(name); }
+    void put(Ctx &be, const std::string &name, const FrVec &v) {
+        tables[name] = be.to_device(v);
+        lens[name] = v.size();
+    }
+
+    // the table names and lengths of dhyperplonk.rs:65-156 (a_evals, b_evals, c_evals are folds of V, :71-73)
+    static std::vector<std::pair<std::string, size_t>> layout(size_t n, const PackedSharingParams &pp) {
+        size_t M = size_t(1) << n, l = pp.l, np = pp.n;
+        return {{"V", 4 * M / l},        {"I", M / l},           {"I_p", M / np},        {"S1", M / l},          {"S2", M / l},         {"S1_p", M / np},
+                {"S2_p", M / np},        {"ssigma", 4 * M / l},  {"ssigma_p", 4 * M / np}, {"sid", 4 * M / l},   {"sid_p", 4 * M / np}, {"eq", M / l},
+                {"eq_top_p", 2 * np},    {"eq_r1", 4 * M / l},   {"eq_r1_p", 4 * M / np}, {"eq_r2", 4 * M / l},  {"eq_r2_p", 4 * M / np},
+                // "Jump from sky" (:187-190) and the data-parallel s (:603): per-run random data, kept with the tables here
+                {"local_s_p", 4 * M / np}, {"local_s_l", 4 * M / np / l}, {"eq_top", np}, {"s_data_parallel", 4 * M / l}};
+    }
+    // challenge vector of 3n + 7 Fr: challenge (n), challenge_r1 (n + 2), challenge_r2 (n + 2), alpha, beta, gamma
+    void set_challenges(const FrVec &ch) {
+        if (ch.size() != 3 * n + 7) throw ZkError(ZK_ERR_INVALID, "PackedProvingParameters: 3n + 7 challenge values expected");
+        challenge.assign(ch.begin(), ch.begin() + n);
+        challenge_r1.assign(ch.begin() + n, ch.begin() + 2 * n + 2);
+        challenge_r2.assign(ch.begin() + 2 * n + 2, ch.begin() + 3 * n + 4);
+        alpha = ch[3 * n + 4], beta = ch[3 * n + 5], gamma = ch[3 * n + 6];
+    }
+    // the folds of V and the synthetic SRS (random points in the reference as well); window_tables: build the MSM window
+    // table of every level up to 2^table_max_log2 points (setup work like generating the level; results are bit-identical
+    // with and without); a level is skipped when its table would leave less than 40 % of the device free
+    void finish_setup(Ctx &be, const PackedSharingParams &pp, uint64_t seed, bool window_tables = true, size_t table_max_log2 = 24) {
+        size_t M = size_t(1) << n, l = pp.l;
+        Fr zero = Fr::zero(), one = Fr::one();
+        const std::pair<const char *, std::array<Fr, 2>> folds[3] = {{"a_evals", {zero, zero}}, {"b_evals", {zero, one}}, {"c_evals", {one, zero}}};
+        for (auto &f : folds) {
+            tables[f.first] = be.fold(T("V"), 4 * M / l, FrVec{f.second[0], f.second[1]});  // fix_variable(&V, ..) :71-73
+            lens[f.first] = M / l;
+        }
+        for (size_t i = 0; i < n + 3; ++i) c_commitment.push_back(be.srs_generate(seed * 7919 + 2 * i + 1, seed * 104729 + 2 * i + 3, std::max<size_t>(1, (size_t(1) << i) / l)));
+        for (size_t i = 0; i + log2_floor(pp.n) < n + 3; ++i) d_commitment.push_back(be.srs_generate(seed * 6007 + 2 * i + 5, seed * 15485863 + 2 * i + 7, size_t(1) << i));
+        if (!window_tables) return;
+        std::vector<SrsPtr> all = c_commitment;
+        all.insert(all.end(), d_commitment.begin(), d_commitment.end());
+        std::stable_sort(all.begin(), all.end(), [](const SrsPtr &a, const SrsPtr &b) { return a->len() < b->len(); });
+        for (auto &lv : all) {  // largest levels last: the ones without a table simply use the table-less path
+            size_t len = lv->len();
+            if (len < 64 || len > (size_t(1) << table_max_log2)) continue;
+            if (len > (size_t(1) << 22)) {
+                size_t fr = 0, tot = 0;
+                be.check(zk_mem_info(be.handle(), &fr, &tot));
+                if ((double)fr - 16.0 * 96.0 * (double)len < 0.4 * (double)tot) break;
+            }
+            int rc = zk_srs_precompute(be.handle(), lv->handle(), 0);
+            if (rc == ZK_ERR_OOM) break;
+            be.check(rc);
+        }
+    }
+    // dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy(): tables from SplitMix64(seed ...)
+    static PackedProvingParameters make(Ctx &be, size_t n, const PackedSharingParams &pp, uint64_t seed, uint64_t chal_seed = 0, bool window_tables = true) {
+        PackedProvingParameters pk;
+        pk.n = n;
+        uint64_t sd = 0x5CA1AB1Eull + 1000 * seed;
+        for (auto &nl : layout(n, pp)) pk.put(be, nl.first, SplitMix64(++sd).fr_vec(nl.second));
+        pk.set_challenges(SplitMix64(chal_seed ? chal_seed : ++sd).fr_vec(3 * n + 7));  // public values every party shares
+        pk.finish_setup(be, pp, seed, window_tables);
+        return pk;
+    }
+};
+
+struct Transcript {
+    std::vector<std::vector<Triple>> gate_proofs;          // the six gate sumchecks (:223-260)
+    std::vector<std::pair<G1, Opening>> gate_commitments;  // (commitment, opening) of a, b, c, I_p, S1_p, S2_p
+    std::vector<std::vector<Triple>> wiring_proofs;
+    G1Vec wiring_commits;
+    std::vector<Opening> wiring_opens;
+};
+
+namespace detail {
+// step 2 of dhyperplonk (:262-514) == the body of dpermcheck (:992-1245), up to (not including) its one batched MSM pass:
+// every sumcheck / fold / open-round kernel has run, every MSM of the step sits in `q`.  -> finalize(): the exchanges of the
+// MSM results, filling the wiring lists in the reference's order.
+inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, MsmQueue &q,
+                                                        bool data_parallel) {
+    size_t l = pp.l, np = net.n_parties, M = size_t(1) << n, sbits = log2_floor(np);
+    const PowersOfG &cc = pk.c_commitment, &dc = pk.d_commitment;
+    const DevPtr &local_s_p = pk.T("local_s_p"), &local_s_l = pk.T("local_s_l");
+    auto tr = std::make_shared<Transcript>();
+    // 2.a (:268-294): every party broadcasts local_s; s = concatenation over parties (an all-gather that stays in HBM over RCCL)
+    DevPtr s_dev = data_parallel ? pk.T("s_data_parallel") : net.all_gather_device(be, local_s_l, 32 * (4 * M / np / l));
+    tr->wiring_proofs.push_back(c_sumcheck_product(be, s_dev, pk.T("V"), 4 * M / l, pk.challenge_r1, pp, net));  // 2.c
+    // 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
+    auto f_copen = c_open_many_q(be, q, cc, {pk.T("V"), pk.T("V")}, {4 * M / l, 4 * M / l}, {pk.challenge_r1, pk.challenge_r2}, pp, net);
+    // 2.e (:322-340)
+    size_t hlen = 4 * M / np;
+    DevPtr num = be.fr_axpb(local_s_p, pk.T("sid_p"), pk.alpha, pk.beta, hlen);
+    DevPtr den = be.fr_axpb(pk.T("eq_r1_p"), pk.T("ssigma_p"), pk.alpha, pk.beta, hlen);
+    DevPtr h_p = be.fr_batch_div(num, den, hlen);
+    auto [sub, top] = d_acc_product(be, h_p, hlen, net);  // :342
+    q.keep.push_back(sub.tree);  // v1x and the layer slices below are views into it
+    DevPtr v1x = sub.tree.fr(hlen);
+    auto [vx0, vx1] = be.fr_deinterleave(sub.tree, hlen);  // :344-359
+    // :363-380 / :383-407: independent commits / opens
+    std::vector<DevPtr> tabs8 = {pk.T("ssigma_p"), pk.T("sid_p"), h_p, num, den, v1x, vx0, vx1};
+    std::vector<DevPtr> com_tabs = {local_s_p};
+    com_tabs.insert(com_tabs.end(), tabs8.begin(), tabs8.end());
+    std::vector<size_t> com_lens(9, hlen);
+    auto f_dcommit = d_commit_many_q(be, q, dc, com_tabs, com_lens, net);  // 2.b, then :363-380
+    std::vector<DevPtr> lay_tabs(com_tabs.begin(), com_tabs.begin() + 6);   // 2.d, then :383-407
+    std::vector<size_t> lay_lens(6, hlen);
+    std::vector<FrVec> lay_pts(6, pk.challenge_r2);
+    // the 3 + 3 (n - s) d_sumcheck_products of 2.e are independent of each other: one batched local phase, one exchange
+    std::vector<DsumcheckItem> dsp = {{den, pk.T("eq_r2_p"), hlen, pk.challenge_r2}, {h_p, den, hlen, pk.challenge_r2}, {num, pk.T("eq_r2_p"), hlen, pk.challenge_r2}};  // :411-413
+    // 2.e.2 layered sumcheck + opens on halving slices (:417-478)
+    DevPtr cur[4] = {v1x, vx0, vx1, pk.T("eq_r2_p")};
+    size_t clen = hlen / 2;  // current_* = first half
+    for (size_t i = 1; i + sbits <= n; ++i) {
+        FrVec ch(pk.challenge_r2.begin() + i, pk.challenge_r2.end());
+        dsp.push_back({cur[3], cur[0], clen, ch}), dsp.push_back({cur[3], cur[1], clen, ch}), dsp.push_back({cur[1], cur[2], clen, ch});
+        for (int k = 0; k < 3; ++k) lay_tabs.push_back(cur[k]), lay_lens.push_back(clen), lay_pts.push_back(ch);
+        for (auto &c : cur) c = c.fr(clen / 2);  // current = current[len/2..]
+        clen /= 2;
+    }
+    auto f_dsp = d_sumcheck_product_many_q(be, dsp, net);
+    auto f_dopen = d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net);
+    // leader-only tail on the N_p-leaf top tree (:480-511)
+    auto top_commits = std::make_shared<std::vector<std::function<G1()>>>();
+    auto top_opens = std::make_shared<OpensInFlight>();
+    auto top_proofs = std::make_shared<std::vector<std::vector<Triple>>>();
+    bool has_top = top.has_value();
+    if (has_top) {
+        const FrVec &tt = *top;
+        size_t half = tt.size() / 2;
+        FrVec lv1x(tt.begin() + half, tt.end()), lvx0, lvx1;
+        for (size_t i = 0; i < tt.size(); ++i) (i % 2 ? lvx1 : lvx0).push_back(tt[i]);
+        FrVec chs(pk.challenge_r2.begin(), pk.challenge_r2.begin() + sbits);
+        DevPtr d0 = be.to_device(lvx0), dd1 = be.to_device(lvx1), d1 = be.to_device(lv1x);
+        for (auto &d : {d0, dd1, d1}) top_commits->push_back(commit_q(q, dc, d, half)), q.keep.push_back(d);
+        *top_opens = open_many_q(be, q, dc, {d0, dd1, d1}, {half, half, half}, {chs, chs, chs});
+        top_proofs->push_back(sumcheck_product(be, pk.T("eq_top"), d1, half, chs));
+        top_proofs->push_back(sumcheck_product(be, pk.T("eq_top"), d0, half, chs));
+        top_proofs->push_back(sumcheck_product(be, d0, dd1, half, chs));
+    }
+    return [tr, f_dsp, f_copen, f_dcommit, f_dopen, top_commits, top_opens, top_proofs, has_top](Transcript &out) {
+        out.wiring_proofs = tr->wiring_proofs;
+        for (auto &p : f_dsp()) out.wiring_proofs.push_back(p);  // 2.e: after 2.c, before the leader-tree sumchecks (the reference's order)
+        out.wiring_opens = f_copen();                           // 2.d
+        out.wiring_commits = f_dcommit();                       // 2.b, then :363-380
+        for (auto &o : f_dopen()) out.wiring_opens.push_back(o);
+        if (has_top) {
+            std::vector<Opening> to = top_opens->finish();
+            for (size_t i = 0; i < 3; ++i) {  // (commit, open) per table, in the reference's order
+                out.wiring_commits.push_back((*top_commits)[i]());
+                out.wiring_opens.push_back(to[i]);
+            }
+            for (auto &p : *top_proofs) out.wiring_proofs.push_back(p);
+        }
+    };
+}
+}  // namespace detail
+
+// dhyperplonk.rs:159-571 (data_parallel: dhyperplonk_data_parallel :573-960, which differs only at step 2.a -- `s` is local
+// random data, no exchange, :603)
+inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers *tm_out = nullptr,
+                              bool data_parallel = false) {
+    size_t l = pp.l, M = size_t(1) << n, Ml = M / l;
+    const PowersOfG &cc = pk.c_commitment, &dc = pk.d_commitment;
+    Timers tm;
+    Transcript out;
+    net.sync();
+    tm.start("Distributed HyperPlonk");
+
+    // Step 1: commit (:198-215): both commit families in one batched MSM pass, started here and collected later
+    tm.start("Commit");
+    const char *names_c[3] = {"a_evals", "b_evals", "c_evals"}, *names_d[3] = {"I_p", "S1_p", "S2_p"};
+    std::vector<DevPtr> tc, td;
+    std::vector<size_t> lc, ld;
+    for (auto x : names_c) tc.push_back(pk.T(x)), lc.push_back(pk.L(x));
+    for (auto x : names_d) td.push_back(pk.T(x)), ld.push_back(pk.L(x));
+    MsmQueue q(be);
+    auto f_c = c_commit_q(be, q, cc, tc, lc, pp, net);
+    auto f_d = d_commit_many_q(be, q, dc, td, ld, net);
+    q.start();
+    tm.end();
+
+    // Step 3: gate identity (:223-260): the six sumchecks are independent -- one batched phase 1, then the hand-offs in order
+    tm.start("Gate identity");
+    DevPtr sum_ab = be.fr_add(pk.T("a_evals"), pk.T("b_evals"), Ml);  // :233-238
+    DevPtr sum_ci = be.fr_sub(pk.T("I"), pk.T("c_evals"), Ml);        // -c + I  :251-256
+    out.gate_proofs = c_sumcheck_product_many(be, {{pk.T("eq"), pk.T("S1")}, {pk.T("S1"), sum_ab}, {pk.T("eq"), pk.T("S2")}, {pk.T("a_evals"), pk.T("b_evals")},
+                                                   {pk.T("S2"), pk.T("a_evals")}, {pk.T("eq"), sum_ci}}, Ml, pk.challenge, pp, net);
+    tm.end();
+
+    // Step 2: wiring identity (shared with dpermcheck).  The kernel phase of the Open step (:517-553) depends on nothing the
+    // wiring step produces, so it runs BEFORE the wiring pass is started: both passes are then in flight back to back.
+    tm.start("Wire identity");
+    MsmQueue q_w(be), q_o(be);
+    auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel);
+    std::vector<FrVec> pts3(3, pk.challenge);
+    auto f_co = c_open_many_q(be, q_o, cc, tc, lc, pts3, pp, net);
+    auto f_do = d_open_many_q(be, q_o, dc, td, ld, pts3, net);
+    q_w.start();
+    q_o.start();
+    q.finish();  // (host: exchange + point combinations of step 1, beside the passes on the GPU)
+    G1Vec com = f_c(), com_d = f_d();
+    com.insert(com.end(), com_d.begin(), com_d.end());
+    tm.end();
+
+    // Open (:517-553): collection of both passes
+    tm.start("Open");
+    q_w.finish();
+    finalize_wiring(out);
+    q_o.finish();
+    std::vector<Opening> ops = f_co(), ops_d = f_do();
+    ops.insert(ops.end(), ops_d.begin(), ops_d.end());
+    for (size_t i = 0; i < 6; ++i) out.gate_commitments.push_back({com[i], ops[i]});
+    tm.end();
+    tm.end();
+    if (tm_out) *tm_out = tm;
+    return out;
+}
+
+// hyperplonk/src/dhyperplonk.rs:962-1247: the distributed permutation check alone (= step 2 of dhyperplonk)
+inline Transcript dpermcheck(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers *tm_out = nullptr) {
+    Timers tm;
+    Transcript out;
+    net.sync();
+    tm.start("Distributed Permcheck");
+    MsmQueue q(be);
+    auto fin = detail::wiring_enqueue(n, pk, pp, be, net, q, false);
+    q.run();
+    fin(out);
+    tm.end();
+    if (tm_out) *tm_out = tm;
+    return out;
+}
+
+// hyperplonk/src/dhyperplonk.rs:1249-1385: the collaborative (packed) permutation check: num / den maps, c_commit / c_open of
+// the public wires, and per polynomial the masked product tree (c_acc_product_and_share) with its commits, opens and three
+// product sumchecks.  masks: "mask", "unmask0..2" tables of 4 (2^n / l) Fr (PackedProvingParameters::new :124-127).
+inline Transcript cpermcheck(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers *tm_out = nullptr) {
+    size_t G4 = 4 * ((size_t(1) << n) / pp.l);  // gate_count * 4 with gate_count = 2^n / l (:1270)
+    const PowersOfG &cc = pk.c_commitment;
+    Timers tm;
+    Transcript out;
+    net.sync();
+    tm.start("Collaborative Permcheck");
+    DevPtr num = be.fr_axpb(pk.T("V"), pk.T("sid"), pk.alpha, pk.beta, G4);          // :1277-1279
+    DevPtr den = be.fr_axpb(pk.T("eq_r1"), pk.T("ssigma"), pk.alpha, pk.beta, G4);  // :1280-1282
+    auto commit_open = [&](const DevPtr &tab) {
+        out.wiring_commits.push_back(c_commit(be, cc, {tab}, {G4}, pp, net)[0]);
+        out.wiring_opens.push_back(c_open(be, cc, tab, G4, pk.challenge_r1, pp, net));
+    };
+    commit_open(pk.T("ssigma")), commit_open(pk.T("sid"));  // :1289-1308
+    for (const DevPtr &ev : {num, den}) {
+        auto sh = c_acc_product_and_share(be, ev, pk.T("mask"), pk.T("unmask0"), pk.T("unmask1"), pk.T("unmask2"), G4, pp, net);
+        if (sh[0].len != G4 || sh[1].len != G4 || sh[2].len != G4) throw ZkError(ZK_ERR_INVALID, "cpermcheck: share vectors of unexpected length");
+        commit_open(ev), commit_open(sh[0].buf), commit_open(sh[1].buf), commit_open(sh[2].buf);  // :1324-1363
+        out.wiring_proofs.push_back(c_sumcheck_product(be, pk.T("eq_r1"), sh[2].buf, G4, pk.challenge_r1, pp, net));  // :1365-1369
+        out.wiring_proofs.push_back(c_sumcheck_product(be, pk.T("eq_r1"), sh[0].buf, G4, pk.challenge_r1, pp, net));
+        out.wiring_proofs.push_back(c_sumcheck_product(be, sh[0].buf, sh[1].buf, G4, pk.challenge_r1, pp, net));
+        out.wiring_opens.push_back(c_open(be, cc, ev, G4, pk.challenge_r1, pp, net));  // :1371-1375
+    }
+    tm.end();
+    if (tm_out) *tm_out = tm;
+    return out;
+}
+
+}  // namespace zkhost

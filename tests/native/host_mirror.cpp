@@ -5,6 +5,8 @@
 //   host_mirror host <in> <out>     no GPU: field arithmetic, PackedSharingParams, the leader rounds, merge / transpose / sub_index
 //   host_mirror gpu  <in> <out>     all parties as threads of this process, one ctx each on GPU 0 (LocalTestNet), or party 0 on
 //                                   the leader-echo net; every collaborative primitive once
+//   host_mirror proof <in> <out>    the protocol drivers (zkhost/hyperplonk.hpp) on tables written by pytest: params = l, n, echo,
+//                                   which (0 dhyperplonk, 1 data-parallel, 2 dpermcheck, 3 cpermcheck); the transcript of every party
 // Record file: { char name[24]; u64 party; u64 nbytes; payload } ...
 #include <cstdio>
 #include <cstring>
@@ -12,7 +14,7 @@
 #include <mutex>
 #include <string>
 
-#include "zkhost/dist_primitive.hpp"
+#include "zkhost/hyperplonk.hpp"
 
 using namespace zkhost;
 
@@ -228,9 +230,41 @@ static void run_party(const Records &in, Records &out, size_t p, Net &net, const
     out.put_u64("comm", p, net.upload), out.put_u64("comm", p, net.download);
 }
 
+// ---- one party's run of a protocol driver ----
+static void put_transcript(Records &out, size_t p, const Transcript &t) {
+    for (auto &pr : t.gate_proofs) out.put("gate_proofs", p, pr);
+    for (auto &co : t.gate_commitments) out.put("gate_commitments", p, co.first), out.put("gate_commitments", p, co.second);
+    for (auto &pr : t.wiring_proofs) out.put("wiring_proofs", p, pr);
+    out.put("wiring_commits", p, t.wiring_commits);
+    for (auto &o : t.wiring_opens) out.put("wiring_opens", p, o);
+    for (const char *name : {"gate_proofs", "gate_commitments", "wiring_proofs", "wiring_commits", "wiring_opens"}) out.put(name, p, nullptr, 0);  // (empty lists still get a record)
+}
+
+static void run_proof(const Records &in, Records &out, size_t p, Net &net, const PackedSharingParams &pp) {
+    size_t n = in.u64("params", 1), which = in.u64("params", 3);
+    Ctx be(0);
+    PackedProvingParameters pk;
+    pk.n = n;
+    for (auto &nl : PackedProvingParameters::layout(n, pp)) {
+        FrVec v = in.fr(nl.first, p);
+        if (v.size() != nl.second) throw std::runtime_error("table " + nl.first + " has an unexpected length");
+        pk.put(be, nl.first, v);
+    }
+    if (which == 3)
+        for (const char *name : {"mask", "unmask0", "unmask1", "unmask2"}) pk.put(be, name, in.fr(name, p));
+    pk.set_challenges(in.fr("chal"));
+    pk.finish_setup(be, pp, in.u64("seeds", p));
+    Timers tm;
+    Transcript t = which == 3 ? cpermcheck(n, pk, pp, be, net, &tm) : which == 2 ? dpermcheck(n, pk, pp, be, net, &tm) : dhyperplonk(n, pk, pp, be, net, &tm, which == 1);
+    put_transcript(out, p, t);
+    out.put_u64("comm", p, net.upload), out.put_u64("comm", p, net.download);
+    if (p == 0)
+        for (auto &kv : tm.t) std::printf("timer %-24s %.6f s\n", kv.first.c_str(), kv.second);
+}
+
 int main(int argc, char **argv) {
     if (argc != 4) {
-        std::fprintf(stderr, "usage: host_mirror host|gpu <in> <out>\n");
+        std::fprintf(stderr, "usage: host_mirror host|gpu|proof <in> <out>\n");
         return 64;
     }
     Records in, out;
@@ -247,11 +281,12 @@ int main(int argc, char **argv) {
                 return 2;
             }
             PackedSharingParams pp(in.u64("params", 0));
+            auto run = !std::strcmp(argv[1], "proof") ? run_proof : run_party;
             if (in.u64("params", 2)) {  // the no-`comm` fake: party 0 alone
                 LeaderEchoNet net(pp.n);
-                run_party(in, out, 0, net, pp);
+                run(in, out, 0, net, pp);
             } else {
-                LocalTestNet::simulate_network_round(pp.n, [&](size_t p, LocalTestNet &net) { run_party(in, out, p, net, pp); });
+                LocalTestNet::simulate_network_round(pp.n, [&](size_t p, LocalTestNet &net) { run(in, out, p, net, pp); });
             }
         }
     } catch (const std::exception &e) {

@@ -266,3 +266,72 @@ def test_cpp_host_equals_python_host_on_the_gpu(tmp_path, l, m, echo):
     assert len(want[("d_sumcheck_product", 0)]) == 96 * (m + pp.n.bit_length() - 1)
     if not echo:
         assert len(want[("d_sumcheck_product", 1)]) == 0 and len(want[("c_open", pp.n - 1)]) == 32 + 144 * (m + pp.l.bit_length() - 1)
+
+
+# ---------------------------------------------------------------------------------------
+# GPU: the protocol drivers of the C++ host (zkhost/hyperplonk.hpp) against zkhip.hyperplonk, transcript by transcript
+# ---------------------------------------------------------------------------------------
+def _flat_transcript(res):
+    (gate_proofs, gate_commitments), (w_proofs, w_commits, w_opens) = res
+    b = lambda *arrs: b"".join(np.ascontiguousarray(a, dtype=np.uint64).tobytes() for a in arrs)
+    return {
+        "gate_proofs": b(*gate_proofs),
+        "gate_commitments": b"".join(b(c, v, prf) for c, (v, prf) in gate_commitments),
+        "wiring_proofs": b(*w_proofs),
+        "wiring_commits": b(*w_commits),
+        "wiring_opens": b"".join(b(v, prf) for v, prf in w_opens),
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,l,n,echo", [("dhyperplonk", 1, 8, False), ("dhyperplonk", 1, 12, True), ("data_parallel", 1, 7, False), ("dhyperplonk", 2, 7, False),
+                                            ("dpermcheck", 1, 8, False), ("cpermcheck", 1, 7, False), ("cpermcheck", 2, 7, True)])
+def test_cpp_protocol_drivers_equal_the_python_drivers(tmp_path, which, l, n, echo):
+    import zkhip
+    from zkhip.field import random_fr
+    from zkhip.hyperplonk import PackedProvingParameters, cpermcheck, dhyperplonk, dpermcheck
+    from zkhip.net import LeaderEchoNet, LocalTestNet
+    from zkhip.pss import PackedSharingParams
+
+    pp = PackedSharingParams(l)
+    M, npar, chal_seed = 1 << n, pp.n, 4242
+    code = {"dhyperplonk": 0, "data_parallel": 1, "dpermcheck": 2, "cpermcheck": 3}[which]
+    records = {("params", 0): np.array([l, n, int(echo), code], dtype=np.uint64), ("seeds", 0): np.array([100 + p for p in range(npar)], dtype=np.uint64)}
+    want = {}
+
+    def party(net):
+        p = net.party_id
+        be = zkhip.Ctx(0)
+        seed, run_seed = 100 + p, 200 + p
+        pk = PackedProvingParameters.new(n, pp, be, seed=seed, chal_seed=chal_seed)
+        rec = {(name, p): pk.tables[name].download((pk.lens[name], 4)) for name in pk.tables if not name.endswith("_evals")}
+        # the per-run random data the Python drivers draw from their `seed` ("Jump from sky", dhyperplonk.rs:187-190, and :603)
+        rec[("local_s_p", p)] = random_fr(4 * M // npar, run_seed * 31 + 1)
+        rec[("local_s_l", p)] = random_fr(4 * M // npar // l, run_seed * 31 + 2)
+        rec[("eq_top", p)] = random_fr(pp.n, run_seed * 31 + 3)
+        rec[("s_data_parallel", p)] = random_fr(4 * M // l, run_seed * 31 + 4)
+        if which == "cpermcheck":
+            for i, name in enumerate(("mask", "unmask0", "unmask1", "unmask2")):
+                rec[(name, p)] = random_fr(4 * (M // l), run_seed * 977 + 50 + i)
+        if p == 0:
+            rec[("chal", 0)] = np.concatenate([pk.challenge, pk.challenge_r1, pk.challenge_r2, pk.alpha[None], pk.beta[None], pk.gamma[None]])
+        if which == "cpermcheck":
+            res = cpermcheck(n, pk, pp, be, net, seed=run_seed)[0]
+            res = (([], []), res)
+        elif which == "dpermcheck":
+            res = (([], []), dpermcheck(n, pk, pp, be, net, seed=run_seed)[0])
+        else:
+            res = dhyperplonk(n, pk, pp, be, net, seed=run_seed, data_parallel=which == "data_parallel")[0]
+        return rec, {(k, p): v for k, v in _flat_transcript(res).items()}
+
+    outs = [party(LeaderEchoNet(npar))] if echo else LocalTestNet.simulate_network_round(npar, party)
+    for rec, tr in outs:
+        records.update(rec)
+        want.update(tr)
+    r, got = _run("proof", records, tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = {k: v for k, v in got.items() if k[0] != "comm"}
+    assert set(got) == set(want), sorted(set(got) ^ set(want))
+    bad = [k for k in sorted(want) if got[k] != want[k]]
+    assert not bad, bad
+    assert len(want[("wiring_proofs", 0)]) > 0 and len(want[("wiring_opens", 0)]) > 0
