@@ -51,6 +51,38 @@ MADS_PER_MADD = 6 * 338 + 2 * 260 + 507  # XYZZ mixed addition on 13x30-bit limb
 FR_MUL_PEAK = 133.0e9  # measured Fr Montgomery mul/s (same file)
 
 
+def cpp_host_e2e(n: int, reps: int = 4):
+    """
+    The same proof driven by the COMPILED host (scalable-collaborative-zksnark_amd/host: zkhost/hyperplonk.hpp, the C++ mirror of the
+    reference's Rust crates above the C ABI) in its own process: leader mode, SplitMix64 tables, best of `reps`.  Its transcripts are
+    bit-identical to the Python driver's on the same inputs (tests/test_host_cpp.py); the figure shows what the host language costs.
+    """
+    import subprocess
+
+    exe = os.path.join(ROOT, "scalable-collaborative-zksnark_amd", "host", "bin", "hyperplonk")
+    if not os.path.exists(exe):
+        return {"error": "host/bin/hyperplonk is not built (__graft_entry__.build())"}
+    try:
+        r = subprocess.run([exe, "--l", "1", "--n", str(n), "--reps", str(reps)], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+        runs, comm = [], None
+        for line in r.stdout.splitlines():
+            w = line.split()
+            if line.startswith("rep "):
+                runs.append({})
+            elif line.startswith("  End:") and runs:
+                runs[-1][" ".join(w[1:-2])] = float(w[-2])
+            elif line.startswith("Comm:"):
+                comm = line[len("Comm: "):]
+        best = min(runs, key=lambda t: t.get("Distributed HyperPlonk", 1e9))
+        return {"timers_s": best, "comm_per_proof": comm, "reps": reps,
+                "what": "the same call sequence from the compiled C++ host (zkhost/hyperplonk.hpp) in its own process, leader mode, synthetic SplitMix64 tables; "
+                        "transcripts bit-identical to the Python driver's on the same inputs (tests/test_host_cpp.py)"}
+    except Exception as ex:
+        return {"error": repr(ex)}
+
+
 def pmc_traffic(kernel: str, pick: str = "most_dispatches"):
     """
     Memory-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this command
@@ -726,6 +758,8 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 ctx.trim()
             except Exception as ex:  # the headline must survive a failure of this leg
                 extra["e2e"] = {"error": repr(ex)}
+            if world == 1 and isinstance(extra.get("e2e"), dict) and "error" not in extra["e2e"]:
+                extra["e2e"]["cpp_host"] = cpp_host_e2e(args.e2e_n)
 
         # ---- G2: `d_msm` is generic over CurveGroup (dmsm.rs:9), powers_of_g2 are G2 points (dpoly_comm.rs:27,59-62) ----
         if world == 1:

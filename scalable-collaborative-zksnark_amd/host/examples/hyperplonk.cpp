@@ -1,0 +1,116 @@
+// The C++ host's counterpart of the reference's hyperplonk/examples/{hyperplonk,bench_hyperplonk,bench_hyperplonk_dataparallel,
+// bench_dpermcheck,bench_cpermcheck}.rs: build the synthetic parameter set (PackedProvingParameters::new, dhyperplonk.rs:65-156),
+// run the collaborative proof on the GPU(s), print the reference's timer labels and its `Comm: (up, down)` line (:564).
+//
+//   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables]
+//     leader   party 0 on the no-`comm` echo net (the reference's `-F leader` build: one party's full work; default)
+//     threads  all 8 l parties as threads of this process, one ctx each, exchanges through host memory (LocalTestNet); the
+//              parties share the visible GPUs round-robin
+//     rccl     all 8 l parties as threads, party p on GPU p, exchanges over RCCL / xGMI inside the ctx (zk_comm_init_all);
+//              needs 8 l GPUs
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "zkhost/hyperplonk.hpp"
+
+using namespace zkhost;
+
+struct Args {
+    size_t l = 1, n = 12, reps = 3;
+    std::string mode = "leader", which = "dhyperplonk";
+    bool tables = true;
+};
+
+static Transcript run_once(const Args &a, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers &tm) {
+    if (a.which == "cpermcheck") return cpermcheck(a.n, pk, pp, be, net, &tm);
+    if (a.which == "dpermcheck") return dpermcheck(a.n, pk, pp, be, net, &tm);
+    return dhyperplonk(a.n, pk, pp, be, net, &tm, a.which == "data-parallel");
+}
+
+static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &net) {
+    size_t p = net.party_id;
+    auto t0 = std::chrono::steady_clock::now();
+    // per-party tables, shared public challenges (the reference's local mode clones ONE parameter set, mpc-net/src/multi.rs:344)
+    PackedProvingParameters pk = PackedProvingParameters::make(be, a.n, pp, 100 + p, 4242, a.tables);
+    if (a.which == "cpermcheck") {
+        size_t G4 = 4 * ((size_t(1) << a.n) / pp.l);
+        const char *names[4] = {"mask", "unmask0", "unmask1", "unmask2"};
+        for (size_t i = 0; i < 4; ++i) pk.put(be, names[i], SplitMix64(977 * (100 + p) + 50 + i).fr_vec(G4));
+    }
+    be.sync();
+    double setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t r = 0; r < a.reps; ++r) {
+        Timers tm;
+        uint64_t up0 = net.upload, down0 = net.download;
+        Transcript t = run_once(a, pk, pp, be, net, tm);
+        if (net.is_leader()) {
+            std::printf("rep %zu (setup %.3f s): proofs %zu + %zu, commitments %zu + %zu, openings %zu\n", r, setup, t.gate_proofs.size(), t.wiring_proofs.size(),
+                        t.gate_commitments.size(), t.wiring_commits.size(), t.wiring_opens.size());
+            for (auto &kv : tm.t) std::printf("  End: %-28s %.6f s\n", kv.first.c_str(), kv.second);
+            std::printf("Comm: (%llu, %llu)\n", (unsigned long long)(net.upload - up0), (unsigned long long)(net.download - down0));
+        }
+    }
+}
+
+int main(int argc, char **argv) {
+    Args a;
+    for (int i = 1; i < argc; ++i) {
+        std::string k = argv[i];
+        auto val = [&]() -> const char * {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "missing value for %s\n", k.c_str());
+                std::exit(64);
+            }
+            return argv[++i];
+        };
+        if (k == "--l") a.l = std::strtoull(val(), nullptr, 10);
+        else if (k == "--n") a.n = std::strtoull(val(), nullptr, 10);
+        else if (k == "--reps") a.reps = std::strtoull(val(), nullptr, 10);
+        else if (k == "--mode") a.mode = val();
+        else if (k == "--which") a.which = val();
+        else if (k == "--no-tables") a.tables = false;
+        else {
+            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables]\n");
+            return 64;
+        }
+    }
+    int ngpu = zk_device_count();
+    if (ngpu <= 0) {
+        std::fprintf(stderr, "hyperplonk: no GPU visible -- this host has no CPU fallback (zk_device_count = %d)\n", ngpu);
+        return 2;
+    }
+    try {
+        PackedSharingParams pp(a.l);
+        if (a.n < log2_floor(pp.n) + 1) throw std::invalid_argument("n too small for this party count");
+        if (a.mode == "leader") {
+            Ctx be(0);
+            LeaderEchoNet net(pp.n);
+            party(a, pp, be, net);
+        } else if (a.mode == "threads") {
+            LocalTestNet::simulate_network_round(pp.n, [&](size_t p, LocalTestNet &net) {
+                Ctx be((int)(p % (size_t)ngpu));
+                party(a, pp, be, net);
+            });
+        } else if (a.mode == "rccl") {
+            if ((size_t)ngpu < pp.n) throw std::invalid_argument("--mode rccl needs one GPU per party (" + std::to_string(pp.n) + "), found " + std::to_string(ngpu));
+            std::vector<std::unique_ptr<Ctx>> ctxs;
+            std::vector<zk_ctx *> raw;
+            for (size_t p = 0; p < pp.n; ++p) ctxs.push_back(std::make_unique<Ctx>((int)p)), raw.push_back(ctxs.back()->handle());
+            ctxs[0]->check(zk_comm_init_all(raw.data(), (int)pp.n));
+            // every party on its own host thread (the collectives block until all parties have entered them)
+            LocalTestNet::simulate_network_round(pp.n, [&](size_t p, LocalTestNet &) {
+                RcclNet net(*ctxs[p]);
+                party(a, pp, *ctxs[p], net);
+            });
+        } else {
+            throw std::invalid_argument("unknown --mode " + a.mode);
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "hyperplonk: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

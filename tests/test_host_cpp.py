@@ -322,7 +322,9 @@ def test_cpp_protocol_drivers_equal_the_python_drivers(tmp_path, which, l, n, ec
             res = (([], []), dpermcheck(n, pk, pp, be, net, seed=run_seed)[0])
         else:
             res = dhyperplonk(n, pk, pp, be, net, seed=run_seed, data_parallel=which == "data_parallel")[0]
-        return rec, {(k, p): v for k, v in _flat_transcript(res).items()}
+        tr = {(k, p): v for k, v in _flat_transcript(res).items()}
+        tr[("comm", p)] = struct.pack("<QQ", net.upload, net.download)  # MPCNet::get_comm accounting of the whole run
+        return rec, tr
 
     outs = [party(LeaderEchoNet(npar))] if echo else LocalTestNet.simulate_network_round(npar, party)
     for rec, tr in outs:
@@ -330,8 +332,56 @@ def test_cpp_protocol_drivers_equal_the_python_drivers(tmp_path, which, l, n, ec
         want.update(tr)
     r, got = _run("proof", records, tmp_path)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    got = {k: v for k, v in got.items() if k[0] != "comm"}
     assert set(got) == set(want), sorted(set(got) ^ set(want))
     bad = [k for k in sorted(want) if got[k] != want[k]]
     assert not bad, bad
     assert len(want[("wiring_proofs", 0)]) > 0 and len(want[("wiring_opens", 0)]) > 0
+
+
+# ---------------------------------------------------------------------------------------
+# the example binary (host/examples/hyperplonk.cpp: the reference's hyperplonk/examples/*.rs in one program)
+# ---------------------------------------------------------------------------------------
+def _example():
+    host = os.path.join(ROOT, "scalable-collaborative-zksnark_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    return os.path.join(host, "bin", "hyperplonk")
+
+
+def test_cpp_example_builds_and_refuses_to_run_without_a_gpu():
+    exe = _example()
+    import zkhip
+
+    if zkhip.lib().zk_device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu test")
+    r = subprocess.run([exe, "--l", "1", "--n", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr, (r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,label,comm", [
+    (["--l", "1", "--n", "12"], "Distributed HyperPlonk", "(959224, 959224)"),  # (the drivers' byte counts are compared with the Python drivers' in the parity test above)
+    (["--l", "1", "--n", "10", "--mode", "threads"], "Distributed HyperPlonk", None),
+    (["--l", "2", "--n", "9", "--mode", "threads", "--which", "cpermcheck"], "Collaborative Permcheck", None),
+    (["--l", "1", "--n", "9", "--which", "dpermcheck"], "Distributed Permcheck", None),
+    (["--l", "1", "--n", "9", "--which", "data-parallel", "--no-tables"], "Distributed HyperPlonk", None),
+])
+def test_cpp_example_on_the_gpu(args, label, comm):
+    exe = _example()
+    r = subprocess.run([exe] + args + ["--reps", "2"], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    ends = [l for l in r.stdout.splitlines() if l.startswith("  End: " + label)]
+    assert len(ends) == 2 and all(float(l.split()[-2]) > 0 for l in ends), r.stdout
+    comms = [l for l in r.stdout.splitlines() if l.startswith("Comm: ")]
+    assert len(comms) == 2 and comms[0] == comms[1]  # the same exchanges every proof
+    if comm:
+        assert comms[0] == "Comm: " + comm
+
+
+@pytest.mark.gpu
+def test_cpp_example_rccl_mode_needs_one_gpu_per_party():
+    import zkhip
+
+    if zkhip.lib().zk_device_count() >= 8:
+        pytest.skip("8 GPUs visible: the mode would run")
+    r = subprocess.run([_example(), "--l", "1", "--n", "8", "--mode", "rccl"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "one GPU per party" in r.stderr
