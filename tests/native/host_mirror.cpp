@@ -262,7 +262,39 @@ static void run_proof(const Records &in, Records &out, size_t p, Net &net, const
         for (auto &kv : tm.t) std::printf("timer %-24s %.6f s\n", kv.first.c_str(), kv.second);
 }
 
+// ---- RcclNet on a world of ONE party (all a one-GPU box can form): the C-ABI communicator under the C++ net, and d_msm as the
+// single zk_d_msm call it becomes when the communicator lives in the compute ctx -- checked against the queue-free local form ----
+static int run_rccl1() {
+    Ctx be(0);
+    uint8_t id[ZK_COMM_ID_BYTES];
+    be.check(zk_comm_unique_id(id));
+    RcclNet net(be, 0, 1, id);
+    PackedSharingParams pp(1);
+    size_t M = 1 << 10;
+    FrVec f = SplitMix64(77).fr_vec(M), g = SplitMix64(78).fr_vec(M / 2);
+    DevPtr df = be.to_device(f), dg = be.to_device(g);
+    PowersOfG pg = PolynomialCommitmentCub::new_single(be, 10, pp, 9).mature();
+    G1Vec got = d_msm(be, {pg[10], pg[9]}, {df, dg}, {M, M / 2}, pp, net);  // -> zk_d_msm (lambda_0 on the device, c_0 on the sum)
+    G1Vec local = be.msm_g1_batch({pg[10].get(), pg[9].get()}, {df, dg}, {M, M / 2});
+    G1Vec want = be.g1_lincomb_batch(local, FrVec{(pp.c(0) * pp.lambda(0)).to_canonical()}, 2);
+    if (got != want) return std::fprintf(stderr, "rccl1: d_msm over RcclNet differs from c_0 lambda_0 MSM\n"), 1;
+    // the exchanges: a world of one returns its own data, through HBM
+    std::vector<FrVec> ag = net.all_gather_fr(FrVec(f.begin(), f.begin() + 5));
+    DevPtr a2a = net.all_to_all_device(be, df, 32 * 7);
+    if (ag.size() != 1 || ag[0] != FrVec(f.begin(), f.begin() + 5) || be.to_host(a2a, 7) != FrVec(f.begin(), f.begin() + 7)) return std::fprintf(stderr, "rccl1: exchange mismatch\n"), 1;
+    if (net.upload != 0 || net.download != 0) return std::fprintf(stderr, "rccl1: a world of one moves no bytes\n"), 1;
+    std::printf("host_mirror ok: rccl world of one\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 2 && !std::strcmp(argv[1], "rccl1")) {
+        try {
+            return zk_device_count() > 0 ? run_rccl1() : (std::fprintf(stderr, "host_mirror: no GPU visible -- no CPU fallback\n"), 2);
+        } catch (const std::exception &e) {
+            return std::fprintf(stderr, "host_mirror: %s\n", e.what()), 1;
+        }
+    }
     if (argc != 4) {
         std::fprintf(stderr, "usage: host_mirror host|gpu|proof <in> <out>\n");
         return 64;

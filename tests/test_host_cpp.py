@@ -385,3 +385,10 @@ def test_cpp_example_rccl_mode_needs_one_gpu_per_party():
         pytest.skip("8 GPUs visible: the mode would run")
     r = subprocess.run([_example(), "--l", "1", "--n", "8", "--mode", "rccl"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "one GPU per party" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_net_and_zk_d_msm_on_a_world_of_one():
+    """RcclNet (zk_comm_unique_id / zk_comm_init / zk_allgather / zk_alltoall) and d_msm as ONE zk_d_msm call, from the C++ host"""
+    r = subprocess.run([_build(), "rccl1"], capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "rccl world of one" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
