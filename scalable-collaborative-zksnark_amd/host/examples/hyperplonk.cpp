@@ -34,7 +34,23 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
     size_t p = net.party_id;
     auto t0 = std::chrono::steady_clock::now();
     // per-party tables, shared public challenges (the reference's local mode clones ONE parameter set, mpc-net/src/multi.rs:344)
-    PackedProvingParameters pk = PackedProvingParameters::make(be, a.n, pp, 100 + p, 4242, a.tables);
+    // experiment hook: ZK_TABLE_POLICY="lo:hi:delta,..." shifts the table width of the levels with lo <= log2(len) <= hi
+    std::function<int(size_t)> policy = nullptr;
+    if (const char *e = std::getenv("ZK_TABLE_POLICY")) {
+        std::string spec = e;
+        policy = [spec](size_t len) {
+            int lg = (int)log2_floor(len), c = lg <= 15 ? lg + 2 : (lg <= 18 ? 17 : lg - 1);  // the library's single-MSM pick (csrc/zk_msm.hip msm_pick_window_full)
+            const char *q = spec.c_str();
+            int lo, hi, d, used;
+            while (std::sscanf(q, "%d:%d:%d%n", &lo, &hi, &d, &used) == 3) {
+                if (lg >= lo && lg <= hi) c += d;
+                q += used;
+                if (*q == ',') ++q;
+            }
+            return std::max(4, std::min(20, c));
+        };
+    }
+    PackedProvingParameters pk = PackedProvingParameters::make(be, a.n, pp, 100 + p, 4242, a.tables, policy);
     if (a.which == "cpermcheck") {
         size_t G4 = 4 * ((size_t(1) << a.n) / pp.l);
         const char *names[4] = {"mask", "unmask0", "unmask1", "unmask2"};

@@ -28,15 +28,27 @@ struct MsmLengthError : ZkError {
 
 class Ctx;
 
+// the zk_ctx itself: shared by the Ctx object and by every buffer / SRS level / job created from it, so that the library
+// context is destroyed only after the last of them (a buffer that outlives its `Ctx` variable stays valid and is freed properly)
+struct CtxHandle {
+    zk_ctx *h = nullptr;
+    explicit CtxHandle(zk_ctx *h_) : h(h_) {}
+    CtxHandle(const CtxHandle &) = delete;
+    ~CtxHandle() {
+        if (h) zk_ctx_destroy(h);
+    }
+};
+using CtxRef = std::shared_ptr<CtxHandle>;
+
 // a device allocation (zk_malloc / zk_free); DevPtr below shares it
 struct DevAlloc {
-    zk_ctx *ctx;
+    CtxRef ctx;
     void *ptr;
     size_t bytes;
-    DevAlloc(zk_ctx *c, void *p, size_t b) : ctx(c), ptr(p), bytes(b) {}
+    DevAlloc(CtxRef c, void *p, size_t b) : ctx(std::move(c)), ptr(p), bytes(b) {}
     DevAlloc(const DevAlloc &) = delete;
     ~DevAlloc() {
-        if (ptr) zk_free(ctx, ptr);
+        if (ptr) zk_free(ctx->h, ptr);
     }
 };
 
@@ -55,16 +67,16 @@ struct DevPtr {
 // one SRS level resident in HBM (zk_srs)
 class Srs {
   public:
-    Srs(zk_ctx *c, zk_srs *h) : ctx_(c), h_(h) {}
+    Srs(CtxRef c, zk_srs *h) : ctx_(std::move(c)), h_(h) {}
     Srs(const Srs &) = delete;
     ~Srs() {
-        if (h_) zk_srs_free(ctx_, h_);
+        if (h_) zk_srs_free(ctx_->h, h_);
     }
     zk_srs *handle() const { return h_; }
     size_t len() const { return zk_srs_len(h_); }
 
   private:
-    zk_ctx *ctx_;
+    CtxRef ctx_;
     zk_srs *h_;
 };
 using SrsPtr = std::shared_ptr<Srs>;
@@ -87,11 +99,9 @@ class Ctx {
     explicit Ctx(int device = 0) {
         int rc = zk_ctx_create(device, &h_);
         if (rc) throw ZkError(rc, "zk_ctx_create failed (no gfx950 device / library without device code?)");
+        ref_ = std::make_shared<CtxHandle>(h_);
     }
     Ctx(const Ctx &) = delete;
-    ~Ctx() {
-        if (h_) zk_ctx_destroy(h_);
-    }
     zk_ctx *handle() const { return h_; }
     void check(int rc) const {
         if (rc == ZK_ERR_LENGTH) throw MsmLengthError(rc, zk_last_error(h_));
@@ -103,7 +113,7 @@ class Ctx {
     DevPtr alloc(size_t bytes) {
         void *p = nullptr;
         check(zk_malloc(h_, bytes ? bytes : 1, &p));
-        return DevPtr(std::make_shared<DevAlloc>(h_, p, bytes), (char *)p);
+        return DevPtr(std::make_shared<DevAlloc>(ref_, p, bytes), (char *)p);
     }
     DevPtr alloc_fr(size_t n) { return alloc(32 * n); }
     void upload(const DevPtr &dst, const void *src, size_t bytes) {
@@ -227,28 +237,28 @@ class Ctx {
     SrsPtr srs_register(const void *bases, size_t stride, size_t n) {
         zk_srs *s = nullptr;
         check(zk_srs_register(h_, bases, stride, n, &s));
-        return std::make_shared<Srs>(h_, s);
+        return std::make_shared<Srs>(ref_, s);
     }
     // P_i = (k0 + i k1) G (canonical scalars)
     SrsPtr srs_generate(uint64_t k0, uint64_t k1, size_t n) {
         uint64_t a[4] = {k0, 0, 0, 0}, b[4] = {k1, 0, 0, 0};
         zk_srs *s = nullptr;
         check(zk_srs_generate(h_, a, b, n, &s));
-        return std::make_shared<Srs>(h_, s);
+        return std::make_shared<Srs>(ref_, s);
     }
     // PolynomialCommitmentCub::new (dpoly_comm.rs:37-67): levels 0 .. nvars
     std::vector<SrsPtr> srs_powers(const FrVec &s, const void *g96 = nullptr) {
         std::vector<zk_srs *> lv(s.size() + 1, nullptr);
         check(zk_srs_powers(h_, g96, s.empty() ? nullptr : s[0].v, s.size(), lv.data()));
         std::vector<SrsPtr> out;
-        for (zk_srs *x : lv) out.push_back(std::make_shared<Srs>(h_, x));
+        for (zk_srs *x : lv) out.push_back(std::make_shared<Srs>(ref_, x));
         return out;
     }
     // to_packed for ONE party (dpoly_comm.rs:164-194): row = l canonical pack coefficients
     SrsPtr srs_to_packed(const Srs &level, const FrVec &row_canonical, size_t l) {
         zk_srs *s = nullptr;
         check(zk_srs_to_packed(h_, level.handle(), row_canonical[0].v, l, &s));
-        return std::make_shared<Srs>(h_, s);
+        return std::make_shared<Srs>(ref_, s);
     }
     void srs_precompute(Srs &s, int window_bits = 0) { check(zk_srs_precompute(h_, s.handle(), window_bits)); }
 
@@ -272,7 +282,7 @@ class Ctx {
     // asynchronous form: the pass runs on the ctx's job lanes while the caller enqueues other work; wait() collects the points.
     // The scalar buffers must stay alive and unmodified until then (MsmJob holds them).
     struct MsmJob {
-        zk_ctx *ctx = nullptr;
+        CtxRef ctx;
         zk_msm_job *job = nullptr;
         size_t count = 0;
         std::vector<DevPtr> keep;
@@ -281,7 +291,7 @@ class Ctx {
         MsmJob(MsmJob &&o) noexcept { *this = std::move(o); }
         MsmJob &operator=(MsmJob &&o) noexcept {
             drain();
-            ctx = o.ctx, job = o.job, count = o.count, keep = std::move(o.keep);
+            ctx = std::move(o.ctx), job = o.job, count = o.count, keep = std::move(o.keep);
             o.job = nullptr;
             return *this;
         }
@@ -290,7 +300,7 @@ class Ctx {
         void drain() {  // never waited for: let it finish and release it
             if (job) {
                 G1Vec tmp(count);
-                zk_msm_wait(ctx, job, tmp[0].data());
+                zk_msm_wait(ctx->h, job, tmp[0].data());
                 job = nullptr;
             }
         }
@@ -302,7 +312,7 @@ class Ctx {
         std::vector<const void *> sp(count);
         for (size_t i = 0; i < count; ++i) h[i] = srs[i]->handle(), sp[i] = scalars[i].get();
         MsmJob j;
-        j.ctx = h_, j.count = count, j.keep = scalars;
+        j.ctx = ref_, j.count = count, j.keep = scalars;
         check(zk_msm_g1_batch_async(h_, count, h.data(), nullptr, sp.data(), lens.data(), &j.job));
         return j;
     }
@@ -353,6 +363,7 @@ class Ctx {
         return out;
     }
     zk_ctx *h_ = nullptr;
+    CtxRef ref_;
 };
 
 }  // namespace zkhost

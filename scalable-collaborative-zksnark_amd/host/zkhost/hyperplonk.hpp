@@ -92,7 +92,9 @@ struct PackedProvingParameters {
     // the folds of V and the synthetic SRS (random points in the reference as well); window_tables: build the MSM window
     // table of every level up to 2^table_max_log2 points (setup work like generating the level; results are bit-identical
     // with and without); a level is skipped when its table would leave less than 40 % of the device free
-    void finish_setup(Ctx &be, const PackedSharingParams &pp, uint64_t seed, bool window_tables = true, size_t table_max_log2 = 24) {
+    // window_bits(len): width of a level's table (0 = the library's pick for a single MSM of that length)
+    void finish_setup(Ctx &be, const PackedSharingParams &pp, uint64_t seed, bool window_tables = true, size_t table_max_log2 = 24,
+                      const std::function<int(size_t)> &window_bits = nullptr) {
         size_t M = size_t(1) << n, l = pp.l;
         Fr zero = Fr::zero(), one = Fr::one();
         const std::pair<const char *, std::array<Fr, 2>> folds[3] = {{"a_evals", {zero, zero}}, {"b_evals", {zero, one}}, {"c_evals", {one, zero}}};
@@ -114,19 +116,20 @@ struct PackedProvingParameters {
                 be.check(zk_mem_info(be.handle(), &fr, &tot));
                 if ((double)fr - 16.0 * 96.0 * (double)len < 0.4 * (double)tot) break;
             }
-            int rc = zk_srs_precompute(be.handle(), lv->handle(), 0);
+            int rc = zk_srs_precompute(be.handle(), lv->handle(), window_bits ? window_bits(len) : 0);
             if (rc == ZK_ERR_OOM) break;
             be.check(rc);
         }
     }
     // dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy(): tables from SplitMix64(seed ...)
-    static PackedProvingParameters make(Ctx &be, size_t n, const PackedSharingParams &pp, uint64_t seed, uint64_t chal_seed = 0, bool window_tables = true) {
+    static PackedProvingParameters make(Ctx &be, size_t n, const PackedSharingParams &pp, uint64_t seed, uint64_t chal_seed = 0, bool window_tables = true,
+                                        const std::function<int(size_t)> &window_bits = nullptr) {
         PackedProvingParameters pk;
         pk.n = n;
         uint64_t sd = 0x5CA1AB1Eull + 1000 * seed;
         for (auto &nl : layout(n, pp)) pk.put(be, nl.first, SplitMix64(++sd).fr_vec(nl.second));
         pk.set_challenges(SplitMix64(chal_seed ? chal_seed : ++sd).fr_vec(3 * n + 7));  // public values every party shares
-        pk.finish_setup(be, pp, seed, window_tables);
+        pk.finish_setup(be, pp, seed, window_tables, 24, window_bits);
         return pk;
     }
 };

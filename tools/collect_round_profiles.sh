@@ -11,6 +11,12 @@ python tools/msm_time.py 12 14 16 18 20 22 24 > gpurun_out/${T}_msm_sizes.txt 2>
 tools/trace_one_msm_table.sh 20 > gpurun_out/${T}_msm_2e20_dispatch_timeline.txt 2>&1
 for n in 12 16 20 24; do python tools/hyperplonk_bench.py --n $n --reps 3 | tail -1; done > gpurun_out/${T}_e2e.jsonl 2>&1
 for n in 12 16 20; do python tools/hyperplonk_bench.py --n $n --party-threads | tail -1; done > gpurun_out/${T}_e2e_party_threads.jsonl 2>&1
+# the same proofs from the compiled C++ host (host/examples/hyperplonk.cpp): leader mode n = 12 .. 24, 8 party threads on the one GPU, cpermcheck
+{ B=scalable-collaborative-zksnark_amd/host/bin/hyperplonk
+  for n in 12 16 20 24; do echo "== hyperplonk --l 1 --n $n --reps 4 (leader)"; $B --l 1 --n $n --reps 4 | tail -7; done
+  for n in 12 16 20; do echo "== hyperplonk --l 1 --n $n --mode threads --reps 3 (8 party threads, ONE GPU does the work of eight)"; $B --l 1 --n $n --mode threads --reps 3 | tail -7; done
+  echo "== hyperplonk --l 2 --n 16 --which cpermcheck --reps 3 (leader)"; $B --l 2 --n 16 --which cpermcheck --reps 3 | tail -3
+} > gpurun_out/${T}_e2e_cpp_host.txt 2>&1
 python tools/g2_time.py 17 0 > gpurun_out/${T}_g2.txt 2>&1
 python tools/cpermcheck_time.py 20 3 > gpurun_out/${T}_cpermcheck.jsonl 2>&1
 python tools/sc_batch_time.py 18 > gpurun_out/${T}_sc_batch.txt 2>&1
