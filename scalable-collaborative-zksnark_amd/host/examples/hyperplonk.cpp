@@ -2,7 +2,7 @@
 // bench_dpermcheck,bench_cpermcheck}.rs: build the synthetic parameter set (PackedProvingParameters::new, dhyperplonk.rs:65-156),
 // run the collaborative proof on the GPU(s), print the reference's timer labels and its `Comm: (up, down)` line (:564).
 //
-//   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables]
+//   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2]
 //     leader   party 0 on the no-`comm` echo net (the reference's `-F leader` build: one party's full work; default)
 //     threads  all 8 l parties as threads of this process, one ctx each, exchanges through host memory (LocalTestNet); the
 //              parties share the visible GPUs round-robin
@@ -19,7 +19,7 @@
 using namespace zkhost;
 
 struct Args {
-    size_t l = 1, n = 12, reps = 3;
+    size_t l = 1, n = 12, reps = 3, table_max = 24;
     std::string mode = "leader", which = "dhyperplonk";
     bool tables = true;
 };
@@ -50,7 +50,7 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
             return std::max(4, std::min(20, c));
         };
     }
-    PackedProvingParameters pk = PackedProvingParameters::make(be, a.n, pp, 100 + p, 4242, a.tables, policy);
+    PackedProvingParameters pk = PackedProvingParameters::make(be, a.n, pp, 100 + p, 4242, a.tables, policy, a.table_max);
     if (a.which == "cpermcheck") {
         size_t G4 = 4 * ((size_t(1) << a.n) / pp.l);
         const char *names[4] = {"mask", "unmask0", "unmask1", "unmask2"};
@@ -88,8 +88,9 @@ int main(int argc, char **argv) {
         else if (k == "--mode") a.mode = val();
         else if (k == "--which") a.which = val();
         else if (k == "--no-tables") a.tables = false;
+        else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
         else {
-            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables]\n");
+            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2]\n");
             return 64;
         }
     }

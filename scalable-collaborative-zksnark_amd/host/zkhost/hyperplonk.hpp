@@ -123,13 +123,13 @@ struct PackedProvingParameters {
     }
     // dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy(): tables from SplitMix64(seed ...)
     static PackedProvingParameters make(Ctx &be, size_t n, const PackedSharingParams &pp, uint64_t seed, uint64_t chal_seed = 0, bool window_tables = true,
-                                        const std::function<int(size_t)> &window_bits = nullptr) {
+                                        const std::function<int(size_t)> &window_bits = nullptr, size_t table_max_log2 = 24) {
         PackedProvingParameters pk;
         pk.n = n;
         uint64_t sd = 0x5CA1AB1Eull + 1000 * seed;
         for (auto &nl : layout(n, pp)) pk.put(be, nl.first, SplitMix64(++sd).fr_vec(nl.second));
         pk.set_challenges(SplitMix64(chal_seed ? chal_seed : ++sd).fr_vec(3 * n + 7));  // public values every party shares
-        pk.finish_setup(be, pp, seed, window_tables, 24, window_bits);
+        pk.finish_setup(be, pp, seed, window_tables, table_max_log2, window_bits);
         return pk;
     }
 };
