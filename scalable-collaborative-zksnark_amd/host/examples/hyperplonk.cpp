@@ -2,7 +2,7 @@
 // bench_dpermcheck,bench_cpermcheck}.rs: build the synthetic parameter set (PackedProvingParameters::new, dhyperplonk.rs:65-156),
 // run the collaborative proof on the GPU(s), print the reference's timer labels and its `Comm: (up, down)` line (:564).
 //
-//   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2]
+//   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--digest]
 //     leader   party 0 on the no-`comm` echo net (the reference's `-F leader` build: one party's full work; default)
 //     threads  all 8 l parties as threads of this process, one ctx each, exchanges through host memory (LocalTestNet); the
 //              parties share the visible GPUs round-robin
@@ -14,6 +14,7 @@
 #include <memory>
 #include <string>
 
+#include "sha256.hpp"
 #include "zkhost/hyperplonk.hpp"
 
 using namespace zkhost;
@@ -21,13 +22,25 @@ using namespace zkhost;
 struct Args {
     size_t l = 1, n = 12, reps = 3, table_max = 24;
     std::string mode = "leader", which = "dhyperplonk";
-    bool tables = true;
+    bool tables = true, digest = false;
 };
 
 static Transcript run_once(const Args &a, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers &tm) {
     if (a.which == "cpermcheck") return cpermcheck(a.n, pk, pp, be, net, &tm);
     if (a.which == "dpermcheck") return dpermcheck(a.n, pk, pp, be, net, &tm);
     return dhyperplonk(a.n, pk, pp, be, net, &tm, a.which == "data-parallel");
+}
+
+// SHA-256 over the transcript in the reference's order: gate proofs, (commitment, value, proofs) of the six gate openings, wiring
+// proofs, wiring commitments, (value, proofs) of the wiring openings -- raw limbs, as tests/test_host_cpp.py hashes the Python host's
+static std::string transcript_digest(const Transcript &t) {
+    Sha256 h;
+    for (auto &p : t.gate_proofs) h.update(p.data(), 96 * p.size());
+    for (auto &c : t.gate_commitments) h.update(c.first.data(), 144), h.update(c.second.value.v, 32), h.update(c.second.proofs.data(), 144 * c.second.proofs.size());
+    for (auto &p : t.wiring_proofs) h.update(p.data(), 96 * p.size());
+    h.update(t.wiring_commits.data(), 144 * t.wiring_commits.size());
+    for (auto &o : t.wiring_opens) h.update(o.value.v, 32), h.update(o.proofs.data(), 144 * o.proofs.size());
+    return h.hex();
 }
 
 static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &net) {
@@ -67,6 +80,7 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
                         t.gate_commitments.size(), t.wiring_commits.size(), t.wiring_opens.size());
             for (auto &kv : tm.t) std::printf("  End: %-28s %.6f s\n", kv.first.c_str(), kv.second);
             std::printf("Comm: (%llu, %llu)\n", (unsigned long long)(net.upload - up0), (unsigned long long)(net.download - down0));
+            if (a.digest) std::printf("transcript sha256 %s\n", transcript_digest(t).c_str());
         }
     }
 }
@@ -88,9 +102,10 @@ int main(int argc, char **argv) {
         else if (k == "--mode") a.mode = val();
         else if (k == "--which") a.which = val();
         else if (k == "--no-tables") a.tables = false;
+        else if (k == "--digest") a.digest = true;
         else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
         else {
-            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2]\n");
+            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--digest]\n");
             return 64;
         }
     }

@@ -88,6 +88,38 @@ def random_fr(n: int, seed: int) -> np.ndarray:
     return out
 
 
+def splitmix_fr(n: int, seed: int) -> np.ndarray:
+    """
+    n uniform field elements from SplitMix64(seed) by rejection (SURVEY.md 8(d) "Synthetic inputs"): candidate k takes outputs
+    4k+1 .. 4k+4 of the generator as limbs 0..3 (top bit of limb 3 cleared) and is kept when it is < r.  The generator's state is
+    seed + k * gamma, so every output is computable on its own: vectorised here, sequential in the C++ host
+    (host/zkhost/hyperplonk.hpp SplitMix64) -- the same elements.
+    """
+    gamma, m1, m2 = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xBF58476D1CE4E5B9), np.uint64(0x94D049BB133111EB)
+    out = np.empty((n, 4), dtype=np.uint64)
+    filled, k0 = 0, 0  # candidates consumed so far
+    with np.errstate(over="ignore"):
+        while filled < n:
+            m = max(16, int((n - filled) * 1.12) + 8)
+            idx = np.arange(4 * k0 + 1, 4 * (k0 + m) + 1, dtype=np.uint64)
+            z = np.uint64(seed & _M64) + idx * gamma
+            z = (z ^ (z >> np.uint64(30))) * m1
+            z = (z ^ (z >> np.uint64(27))) * m2
+            cand = (z ^ (z >> np.uint64(31))).reshape(m, 4)
+            cand[:, 3] &= np.uint64(0x7FFFFFFFFFFFFFFF)
+            lt = np.zeros(m, dtype=bool)
+            eq = np.ones(m, dtype=bool)
+            for k in (3, 2, 1, 0):
+                lt |= eq & (cand[:, k] < _R_LIMBS[k])
+                eq &= cand[:, k] == _R_LIMBS[k]
+            good = cand[lt]
+            take = min(len(good), n - filled)
+            out[filled : filled + take] = good[:take]
+            filled += take
+            k0 += m
+    return out
+
+
 def jacobian_to_affine_ints(j18):
     """normalised Jacobian (18 u64, as returned by zk_msm_g1) -> (x, y) ints or None"""
     j = np.asarray(j18, dtype=np.uint64).reshape(18)

@@ -14,7 +14,7 @@ from typing import Dict, List
 import numpy as np
 
 from . import dist_primitive as dp
-from .field import fr_mont, random_fr
+from .field import fr_mont, random_fr, splitmix_fr
 from .net import Net
 from .pss import PackedSharingParams
 
@@ -87,6 +87,44 @@ class PackedProvingParameters:
         ch = random_fr(3 * n + 4 + 3, sd[0] if chal_seed is None else chal_seed)
         pk.challenge, pk.challenge_r1, pk.challenge_r2 = ch[:n], ch[n : 2 * n + 2], ch[2 * n + 2 : 3 * n + 4]
         pk.alpha, pk.beta, pk.gamma = ch[3 * n + 4], ch[3 * n + 5], ch[3 * n + 6]
+        pk._synthetic_srs(be, pp, seed, window_tables, table_max_log2)
+        return pk
+
+    # the 21 tables of the SplitMix64 parameter set, in generation order (seed + 1, + 2, ..): the 17 of dhyperplonk.rs:65-156 and the
+    # per-run random data of the drivers ("Jump from sky" :187-190, the data-parallel s :603), which this form keeps with the tables
+    SPLITMIX_LAYOUT = ("V", "I", "I_p", "S1", "S2", "S1_p", "S2_p", "ssigma", "ssigma_p", "sid", "sid_p", "eq", "eq_top_p", "eq_r1", "eq_r1_p",
+                       "eq_r2", "eq_r2_p", "local_s_p", "local_s_l", "eq_top", "s_data_parallel")
+
+    @staticmethod
+    def new_splitmix(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = 0, window_tables: bool = True, table_max_log2: int = 24) -> "PackedProvingParameters":
+        """
+        The parameter set the C++ host builds (host/zkhost/hyperplonk.hpp `PackedProvingParameters::make`): every table from
+        SplitMix64(0x5CA1AB1E + 1000 seed + k) (SURVEY.md 8(d) "Synthetic inputs"), the same challenges and SRS seeds -- so that a
+        proof of one host can be compared with the other's bit for bit at any size (tests/test_host_cpp.py).
+        """
+        l, npar, M = pp.l, pp.n, 1 << n
+        lens = {"V": 4 * M // l, "I": M // l, "I_p": M // npar, "S1": M // l, "S2": M // l, "S1_p": M // npar, "S2_p": M // npar, "ssigma": 4 * M // l,
+                "ssigma_p": 4 * M // npar, "sid": 4 * M // l, "sid_p": 4 * M // npar, "eq": M // l, "eq_top_p": 2 * npar, "eq_r1": 4 * M // l,
+                "eq_r1_p": 4 * M // npar, "eq_r2": 4 * M // l, "eq_r2_p": 4 * M // npar, "local_s_p": 4 * M // npar, "local_s_l": 4 * M // npar // l,
+                "eq_top": npar, "s_data_parallel": 4 * M // l}
+        pk = PackedProvingParameters(n=n)
+        sd = 0x5CA1AB1E + 1000 * seed
+        for name in PackedProvingParameters.SPLITMIX_LAYOUT:
+            sd += 1
+            pk.tables[name] = be.to_device(splitmix_fr(lens[name], sd))
+            pk.lens[name] = lens[name]
+        zero, one = fr_mont(0), fr_mont(1)
+        for name, pts in (("a_evals", (zero, zero)), ("b_evals", (zero, one)), ("c_evals", (one, zero))):
+            pk.tables[name] = be.fold(pk.tables["V"], 4 * M // l, np.stack(pts))
+            pk.lens[name] = M // l
+        ch = splitmix_fr(3 * n + 7, chal_seed if chal_seed else sd + 1)
+        pk.challenge, pk.challenge_r1, pk.challenge_r2 = ch[:n], ch[n : 2 * n + 2], ch[2 * n + 2 : 3 * n + 4]
+        pk.alpha, pk.beta, pk.gamma = ch[3 * n + 4], ch[3 * n + 5], ch[3 * n + 6]
+        pk._synthetic_srs(be, pp, seed, window_tables, table_max_log2)
+        return pk
+
+    def _synthetic_srs(pk, be, pp, seed, window_tables, table_max_log2):
+        n, l, npar = pk.n, pp.l, pp.n
         # synthetic SRS (random points in the reference as well)
         pk.c_commitment = [be.srs_generate(seed * 7919 + 2 * i + 1, seed * 104729 + 2 * i + 3, max(1, (1 << i) // l)) for i in range(n + 3)]
         pk.d_commitment = [be.srs_generate(seed * 6007 + 2 * i + 5, seed * 15485863 + 2 * i + 7, 1 << i) for i in range(n - (npar.bit_length() - 1) + 3)]
@@ -104,7 +142,16 @@ class PackedProvingParameters:
                         if getattr(e, "code", None) != -6:  # ZK_ERR_OOM: keep going without the remaining tables
                             raise
                         break
-        return pk
+
+
+def _per_run_data(pk, pp, be, net, seed):
+    """"Jump from sky" (dhyperplonk.rs:187-190): the per-run random tables -- the parameter set's own when it carries them
+    (PackedProvingParameters.new_splitmix), otherwise drawn from `seed`; resident like every other table"""
+    T, M, l, npar = pk.tables, 1 << pk.n, pp.l, net.n_parties
+    if "local_s_p" in T:
+        return T["local_s_p"], T["local_s_l"], T["eq_top"]
+    return (be.to_device(random_fr(4 * M // npar, seed * 31 + 1)), be.to_device(random_fr(4 * M // npar // l, seed * 31 + 2)),
+            be.to_device(random_fr(pp.n, seed * 31 + 3)))
 
 
 def _halves(buf, length):
@@ -136,7 +183,7 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
     wiring_proofs, wiring_commits, wiring_opens = [], [], []
     # 2.a (:268-294): every party broadcasts local_s; s = concatenation over parties (an all-gather)
     if data_parallel:
-        s_dev = be.to_device(random_fr(4 * M // l, seed * 31 + 4))
+        s_dev = T["s_data_parallel"] if "s_data_parallel" in T else be.to_device(random_fr(4 * M // l, seed * 31 + 4))
     elif hasattr(net, "all_gather_device") and getattr(net, "ctx", None) is be:  # (a foreign ctx's stream is not ordered with ours)
         # RCCL inside the ctx: the 4M/(l N_p) Fr of every party meet in HBM (256 MiB per party at n = 24),
         # nothing crosses PCIe
@@ -233,9 +280,7 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     M = 1 << n
     tm = Timers(net.is_leader)
     # "Jump from sky" (:187-190)
-    local_s_p = be.to_device(random_fr(4 * M // npar, seed * 31 + 1))
-    local_s_l = be.to_device(random_fr(4 * M // npar // l, seed * 31 + 2))  # resident, like every other table
-    eq_top = be.to_device(random_fr(pp.n, seed * 31 + 3))
+    local_s_p, local_s_l, eq_top = _per_run_data(pk, pp, be, net, seed)
     net.sync()
     tm.start("Distributed HyperPlonk")
 
@@ -309,9 +354,7 @@ def dpermcheck(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be,
     l, npar = pp.l, net.n_parties
     M = 1 << n
     tm = Timers(net.is_leader)
-    local_s_l = be.to_device(random_fr(4 * M // npar // l, seed * 31 + 2))
-    local_s_p = be.to_device(random_fr(4 * M // npar, seed * 31 + 1))
-    eq_top = be.to_device(random_fr(pp.n, seed * 31 + 3))
+    local_s_p, local_s_l, eq_top = _per_run_data(pk, pp, be, net, seed)
     net.sync()
     tm.start("Distributed Permcheck")
     res = _wiring_identity(n, pk, pp, be, net, seed, False, local_s_p, local_s_l, eq_top)

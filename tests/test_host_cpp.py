@@ -392,3 +392,35 @@ def test_cpp_rccl_net_and_zk_d_msm_on_a_world_of_one():
     """RcclNet (zk_comm_unique_id / zk_comm_init / zk_allgather / zk_alltoall) and d_msm as ONE zk_d_msm call, from the C++ host"""
     r = subprocess.run([_build(), "rccl1"], capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and "rccl world of one" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,n", [("dhyperplonk", 20), ("data-parallel", 16), ("dpermcheck", 18)])
+def test_cpp_host_full_size_proof_has_the_python_hosts_digest(which, n):
+    """
+    BASELINE configs[3] (n = 20, l = 1) from the compiled host: the same SplitMix64 parameter set built by both hosts
+    (PackedProvingParameters::make / .new_splitmix), leader mode, SHA-256 over the whole transcript.  The Python driver's
+    transcripts at this size are pinned by the anchored checks of tests/test_gpu_e2e_fullsize.py.
+    """
+    import hashlib
+
+    import zkhip
+    from zkhip.hyperplonk import PackedProvingParameters, dhyperplonk, dpermcheck
+    from zkhip.net import LeaderEchoNet
+    from zkhip.pss import PackedSharingParams
+
+    r = subprocess.run([_example(), "--l", "1", "--n", str(n), "--which", which, "--reps", "2", "--digest"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    digests = [l.split()[-1] for l in r.stdout.splitlines() if l.startswith("transcript sha256")]
+    assert len(digests) == 2 and digests[0] == digests[1]  # (and the proof is reproducible run to run)
+
+    pp, be = PackedSharingParams(1), zkhip.Ctx(0)
+    pk = PackedProvingParameters.new_splitmix(n, pp, be, seed=100, chal_seed=4242)
+    net = LeaderEchoNet(8)
+    if which == "dpermcheck":
+        res = (([], []), dpermcheck(n, pk, pp, be, net)[0])
+    else:
+        res = dhyperplonk(n, pk, pp, be, net, data_parallel=which == "data-parallel")[0]
+    t = _flat_transcript(res)
+    want = hashlib.sha256(b"".join(t[k] for k in ("gate_proofs", "gate_commitments", "wiring_proofs", "wiring_commits", "wiring_opens"))).hexdigest()
+    assert digests[0] == want
