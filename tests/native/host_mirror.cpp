@@ -15,6 +15,7 @@
 #include <string>
 
 #include "zkhost/hyperplonk.hpp"
+#include "zkhost/serialize.hpp"
 
 using namespace zkhost;
 
@@ -154,6 +155,30 @@ static void run_host(const Records &in, Records &out) {
         out.put("round_plain", 0, s.data(), 64);
     }
     out.put("round_last", 0, FrVec{f[0], g[0], v[0]});
+    // wire formats (zkhost/serialize.hpp): Fr, Vec<Fr>, G1 compressed / uncompressed (+ round trips), the delegator's share files
+    {
+        out.put("fr_vec_serialize", 0, fr_vec_serialize(a).data(), 8 + 32 * a.size());
+        if (fr_vec_deserialize(fr_vec_serialize(a)) != a) throw std::runtime_error("Vec<Fr> round trip");
+        const Bytes &raw = in.rec.at({"points", 0});
+        G1Vec pts(raw.size() / 144);
+        std::memcpy(pts.data(), raw.data(), raw.size());
+        Bytes comp, unc;
+        for (const G1 &p : pts) {
+            G1Affine af = g1_affine(p);
+            size_t c0 = comp.size(), u0 = unc.size();
+            g1_serialize_compressed(af, comp), g1_serialize_uncompressed(af, unc);
+            G1Affine b1 = g1_deserialize_compressed(&comp[c0]), b2 = g1_deserialize_uncompressed(&unc[u0]);
+            for (const G1Affine &b : {b1, b2})
+                if (b.infinity != af.infinity || (!af.infinity && (b.x != af.x || b.y != af.y))) throw std::runtime_error("G1 round trip");
+        }
+        out.put("g1_compressed", 0, comp.data(), comp.size()), out.put("g1_uncompressed", 0, unc.data(), unc.size());
+        Bytes vec = g1_vec_serialize_compressed(pts);
+        out.put("g1_vec_compressed", 0, vec.data(), vec.size());
+        if (in.rec.count({"dir", 0})) {
+            const Bytes &d = in.rec.at({"dir", 0});
+            delegator_write(std::string(d.begin(), d.end()), a, PackedSharingParams(2));
+        }
+    }
     // merge (dacc_product.rs:416-428) of 3 vectors of 7, sub_index (:18-23; KAT :442-448), transpose (operator.rs:42-49)
     std::vector<FrVec> parts;
     for (size_t q = 0; q < 3; ++q) parts.emplace_back(a.begin() + 7 * q, a.begin() + 7 * q + 7);
@@ -222,6 +247,13 @@ static void run_party(const Records &in, Records &out, size_t p, Net &net, const
     out.put("d_unpack2", p, d_unpack2(share, 1 % P, pp, net));
     out.put("d_unpack2_many", p, d_unpack2_many(be, few, 0, pp, net));
 
+    if (p == 0 && in.rec.count({"dir", 0})) {  // a share file onto the device and back (Montgomery conversion on the GPU)
+        const Bytes &d = in.rec.at({"dir", 0});
+        std::string dir(d.begin(), d.end());
+        auto [buf, cnt] = fr_file_to_device(be, dir + "/worker_3");
+        out.put("share_file_on_device", 0, be.to_host(buf, cnt));
+        fr_device_to_file(be, buf, cnt, dir + "/worker_3.copy");
+    }
     auto sh = c_acc_product_and_share(be, f, g, h0, h1, h2, M, pp, net);
     for (auto &s : sh) {
         out.put_u64("c_acc_share_len", p, s.len);

@@ -73,8 +73,32 @@ def test_cpp_host_arithmetic_pss_and_leader_rounds_match_the_oracle(tmp_path):
     a, b = rng.fr_vec(64), rng.fr_vec(64)
     a[5] = 0
     ls = [1, 2, 4, 8]
-    r, out = _run("host", {("a", 0): _mont(a), ("b", 0): _mont(b), ("ls", 0): np.array(ls, dtype=np.uint64)}, tmp_path)
+    # points for the wire formats: k G (python big-int group law), infinity, and a point whose y is the smaller root
+    from helpers import pt_mont
+    import zkhip.serialize as ser
+    from zkhip.pss import PackedSharingParams as HostPP
+
+    pts = [po.g1_mul(po.G1_GEN, k) for k in (1, 2, 3, 0x1234567, R - 1)] + [None]
+    one_q = np.array(po.fq_to_mont_limbs(1), dtype=np.uint64)
+    jac = np.stack([np.concatenate([pt_mont(P), one_q if P is not None else np.zeros(6, dtype=np.uint64)]) for P in pts])
+    share_dir = tmp_path / "shares"
+    share_dir.mkdir()
+    r, out = _run("host", {("a", 0): _mont(a), ("b", 0): _mont(b), ("ls", 0): np.array(ls, dtype=np.uint64), ("points", 0): jac,
+                           ("dir", 0): np.frombuffer(str(share_dir).encode(), dtype=np.uint8)}, tmp_path)
     assert r.returncode == 0, r.stderr
+    # wire formats against zkhip.serialize (python big-ints) -- the C++ side has already checked its own round trips
+    assert out[("fr_vec_serialize", 0)] == ser.fr_vec_serialize(a)
+    assert out[("g1_compressed", 0)] == b"".join(ser.g1_serialize_compressed(P) for P in pts)
+    assert out[("g1_uncompressed", 0)] == b"".join(ser.g1_serialize_uncompressed(P) for P in pts)
+    assert out[("g1_vec_compressed", 0)] == ser.g1_vec_serialize_compressed(pts) and len(out[("g1_vec_compressed", 0)]) == 8 + 48 * len(pts)
+    assert {bool(ser.g1_serialize_compressed(P)[0] & 0x20) for P in pts if P} == {True, False}  # both roots occur
+    want_dir = tmp_path / "shares_py"
+    want_dir.mkdir()
+    ser.delegator_write(str(want_dir), a, HostPP(2))  # examples/delegator.rs:71-95: `delegator` + 16 worker files
+    names = sorted(os.listdir(want_dir))
+    assert names == sorted(os.listdir(share_dir)) and len(names) == 17
+    for nm in names:
+        assert open(share_dir / nm, "rb").read() == open(want_dir / nm, "rb").read(), nm
     g = lambda name, party=0: _ints(out[(name, party)])
     assert g("add") == [(x + y) % R for x, y in zip(a, b)]
     assert g("sub") == [(x - y) % R for x, y in zip(a, b)]
@@ -243,8 +267,19 @@ def test_cpp_host_equals_python_host_on_the_gpu(tmp_path, l, m, echo):
     from zkhip.net import LeaderEchoNet, LocalTestNet
 
     pp, tabs, chal, point, records = _case(l, m, echo, 5200 + 17 * l + m)
+    # a delegator share directory (examples/delegator.rs) for the file -> device -> file round trip of the C++ host
+    import zkhip.serialize as ser
+
+    share_dir = tmp_path / "shares"
+    share_dir.mkdir()
+    witness = po.SplitMix64(99).fr_vec(64)
+    ser.delegator_write(str(share_dir), witness, pp)
+    records[("dir", 0)] = np.frombuffer(str(share_dir).encode(), dtype=np.uint8)
     r, got = _run("gpu", records, tmp_path)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    shares3 = ser.delegator_share(witness, pp)[3]
+    assert _ints(got.pop(("share_file_on_device", 0))) == shares3  # Montgomery limbs in HBM == the file's values
+    assert open(share_dir / "worker_3.copy", "rb").read() == open(share_dir / "worker_3", "rb").read()
 
     want = {}
     if echo:
