@@ -24,6 +24,7 @@ struct ZkError : std::runtime_error {
 // `G::msm` -> Err(min_len) (dmsm.rs:23)
 struct MsmLengthError : ZkError {
     using ZkError::ZkError;
+    size_t min_len = 0;
 };
 
 class Ctx;
@@ -266,6 +267,20 @@ class Ctx {
     G1 msm_g1(const Srs &srs, const DevPtr &scalars, size_t n, size_t offset = 0) {
         G1 out;
         check(zk_msm_g1(h_, srs.handle(), offset, scalars.get(), n, out.data()));
+        return out;
+    }
+    // drop-in for `G::msm(&[Affine], &[Fr]) -> Result<G, usize>` on host slices (dmsm.rs:23): bases at `stride` bytes (96, or 104 =
+    // the Rust struct); a length mismatch throws MsmLengthError whose min_len is the reference's Err(min_len)
+    G1 msm_g1_host(const void *bases, size_t stride, size_t n_bases, const FrVec &scalars) {
+        G1 out;
+        size_t min_len = 0;
+        int rc = zk_msm_g1_host(h_, bases, stride, n_bases, scalars.empty() ? nullptr : scalars[0].v, scalars.size(), out.data(), &min_len);
+        if (rc == ZK_ERR_LENGTH) {
+            MsmLengthError e(rc, zk_last_error(h_));
+            e.min_len = min_len;
+            throw e;
+        }
+        check(rc);
         return out;
     }
     G1Vec msm_g1_batch(const std::vector<const Srs *> &srs, const std::vector<DevPtr> &scalars, const std::vector<size_t> &lens) {

@@ -310,6 +310,22 @@ static int run_rccl1() {
     G1Vec local = be.msm_g1_batch({pg[10].get(), pg[9].get()}, {df, dg}, {M, M / 2});
     G1Vec want = be.g1_lincomb_batch(local, FrVec{(pp.c(0) * pp.lambda(0)).to_canonical()}, 2);
     if (got != want) return std::fprintf(stderr, "rccl1: d_msm over RcclNet differs from c_0 lambda_0 MSM\n"), 1;
+    // G::msm on host slices (dmsm.rs:23): the generator 5 times with scalars 1..5 -> 15 G; a length mismatch -> Err(min_len)
+    {
+        G1Affine gen = g1_deserialize_compressed((const uint8_t *)"\x97\xf1\xd3\xa7\x31\x97\xd7\x94\x26\x95\x63\x8c\x4f\xa9\xac\x0f\xc3\x68\x8c\x4f\x97\x74\xb9\x05\xa1\x4e\x3a\x3f\x17\x1b\xac\x58\x6c\x55\xe8\x3f\xf9\x7a\x1a\xef\xfb\x3a\xf0\x0a\xdb\x22\xc6\xbb");
+        uint8_t recs[5 * 96];
+        FrVec sc;
+        for (int i = 0; i < 5; ++i) g1_affine_record(gen, recs + 96 * i), sc.push_back(Fr::from_u64(i + 1));
+        G1 s15 = be.msm_g1_host(recs, 96, 5, sc);
+        G1 one = be.msm_g1_host(recs, 96, 1, FrVec{Fr::from_u64(1)});
+        if (be.g1_lincomb_batch(G1Vec{one}, FrVec{Fr::raw_u64(15)}, 1)[0] != s15) return std::fprintf(stderr, "rccl1: msm_g1_host != 15 G\n"), 1;
+        try {
+            be.msm_g1_host(recs, 96, 5, FrVec(3, Fr::one()));
+            return std::fprintf(stderr, "rccl1: a length mismatch must throw\n"), 1;
+        } catch (const MsmLengthError &e) {
+            if (e.min_len != 3) return std::fprintf(stderr, "rccl1: Err(min_len) = %zu, expected 3\n", e.min_len), 1;
+        }
+    }
     // the exchanges: a world of one returns its own data, through HBM
     std::vector<FrVec> ag = net.all_gather_fr(FrVec(f.begin(), f.begin() + 5));
     DevPtr a2a = net.all_to_all_device(be, df, 32 * 7);

@@ -90,6 +90,8 @@ def test_cpp_host_arithmetic_pss_and_leader_rounds_match_the_oracle(tmp_path):
     assert out[("fr_vec_serialize", 0)] == ser.fr_vec_serialize(a)
     assert out[("g1_compressed", 0)] == b"".join(ser.g1_serialize_compressed(P) for P in pts)
     assert out[("g1_uncompressed", 0)] == b"".join(ser.g1_serialize_uncompressed(P) for P in pts)
+    # the published compressed encoding of the BLS12-381 G1 generator (zcash / IETF pairing-friendly-curves draft): an anchor from outside this repo
+    assert out[("g1_compressed", 0)][:48].hex() == "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
     assert out[("g1_vec_compressed", 0)] == ser.g1_vec_serialize_compressed(pts) and len(out[("g1_vec_compressed", 0)]) == 8 + 48 * len(pts)
     assert {bool(ser.g1_serialize_compressed(P)[0] & 0x20) for P in pts if P} == {True, False}  # both roots occur
     want_dir = tmp_path / "shares_py"
