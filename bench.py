@@ -51,7 +51,7 @@ MADS_PER_MADD = 6 * 338 + 2 * 260 + 507  # XYZZ mixed addition on 13x30-bit limb
 FR_MUL_PEAK = 133.0e9  # measured Fr Montgomery mul/s (same file)
 
 
-def cpp_host_e2e(n: int, reps: int = 4):
+def cpp_host_e2e(n: int, reps: int = 4, ctx=None):
     """
     The same proof driven by the COMPILED host (scalable-collaborative-zksnark_amd/host: zkhost/hyperplonk.hpp, the C++ mirror of the
     reference's Rust crates above the C ABI) in its own process: leader mode, SplitMix64 tables, best of `reps`.  Its transcripts are
@@ -63,10 +63,10 @@ def cpp_host_e2e(n: int, reps: int = 4):
     if not os.path.exists(exe):
         return {"error": "host/bin/hyperplonk is not built (__graft_entry__.build())"}
     try:
-        r = subprocess.run([exe, "--l", "1", "--n", str(n), "--reps", str(reps)], capture_output=True, text=True, timeout=900)
+        r = subprocess.run([exe, "--l", "1", "--n", str(n), "--reps", str(reps), "--digest"], capture_output=True, text=True, timeout=900)
         if r.returncode != 0:
             return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
-        runs, comm = [], None
+        runs, comm, digests = [], None, set()
         for line in r.stdout.splitlines():
             w = line.split()
             if line.startswith("rep "):
@@ -75,10 +75,34 @@ def cpp_host_e2e(n: int, reps: int = 4):
                 runs[-1][" ".join(w[1:-2])] = float(w[-2])
             elif line.startswith("Comm:"):
                 comm = line[len("Comm: "):]
+            elif line.startswith("transcript sha256"):
+                digests.add(w[-1])
         best = min(runs, key=lambda t: t.get("Distributed HyperPlonk", 1e9))
-        return {"timers_s": best, "comm_per_proof": comm, "reps": reps,
-                "what": "the same call sequence from the compiled C++ host (zkhost/hyperplonk.hpp) in its own process, leader mode, synthetic SplitMix64 tables; "
-                        "transcripts bit-identical to the Python driver's on the same inputs (tests/test_host_cpp.py)"}
+        out = {"timers_s": best, "comm_per_proof": comm, "reps": reps, "transcript_sha256": sorted(digests),
+               "what": "the same call sequence from the compiled C++ host (zkhost/hyperplonk.hpp) in its own process, leader mode, synthetic SplitMix64 tables; "
+                       "transcripts bit-identical to the Python driver's on the same inputs (tests/test_host_cpp.py)"}
+        if ctx is not None:
+            # self-check of THIS run: the Python driver on the same SplitMix64 parameter set (whose transcripts the anchored check above
+            # pins at this size) must produce the same transcript, byte for byte
+            import hashlib
+
+            import numpy as np
+
+            from zkhip.hyperplonk import PackedProvingParameters, dhyperplonk
+            from zkhip.net import LeaderEchoNet
+            from zkhip.pss import PackedSharingParams
+
+            pp = PackedSharingParams(1)
+            pk = PackedProvingParameters.new_splitmix(n, pp, ctx, seed=100, chal_seed=4242)
+            ((gp, gc), (wp, wc, wo)), _ = dhyperplonk(n, pk, pp, ctx, LeaderEchoNet(8))
+            b = lambda *arrs: b"".join(np.ascontiguousarray(a, dtype=np.uint64).tobytes() for a in arrs)
+            want = hashlib.sha256(b(*gp) + b"".join(b(c, v, prf) for c, (v, prf) in gc) + b(*wp) + b(*wc) + b"".join(b(v, prf) for v, prf in wo)).hexdigest()
+            out["transcript_equals_python_host"] = digests == {want}
+            if digests != {want}:
+                out["timers_s"] = None  # an unverified figure is not a figure
+            del pk
+            ctx.trim()
+        return out
     except Exception as ex:
         return {"error": repr(ex)}
 
@@ -759,7 +783,7 @@ def run_rank(args, grp, gpu: int, ctx, net):
             except Exception as ex:  # the headline must survive a failure of this leg
                 extra["e2e"] = {"error": repr(ex)}
             if world == 1 and isinstance(extra.get("e2e"), dict) and "error" not in extra["e2e"]:
-                extra["e2e"]["cpp_host"] = cpp_host_e2e(args.e2e_n)
+                extra["e2e"]["cpp_host"] = cpp_host_e2e(args.e2e_n, ctx=ctx)
 
         # ---- G2: `d_msm` is generic over CurveGroup (dmsm.rs:9), powers_of_g2 are G2 points (dpoly_comm.rs:27,59-62) ----
         if world == 1:
