@@ -16,6 +16,7 @@
 
 #include "zkhost/hyperplonk.hpp"
 #include "zkhost/serialize.hpp"
+#include "zkhost/sharding.hpp"
 
 using namespace zkhost;
 
@@ -247,6 +248,21 @@ static void run_party(const Records &in, Records &out, size_t p, Net &net, const
     out.put("d_unpack2", p, d_unpack2(share, 1 % P, pp, net));
     out.put("d_unpack2_many", p, d_unpack2_many(be, few, 0, pp, net));
 
+    // strong-scaling shards (zkhost/sharding.hpp): the parties' tables are the cyclic shards of one table of P M elements
+    out.put("sharded_msm", p, sharded_msm(be, *gd[m], f, M, net));
+    out.put("shard_sc", p, sharded_sumcheck(be, f, M, chal, net));
+    out.put("shard_sc_product", p, sharded_sumcheck_product(be, f, g, M, chal, net));
+    if (p == 0 && !net.echo) {  // ... and equal the monolithic calls on that table
+        FrVec ff(P * M), fg(P * M);
+        for (size_t q = 0; q < P; ++q) {
+            FrVec tf = in.fr("f", q), tg = in.fr("g", q);
+            for (size_t i = 0; i < M; ++i) ff[q + P * i] = tf[i], fg[q + P * i] = tg[i];
+        }
+        if (cyclic_shard(ff, 1 % P, P) != in.fr("f", 1 % P)) throw std::runtime_error("cyclic_shard");
+        DevPtr dff = be.to_device(ff), dfg = be.to_device(fg);
+        out.put("mono_sc", 0, sumcheck(be, dff, P * M, chal));
+        out.put("mono_sc_product", 0, sumcheck_product(be, dff, dfg, P * M, chal));
+    }
     if (p == 0 && in.rec.count({"dir", 0})) {  // a share file onto the device and back (Montgomery conversion on the GPU)
         const Bytes &d = in.rec.at({"dir", 0});
         std::string dir(d.begin(), d.end());

@@ -239,6 +239,15 @@ def _python_party(be, net, pp, m, tabs, chal, point, rec):
     put("d_unpack2", dp.d_unpack2(share, 1 % P, pp, net))
     put("d_unpack2_many", dp.d_unpack2_many(few, 0, pp, net, be=be))
 
+    from zkhip import sharding as sh
+
+    put("sharded_msm", sh.sharded_msm(be, gd[m], f, M, net))
+    put("shard_sc", sh.sharded_sumcheck(be, f, M, chal, net))
+    put("shard_sc_product", sh.sharded_sumcheck_product(be, f, g, M, chal, net))
+    if p == 0 and not getattr(net, "echo", False):
+        full = lambda k: be.to_device(np.ascontiguousarray(np.stack(tabs[k], axis=1).reshape(-1, 4)))  # full[q + P i] = tabs[q][i]
+        put("mono_sc", dp.sumcheck(be, full("f"), P * M, chal))
+        put("mono_sc_product", dp.sumcheck_product(be, full("f"), full("g"), P * M, chal))
     for buf, cnt in dp.c_acc_product_and_share(be, f, g, h0, h1, h2, M, pp, net):
         put("c_acc_share_len", np.array([cnt], dtype=np.uint64))
         put("c_acc_product_and_share", buf.download((cnt, 4)))
@@ -299,6 +308,9 @@ def test_cpp_host_equals_python_host_on_the_gpu(tmp_path, l, m, echo):
     assert set(got) == set(want), (sorted(set(got) ^ set(want)))
     bad = [k for k in sorted(want) if got[k] != want[k]]
     assert not bad, bad
+    if not echo:  # the sharded transcripts ARE the monolithic ones (every rank holds them)
+        for p in range(pp.n):
+            assert got[("shard_sc", p)] == got[("mono_sc", 0)] and got[("shard_sc_product", p)] == got[("mono_sc_product", 0)]
     # sanity of what was compared: a d_ result reaches the leader only, c_ results reach everyone
     assert len(want[("d_sumcheck_product", 0)]) == 96 * (m + pp.n.bit_length() - 1)
     if not echo:
