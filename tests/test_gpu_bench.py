@@ -80,3 +80,7 @@ def test_single_gpu_line_has_the_record_fields():
     e2e = line["e2e"]
     assert e2e["transcript_checks"] == "ok" and e2e["transcript_check_kind"].startswith("anchored")
     assert e2e["scalar_muls_computed"] == 97227 - (1 << 13)
+    # the same proof from the compiled C++ host, self-checked in the run: its transcript digest equals the Python driver's
+    cpp = e2e["cpp_host"]
+    assert "error" not in cpp and cpp["transcript_equals_python_host"] is True and len(cpp["transcript_sha256"]) == 1
+    assert 0 < cpp["timers_s"]["Distributed HyperPlonk"] < 1 and cpp["comm_per_proof"] == "(959224, 959224)"
