@@ -92,31 +92,38 @@ def splitmix_fr(n: int, seed: int) -> np.ndarray:
     """
     n uniform field elements from SplitMix64(seed) by rejection (SURVEY.md 8(d) "Synthetic inputs"): candidate k takes outputs
     4k+1 .. 4k+4 of the generator as limbs 0..3 (top bit of limb 3 cleared) and is kept when it is < r.  The generator's state is
-    seed + k * gamma, so every output is computable on its own: vectorised here, sequential in the C++ host
-    (host/zkhost/hyperplonk.hpp SplitMix64) -- the same elements.
+    seed + k * gamma, so every output is computable on its own: vectorised here (cache-sized chunks, in-place arithmetic),
+    sequential in the C++ host (host/zkhost/hyperplonk.hpp SplitMix64) -- the same elements.
     """
     gamma, m1, m2 = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xBF58476D1CE4E5B9), np.uint64(0x94D049BB133111EB)
+    s30, s27, s31, top = np.uint64(30), np.uint64(27), np.uint64(31), np.uint64(0x7FFFFFFFFFFFFFFF)
     out = np.empty((n, 4), dtype=np.uint64)
+    chunk = 1 << 16  # candidates per step: 2 MiB of state
+    z, t = np.empty(4 * chunk, dtype=np.uint64), np.empty(4 * chunk, dtype=np.uint64)
+    ramp = np.arange(1, 4 * chunk + 1, dtype=np.uint64) * gamma  # (k + 1) gamma for the outputs of one chunk
     filled, k0 = 0, 0  # candidates consumed so far
+    r3, r2, r1, r0 = (_R_LIMBS[k] for k in (3, 2, 1, 0))
     with np.errstate(over="ignore"):
         while filled < n:
-            m = max(16, int((n - filled) * 1.12) + 8)
-            idx = np.arange(4 * k0 + 1, 4 * (k0 + m) + 1, dtype=np.uint64)
-            z = np.uint64(seed & _M64) + idx * gamma
-            z = (z ^ (z >> np.uint64(30))) * m1
-            z = (z ^ (z >> np.uint64(27))) * m2
-            cand = (z ^ (z >> np.uint64(31))).reshape(m, 4)
-            cand[:, 3] &= np.uint64(0x7FFFFFFFFFFFFFFF)
-            lt = np.zeros(m, dtype=bool)
-            eq = np.ones(m, dtype=bool)
-            for k in (3, 2, 1, 0):
-                lt |= eq & (cand[:, k] < _R_LIMBS[k])
-                eq &= cand[:, k] == _R_LIMBS[k]
+            np.add(ramp, np.uint64((seed + 4 * k0 * 0x9E3779B97F4A7C15) & _M64), out=z)
+            np.right_shift(z, s30, out=t); np.bitwise_xor(z, t, out=z); np.multiply(z, m1, out=z)
+            np.right_shift(z, s27, out=t); np.bitwise_xor(z, t, out=z); np.multiply(z, m2, out=z)
+            np.right_shift(z, s31, out=t); np.bitwise_xor(z, t, out=z)
+            cand = z.reshape(chunk, 4)
+            cand[:, 3] &= top
+            # < r, lexicographic from the top limb: almost every candidate is decided by limb 3 alone
+            c3 = cand[:, 3]
+            lt = c3 < r3
+            eq = c3 == r3
+            if eq.any():
+                idx = np.nonzero(eq)[0]
+                for i in idx:
+                    lt[i] = (int(cand[i, 2]), int(cand[i, 1]), int(cand[i, 0])) < (int(r2), int(r1), int(r0))
             good = cand[lt]
             take = min(len(good), n - filled)
             out[filled : filled + take] = good[:take]
             filled += take
-            k0 += m
+            k0 += chunk
     return out
 
 
