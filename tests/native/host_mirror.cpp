@@ -108,6 +108,7 @@ static void run_host(const Records &in, Records &out) {
     }
     out.put("add", 0, sum), out.put("sub", 0, dif), out.put("mul", 0, prod), out.put("inv", 0, inv), out.put("canonical", 0, canon);
     out.put("root_of_unity", 0, fr_two_adic_root());
+    out.put("splitmix_fr", 0, SplitMix64(0x5CA1AB1Eull + 100001).fr_vec(300));  // the synthetic-table generator
     size_t nl = in.rec.at({"ls", 0}).size() / 8;
     for (size_t i = 0; i < nl; ++i) {
         size_t l = in.u64("ls", i);

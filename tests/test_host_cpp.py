@@ -109,6 +109,13 @@ def test_cpp_host_arithmetic_pss_and_leader_rounds_match_the_oracle(tmp_path):
     # to_canonical: the limbs ARE the integer
     assert [int.from_bytes(out[("canonical", 0)][32 * i : 32 * i + 32], "little") for i in range(64)] == a
     assert g("root_of_unity") == [0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B]  # SURVEY.md 8 "PSS exact semantics"
+    # the synthetic-table generator of both hosts is the oracle's SplitMix64 (sequential in C++, vectorised in numpy: chunk boundary at 2^16 candidates)
+    from zkhip.field import limbs_to_int, splitmix_fr
+
+    raw = out[("splitmix_fr", 0)]  # (the generator's integers ARE the limb patterns: the Montgomery form of a uniform element)
+    assert [int.from_bytes(raw[32 * i : 32 * i + 32], "little") for i in range(300)] == po.SplitMix64(0x5CA1AB1E + 100001).fr_vec(300)
+    seq = po.SplitMix64(31337).fr_vec(73000)
+    assert [limbs_to_int(x) for x in splitmix_fr(73000, 31337)] == seq
     for l in ls:
         pp = po.PackedSharingParams(l)
         n = pp.n
