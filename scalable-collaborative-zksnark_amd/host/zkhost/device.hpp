@@ -335,8 +335,9 @@ class Ctx {
         G1Vec out(j.count);
         zk_msm_job *job = j.job;
         j.job = nullptr;  // (zk_msm_wait releases the job also on error)
-        j.keep.clear();
-        if (job) check(zk_msm_wait(h_, job, out[0].data()));
+        int rc = job ? zk_msm_wait(h_, job, out[0].data()) : 0;
+        j.keep.clear();  // only now: the pass read the scalar buffers until the wait returned
+        check(rc);
         return out;
     }
     // the whole of d_msm in one call over the ctx's communicator (zk_d_msm)

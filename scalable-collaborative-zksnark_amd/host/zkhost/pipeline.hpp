@@ -6,6 +6,8 @@
 // The `*_q` functions below run their kernels now, queue their MSMs and return a closure that produces the reference's
 // return value once the queue has run; every party calls them, the queue and the closures in the same order.  Every output
 // is bit-identical to the one-call-at-a-time forms of dist_primitive.hpp (same field / group elements).
+// Lifetimes: the closures refer to the backend, the queue, the net and the sharing parameters they were made with -- call them
+// while those are alive (a protocol step makes, runs and finishes its queue inside one function, hyperplonk.hpp).
 #pragma once
 #include <functional>
 #include <map>
