@@ -249,6 +249,14 @@ static void run_party(const Records &in, Records &out, size_t p, Net &net, const
     out.put("d_unpack2", p, d_unpack2(share, 1 % P, pp, net));
     out.put("d_unpack2_many", p, d_unpack2_many(be, few, 0, pp, net));
 
+    // the structured parameter set (PolynomialCommitmentCub::new, dpoly_comm.rs:37-67) and this party's packed share of it (:164-194)
+    {
+        PolynomialCommitmentCub cub = PolynomialCommitmentCub::make(be, FrVec(chal.begin(), chal.begin() + m + logl));
+        PolynomialCommitmentCub packed = cub.to_packed(be, pp, p);
+        out.put("structured_commit", p, commit(be, cub.mature(), f, M));
+        out.put("structured_c_commit", p, c_commit(be, packed.mature(), {f}, {M}, pp, net));
+        out.put("structured_c_open", p, c_open(be, packed.mature(), f, M, point, pp, net));
+    }
     // strong-scaling shards (zkhost/sharding.hpp): the parties' tables are the cyclic shards of one table of P M elements
     out.put("sharded_msm", p, sharded_msm(be, *gd[m], f, M, net));
     out.put("shard_sc", p, sharded_sumcheck(be, f, M, chal, net));

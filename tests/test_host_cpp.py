@@ -246,6 +246,11 @@ def _python_party(be, net, pp, m, tabs, chal, point, rec):
     put("d_unpack2", dp.d_unpack2(share, 1 % P, pp, net))
     put("d_unpack2_many", dp.d_unpack2_many(few, 0, pp, net, be=be))
 
+    cub = dp.PolynomialCommitmentCub.new(be, chal[: m + logl])
+    packed = cub.to_packed(be, pp, p).mature()
+    put("structured_commit", dp.commit(be, cub.mature(), f, M))
+    put("structured_c_commit", dp.c_commit(be, packed, [f], [M], pp, net))
+    put("structured_c_open", *dp.c_open(be, packed, f, M, point, pp, net))
     from zkhip import sharding as sh
 
     put("sharded_msm", sh.sharded_msm(be, gd[m], f, M, net))
