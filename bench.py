@@ -781,6 +781,13 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 extra["e2e"] = {"error": repr(ex)}
             if world == 1 and isinstance(extra.get("e2e"), dict) and "error" not in extra["e2e"]:
                 extra["e2e"]["cpp_host"] = cpp_host_e2e(args.e2e_n, want_digest=extra["e2e"].get("transcript_sha256") if extra["e2e"].get("transcript_checks") == "ok" else None)
+                # one figure per proof: the faster of the two verified hosts (same inputs, same transcript)
+                cand = {"python": (extra["e2e"].get("timers_s") or {}).get("Distributed HyperPlonk"),
+                        "cpp": (extra["e2e"]["cpp_host"].get("timers_s") or {}).get("Distributed HyperPlonk") if extra["e2e"]["cpp_host"].get("transcript_equals_python_host") else None}
+                cand = {k: v for k, v in cand.items() if v}
+                if cand:
+                    best_host = min(cand, key=cand.get)
+                    extra["e2e"]["proof_s"] = {"host": best_host, "seconds": cand[best_host], "all": cand}
 
         # ---- G2: `d_msm` is generic over CurveGroup (dmsm.rs:9), powers_of_g2 are G2 points (dpoly_comm.rs:27,59-62) ----
         if world == 1:

@@ -83,4 +83,5 @@ def test_single_gpu_line_has_the_record_fields():
     # the same proof from the compiled C++ host, self-checked in the run: its transcript digest equals the Python driver's
     cpp = e2e["cpp_host"]
     assert "error" not in cpp and cpp["transcript_equals_python_host"] is True and len(cpp["transcript_sha256"]) == 1
+    assert e2e["proof_s"]["host"] in ("python", "cpp") and e2e["proof_s"]["seconds"] == min(e2e["proof_s"]["all"].values())
     assert 0 < cpp["timers_s"]["Distributed HyperPlonk"] < 1 and cpp["comm_per_proof"] == "(959224, 959224)"
