@@ -284,7 +284,7 @@ def _case(l, m, echo, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("l,m,echo", [(1, 10, False), (2, 9, False), (1, 11, True), (4, 8, True)])
+@pytest.mark.parametrize("l,m,echo", [(1, 10, False), (2, 9, False), (1, 11, True), (4, 8, True), (8, 9, True)])  # l = 8: 64 parties, the transform (zk_fr_ntt_map) branches
 def test_cpp_host_equals_python_host_on_the_gpu(tmp_path, l, m, echo):
     import zkhip
     from zkhip.net import LeaderEchoNet, LocalTestNet
