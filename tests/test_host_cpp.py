@@ -346,7 +346,8 @@ def _flat_transcript(res):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("which,l,n,echo", [("dhyperplonk", 1, 8, False), ("dhyperplonk", 1, 12, True), ("data_parallel", 1, 7, False), ("dhyperplonk", 2, 7, False),
-                                            ("dpermcheck", 1, 8, False), ("cpermcheck", 1, 7, False), ("cpermcheck", 2, 7, True)])
+                                            ("dpermcheck", 1, 8, False), ("cpermcheck", 1, 7, False), ("cpermcheck", 2, 7, True), ("cpermcheck", 8, 11, True),
+                                            ("dhyperplonk", 8, 11, True)])  # l = 8: 64 parties (transform branches), leader echo
 def test_cpp_protocol_drivers_equal_the_python_drivers(tmp_path, which, l, n, echo):
     import zkhip
     from zkhip.field import random_fr
