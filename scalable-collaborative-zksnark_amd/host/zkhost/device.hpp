@@ -352,6 +352,23 @@ class Ctx {
         check(zk_d_msm(h_, count, h.data(), nullptr, sp.data(), lens.data(), lambda_mont ? lambda_mont->v : nullptr, coeffs_canonical[0].v, out[0].data()));
         return out;
     }
+    // the level's points in the reference layout (96 B each: x || y Montgomery limbs, zeros = infinity), on the host
+    std::vector<uint8_t> srs_download(const Srs &s) {
+        std::vector<uint8_t> out(96 * s.len());
+        if (!out.empty()) check(zk_srs_download(h_, s.handle(), out.data()));
+        return out;
+    }
+    // zk_fr_apply_matrix on affine G1 points in HBM (96-B records): the PSS maps are generic over DomainCoeff (pss.rs:93-171).
+    // m: CANONICAL scalars; out[j osv + r osr] = sum_c m[r][c] in[j isv + c isc]
+    DevPtr g1_apply_matrix(const std::vector<FrVec> &m_canonical, const DevPtr &in96, size_t isv, size_t isc, size_t k, size_t osv, size_t osr) {
+        size_t rows = m_canonical.size(), cols = rows ? m_canonical[0].size() : 0;
+        FrVec flat;
+        for (auto &r : m_canonical) flat.insert(flat.end(), r.begin(), r.end());
+        size_t span = (k && rows) ? (k - 1) * osv + (rows - 1) * osr + 1 : 1;
+        DevPtr out = alloc(96 * span);
+        check(zk_g1_apply_matrix(h_, flat.empty() ? nullptr : flat[0].v, rows, cols, in96.get(), isv, isc, out.get(), osv, osr, k));
+        return out;
+    }
     // out[r] = sum_i k_i P[r n + i]; k canonical (zk_g1_lincomb_batch: the leader's public maps on points)
     G1Vec g1_lincomb_batch(const G1Vec &points, const FrVec &scalars_canonical, size_t count) {
         size_t n = scalars_canonical.size();

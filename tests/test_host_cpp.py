@@ -486,3 +486,24 @@ def test_cpp_host_full_size_proof_has_the_python_hosts_digest(which, n):
     t = _flat_transcript(res)
     want = hashlib.sha256(b"".join(t[k] for k in ("gate_proofs", "gate_commitments", "wiring_proofs", "wiring_commits", "wiring_opens"))).hexdigest()
     assert digests[0] == want
+
+
+# ---------------------------------------------------------------------------------------
+# the reference's own unit tests restated for the C++ host (tests/native/host_props.cpp): oracle-free properties
+# ---------------------------------------------------------------------------------------
+def _props():
+    subprocess.check_call(["make", "-C", NATIVE, "-s", "host_props"])
+    return os.path.join(NATIVE, "host_props")
+
+
+def test_cpp_reference_unit_tests_host_part():
+    """pss.rs tests, utils/operator.rs:42-49, dacc_product.rs:442-448, dsumcheck.rs:591-621 -- no GPU needed"""
+    r = subprocess.run([_props(), "host"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "0 failure(s)" in r.stdout and r.stdout.count(" ok\n") == 6, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_reference_unit_tests_gpu_part():
+    """dacc_product.rs:450-466, pss.rs test_group_addition, dmsm.rs:73-138, dsumcheck.rs:541-588,623-859, dpoly_comm.rs:502-581 (no pairing)"""
+    r = subprocess.run([_props(), "gpu"], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "0 failure(s)" in r.stdout and r.stdout.count(" ok\n") == 8, r.stdout[-3000:] + r.stderr[-3000:]
