@@ -42,6 +42,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional (absent from very old builds): falls back to CommDestroy
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -79,6 +80,7 @@ static Rccl* rccl() {
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))dlsym(r.handle, "ncclCommAbort");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
@@ -106,6 +108,38 @@ static int need_comm(zk_ctx* ctx, Rccl** r) {
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice");
     return ZK_OK;
+}
+
+// zk_d_msm's staging -- device scratch slot 7 and the pinned block h_comm -- for batches of up to D_MSM_PREALLOC_ITEMS results is
+// taken when the communicator is created, so the call itself cannot run out of memory before it has joined the exchange (a
+// party that returns early leaves its peers waiting in the collective).  Larger batches grow the blocks at call time.
+constexpr size_t D_MSM_PREALLOC_ITEMS = 256;
+static size_t d_msm_stage_bytes(size_t count, int world) { return (count * 144 + 16) * (size_t)(world + 1); }
+static int d_msm_reserve(zk_ctx* ctx, size_t stage) {
+    if (!scratch(ctx, 7, stage)) return ZK_ERR_OOM;
+    if (ctx->h_comm_cap < stage) {
+        if (ctx->h_comm) hipHostFree(ctx->h_comm);
+        ctx->h_comm = nullptr, ctx->h_comm_cap = 0;
+        const size_t cap = std::max<size_t>(stage, 4096);
+        if (hipHostMalloc(&ctx->h_comm, cap, hipHostMallocDefault) != hipSuccess) {
+            ctx->h_comm = nullptr;
+            return ZK_ERR_OOM;
+        }
+        ctx->h_comm_cap = cap;
+    }
+    return ZK_OK;
+}
+// An error while ENQUEUEING an exchange (the HIP stream or the communicator is unusable): this party cannot take part any
+// more.  Abort its communicator so that its resources are released and the peers' RCCL sees a dead rank (their collectives
+// end with an error where the transport detects it, and with the job where it does not -- the reference's `unwrap()` panic
+// does the same); the ctx is left without a communicator, every later exchange returns ZK_ERR_COMM at once.
+static void comm_abort(zk_ctx* ctx, Rccl* r) {
+    if (!ctx->comm) return;
+    if (r->CommAbort) r->CommAbort((ncclComm_t)ctx->comm);
+    else r->CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
 }
 
 }  // namespace zk
@@ -139,6 +173,10 @@ int zk_comm_init(zk_ctx* ctx, int rank, int world, const uint8_t h_id[ZK_COMM_ID
     ctx->comm = c;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
+    if (d_msm_reserve(ctx, d_msm_stage_bytes(D_MSM_PREALLOC_ITEMS, world))) {
+        comm_abort(ctx, r);
+        return fail(ctx, ZK_ERR_OOM, "zk_comm_init: no staging memory for zk_d_msm");
+    }
     return ZK_OK;
 }
 
@@ -157,7 +195,14 @@ int zk_comm_init_all(zk_ctx* const* ctxs, int world) {
         ctxs[i]->comm_rank = i;
         ctxs[i]->comm_world = world;
     }
-    return ZK_OK;
+    int rc = ZK_OK;
+    for (int i = 0; i < world && !rc; i++) {
+        hipSetDevice(ctxs[i]->device);
+        if (d_msm_reserve(ctxs[i], d_msm_stage_bytes(D_MSM_PREALLOC_ITEMS, world))) rc = fail(ctxs[i], ZK_ERR_OOM, "zk_comm_init_all: no staging memory for zk_d_msm");
+    }
+    if (rc)
+        for (int i = 0; i < world; i++) comm_abort(ctxs[i], r);
+    return rc;
 }
 
 int zk_comm_destroy(zk_ctx* ctx) {
@@ -252,12 +297,13 @@ int zk_scatter(zk_ctx* ctx, const void* d_send, size_t bytes, int root, void* d_
 // A party whose LOCAL part fails (length mismatch, out of memory, a HIP error) still joins the exchange: every
 // payload carries a status word, so all parties return an error instead of the healthy ones blocking forever in
 // the collective (the reference's `unwrap()` panic takes the whole job down; a silent distributed hang would not).
-// The staging memory of the exchange (device slot 7 + a pinned block of the ctx's own) is taken BEFORE the local MSMs, so
-// a party that then runs out of memory can still publish its status.  Paths on which a party does NOT join, i.e. the
-// peers keep waiting until its communicator is torn down (zk_comm_destroy / process exit): (1) no communicator, or an
-// empty batch, on this party only; (2) the staging allocation itself fails (count x 144 x (world + 1) bytes: a few
-// KiB); (3) an error of the HIP runtime or of RCCL while enqueueing the exchange itself (the stream or the
-// communicator is unusable then).  All three return an error on this party.
+// The staging memory of the exchange (device slot 7 + a pinned block of the ctx's own) exists since zk_comm_init for batches
+// of up to 256 results (larger ones grow it BEFORE the local MSMs), so a party that runs out of memory in its MSMs can still
+// publish its status.  Paths on which a party does NOT join: (1) no communicator, or an empty batch, on this party only (a
+// caller error: nobody else is told); (2) a batch beyond 256 results whose staging cannot be grown; (3) an error of the HIP
+// runtime or of RCCL while enqueueing the exchange itself.  In (2) and (3) the party returns an error AND aborts its
+// communicator (ncclCommAbort), the library's form of the reference's `unwrap()` panic: its peers are not left with a
+// half-alive rank, and every later exchange on this ctx fails at once with ZK_ERR_COMM.
 // The MSM results reach the all-gather through pinned host memory: the last step of an MSM (the ~40-step bit-plane /
 // window chain and the normalisation) runs on the host by design, so the 144-byte points exist on the
 // host first; the payload is count x 144 + 16 bytes.
@@ -271,15 +317,12 @@ int zk_d_msm(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* 
     const size_t bytes = count * 144 + 16;  // results + status word (own 16-byte slot keeps the points aligned)
     // ---- staging of the exchange first: whatever happens below, the status can travel ----
     const size_t stage = bytes * (size_t)(w + 1);
-    char* d = (char*)scratch(ctx, 7, stage);
-    if (d && ctx->h_comm_cap < stage) {
-        if (ctx->h_comm) hipHostFree(ctx->h_comm);
-        ctx->h_comm = nullptr, ctx->h_comm_cap = 0;
-        if (hipHostMalloc(&ctx->h_comm, std::max<size_t>(stage, 4096), hipHostMallocDefault) == hipSuccess) ctx->h_comm_cap = std::max<size_t>(stage, 4096);
-        else ctx->h_comm = nullptr;
+    if (d_msm_reserve(ctx, stage)) {  // (only batches beyond D_MSM_PREALLOC_ITEMS can get here without memory)
+        comm_abort(ctx, r);
+        return fail(ctx, ZK_ERR_OOM, "zk_d_msm: no staging memory for the exchange (%zu bytes): this party cannot join it; its communicator was aborted", stage);
     }
-    char* hp = d ? (char*)ctx->h_comm : nullptr;
-    if (!d || !hp) return fail(ctx, ZK_ERR_OOM, "zk_d_msm: no staging memory for the exchange (%zu bytes): this party cannot join it", stage);
+    char* d = (char*)scratch(ctx, 7, stage);
+    char* hp = (char*)ctx->h_comm;
     // ---- local part; any failure is carried into the exchange as `local_rc` ----
     int local_rc = ZK_OK;
     std::vector<uint64_t> local(count * 18 + 2, 0);
@@ -318,10 +361,17 @@ int zk_d_msm(zk_ctx* ctx, size_t count, const zk_srs* const* srs, const size_t* 
     local[count * 18] = (uint64_t)(int64_t)local_rc;
     // ---- exchange (every party, healthy or not) ----
     std::memcpy(hp, local.data(), bytes);
-    ZK_HIP(ctx, hipMemcpyAsync(d, hp, bytes, hipMemcpyHostToDevice, ctx->stream));
-    ZK_NCCL(ctx, r, r->AllGather(d, d + bytes, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream));
-    ZK_HIP(ctx, hipMemcpyAsync(hp + bytes, d + bytes, bytes * w, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        hipError_t e = hipMemcpyAsync(d, hp, bytes, hipMemcpyHostToDevice, ctx->stream);
+        ncclResult_t g = e == hipSuccess ? r->AllGather(d, d + bytes, bytes, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream) : ncclSuccess;
+        if (e == hipSuccess && g == ncclSuccess) e = hipMemcpyAsync(hp + bytes, d + bytes, bytes * w, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && g == ncclSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess || g != ncclSuccess) {  // this party is out of the exchange: do not leave a half-dead rank behind
+            const std::string why = g != ncclSuccess ? std::string("ncclAllGather: ") + r->GetErrorString(g) : std::string(hipGetErrorString(e));
+            comm_abort(ctx, r);
+            return fail(ctx, ZK_ERR_COMM, "zk_d_msm: the exchange failed on this party (%s); its communicator was aborted", why.c_str());
+        }
+    }
     const char* all = hp + bytes;
     if (local_rc) return fail(ctx, local_rc, "%s", local_err.c_str());
     for (int p = 0; p < w; p++) {

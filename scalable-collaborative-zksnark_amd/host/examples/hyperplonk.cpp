@@ -2,12 +2,21 @@
 // bench_dpermcheck,bench_cpermcheck}.rs: build the synthetic parameter set (PackedProvingParameters::new, dhyperplonk.rs:65-156),
 // run the collaborative proof on the GPU(s), print the reference's timer labels and its `Comm: (up, down)` line (:564).
 //
-//   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--digest]
+//   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2]
+//              [--digest] [--check] [--tamper]
 //     leader   party 0 on the no-`comm` echo net (the reference's `-F leader` build: one party's full work; default)
 //     threads  all 8 l parties as threads of this process, one ctx each, exchanges through host memory (LocalTestNet); the
 //              parties share the visible GPUs round-robin
 //     rccl     all 8 l parties as threads, party p on GPU p, exchanges over RCCL / xGMI inside the ctx (zk_comm_init_all);
 //              needs 8 l GPUs
+//     --check  SELF-CHECKING run, no Python and no oracle in the loop (zkhost/verify.hpp): one more run with the operands of every
+//              product sumcheck traced; every transcript chain (dsumcheck.rs:558-588) is pinned at both ends by values from
+//              kernels the product sumcheck does not use (every party's values for the leader's d_ chains), the c_ tails are
+//              recomputed from pss2ss of independently folded values, sampled commits / opens must equal the one-call-at-a-time
+//              forms, the repetitions and the traced run must agree bit for bit, and a copy of the transcript with one limb
+//              flipped must be rejected under exactly its label.  Prints one `check: ...` line per party; exit code 3 when any
+//              party fails.  --tamper flips that limb in the transcript under test instead (the run must then FAIL: exit 3).
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,15 +24,17 @@
 #include <string>
 
 #include "sha256.hpp"
-#include "zkhost/hyperplonk.hpp"
+#include "zkhost/verify.hpp"
 
 using namespace zkhost;
 
 struct Args {
     size_t l = 1, n = 12, reps = 3, table_max = 24;
     std::string mode = "leader", which = "dhyperplonk";
-    bool tables = true, digest = false;
+    bool tables = true, digest = false, check = false, tamper = false;
 };
+
+static std::atomic<int> g_failed{0};  // parties whose self-check failed
 
 static Transcript run_once(const Args &a, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers &tm) {
     if (a.which == "cpermcheck") return cpermcheck(a.n, pk, pp, be, net, &tm);
@@ -41,6 +52,57 @@ static std::string transcript_digest(const Transcript &t) {
     h.update(t.wiring_commits.data(), 144 * t.wiring_commits.size());
     for (auto &o : t.wiring_opens) h.update(o.value.v, 32), h.update(o.proofs.data(), 144 * o.proofs.size());
     return h.hex();
+}
+
+// flip one limb of one t2 in the middle of a transcript every party holds (gate[3], or the first wiring transcript of the
+// drivers without a gate step) -> its label
+static std::string flip_one_limb(Transcript &t) {
+    bool gate = t.gate_proofs.size() > 3;
+    std::vector<Triple> &pr = gate ? t.gate_proofs[3] : t.wiring_proofs.at(0);
+    pr.at(pr.size() / 2)[2].v[0] ^= 1;
+    return gate ? "gate[3]" : "wiring[0]";
+}
+
+// --check (see the header comment); collective: every party runs it in lock step
+static void self_check(const Args &a, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, const std::vector<std::string> &digests) {
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<ScTrace> trace;
+    Timers tm;
+    be.sc_trace = &trace;
+    Transcript t = run_once(a, pk, pp, be, net, tm);
+    be.sc_trace = nullptr;
+    CheckReport rep;
+    for (auto &d : digests)
+        if (d != digests[0]) rep.bad.push_back("repetitions disagree");
+    if (!digests.empty() && transcript_digest(t) != digests.back()) rep.bad.push_back("the traced (anchored) run differs from the timed ones");
+    ProductAnchors anchors = gather_product_anchors(be, trace, pp, net);
+    trace.clear();
+    if (a.tamper) flip_one_limb(t);
+    check_product_transcripts(anchors, t, rep);
+    bool full = a.which == "dhyperplonk" || a.which == "data-parallel";
+    if (full) {
+        check_dhyperplonk_shape(a.n, t, net, rep);
+        check_dhyperplonk_recompute(a.n, pk, pp, be, net, t, rep);
+    }
+    // the check has teeth: one limb off in one t2 is rejected, under its own label and no other
+    std::string teeth = "skipped (--tamper)";
+    if (!a.tamper) {
+        Transcript broken = t;
+        std::string label = flip_one_limb(broken);
+        CheckReport r2;
+        check_product_transcripts(anchors, broken, r2);
+        bool rejected = r2.bad.size() == 1 && r2.bad[0] == label;
+        teeth = rejected ? "rejected as " + label : "NOT rejected";
+        if (!rejected) rep.bad.push_back("a transcript with one limb flipped was not rejected as " + label);
+    }
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::string msg = rep.ok() ? "ok" : "FAILED";
+    for (auto &b : rep.bad) msg += " [" + b + "]";
+    static std::mutex out;
+    std::lock_guard<std::mutex> lk(out);
+    std::printf("check: party %zu of %zu %s -- anchored, %zu transcripts pinned at both ends, %zu c_ tails, %zu recomputed commits / opens, flipped limb %s (%.3f s)\n",
+                (size_t)net.party_id, (size_t)net.n_parties, msg.c_str(), rep.transcripts, rep.closing_rows, rep.recomputed, teeth.c_str(), secs);
+    if (!rep.ok()) ++g_failed;
 }
 
 static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &net) {
@@ -71,10 +133,12 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
     }
     be.sync();
     double setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<std::string> digests;
     for (size_t r = 0; r < a.reps; ++r) {
         Timers tm;
         uint64_t up0 = net.upload, down0 = net.download;
         Transcript t = run_once(a, pk, pp, be, net, tm);
+        if (a.check) digests.push_back(transcript_digest(t));
         if (net.is_leader()) {
             std::printf("rep %zu (setup %.3f s): proofs %zu + %zu, commitments %zu + %zu, openings %zu\n", r, setup, t.gate_proofs.size(), t.wiring_proofs.size(),
                         t.gate_commitments.size(), t.wiring_commits.size(), t.wiring_opens.size());
@@ -83,6 +147,7 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
             if (a.digest) std::printf("transcript sha256 %s\n", transcript_digest(t).c_str());
         }
     }
+    if (a.check) self_check(a, pk, pp, be, net, digests);
 }
 
 int main(int argc, char **argv) {
@@ -103,9 +168,11 @@ int main(int argc, char **argv) {
         else if (k == "--which") a.which = val();
         else if (k == "--no-tables") a.tables = false;
         else if (k == "--digest") a.digest = true;
+        else if (k == "--check") a.check = true;
+        else if (k == "--tamper") a.check = a.tamper = true;
         else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
         else {
-            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--digest]\n");
+            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--digest] [--check] [--tamper]\n");
             return 64;
         }
     }
@@ -143,6 +210,10 @@ int main(int argc, char **argv) {
     } catch (const std::exception &e) {
         std::fprintf(stderr, "hyperplonk: %s\n", e.what());
         return 1;
+    }
+    if (g_failed.load()) {
+        std::fprintf(stderr, "hyperplonk: the self-check failed on %d part%s\n", g_failed.load(), g_failed.load() == 1 ? "y" : "ies");
+        return 3;
     }
     return 0;
 }

@@ -95,8 +95,20 @@ struct ScResult {
     DevPtr out;       // Fold: folded table; Open: the len - 1 quotient elements
 };
 
+// test / self-check hook: the operands of one product sumcheck (zkhost/verify.hpp anchors every transcript of a run on them)
+struct ScTrace {
+    char kind;  // 'p' sumcheck_product, 'c' c_sumcheck_product, 'd' d_sumcheck_product
+    DevPtr f, g;
+    size_t len;
+    FrVec challenge;
+};
+
 class Ctx {
   public:
+    // when set, dist_primitive.hpp / pipeline.hpp append the operands of every product sumcheck they run (the DevPtrs keep the
+    // tables alive); never read by the compute path
+    std::vector<ScTrace> *sc_trace = nullptr;
+
     explicit Ctx(int device = 0) {
         int rc = zk_ctx_create(device, &h_);
         if (rc) throw ZkError(rc, "zk_ctx_create failed (no gfx950 device / library without device code?)");

@@ -148,6 +148,10 @@ inline std::vector<Pair> pairs_of(const FrVec &s) {
     for (size_t i = 0; i < out.size(); ++i) out[i] = {s[2 * i], s[2 * i + 1]};
     return out;
 }
+// the self-check hook (device.hpp ScTrace): record the operands of a product sumcheck
+inline void trace(Ctx &be, char kind, const DevPtr &f, const DevPtr &g, size_t len, const FrVec &challenge, size_t count) {
+    if (be.sc_trace) be.sc_trace->push_back({kind, f, g, len, FrVec(challenge.begin(), challenge.begin() + std::min(count, challenge.size()))});
+}
 inline std::vector<Triple> triples_of(const FrVec &s) {
     std::vector<Triple> out(s.size() / 3);
     for (size_t i = 0; i < out.size(); ++i) out[i] = {s[3 * i], s[3 * i + 1], s[3 * i + 2]};
@@ -165,6 +169,7 @@ inline std::vector<Pair> sumcheck(Ctx &be, const DevPtr &evaluation, size_t len,
 
 // dsumcheck.rs:28-90 -> n + 1 triples, the last one (0, f g, 0)
 inline std::vector<Triple> sumcheck_product(Ctx &be, const DevPtr &f, const DevPtr &g, size_t len, const FrVec &challenge) {
+    detail::trace(be, 'p', f, g, len, challenge, Ctx::log2_exact(len));
     ScResult r = be.sumcheck_product(f, g, len, challenge);
     std::vector<Triple> out = detail::triples_of(r.sums);
     out.push_back({Fr::zero(), r.last_f * r.last_g, Fr::zero()});
@@ -184,6 +189,7 @@ inline std::vector<Pair> c_sumcheck(Ctx &be, const DevPtr &shares, size_t len, c
 // dsumcheck.rs:148-285 -> n + log2(l) + 1 triples
 inline std::vector<Triple> c_sumcheck_product(Ctx &be, const DevPtr &shares_f, const DevPtr &shares_g, size_t len, const FrVec &challenge,
                                               const PackedSharingParams &pp, Net &net) {
+    detail::trace(be, 'c', shares_f, shares_g, len, challenge, Ctx::log2_exact(len));
     ScResult r = be.sumcheck_product(shares_f, shares_g, len, challenge);
     std::vector<Triple> out = detail::triples_of(r.sums);
     FrVec vf = pss2ss(r.last_f, pp, net);  // :224
@@ -215,6 +221,7 @@ inline std::vector<Pair> d_sumcheck(Ctx &be, const DevPtr &partial_poly, size_t 
 // dsumcheck.rs:359-512.  Leader: n' + s triples; workers: empty.  The marker tuple a party sends is (g, f, 0) (:433)
 inline std::vector<Triple> d_sumcheck_product(Ctx &be, const DevPtr &partial_f, const DevPtr &partial_g, size_t len, const FrVec &challenge, Net &net) {
     size_t n = Ctx::log2_exact(len), s = log2_floor(net.n_parties);
+    detail::trace(be, 'd', partial_f, partial_g, len, challenge, n + s);
     ScResult r = be.sumcheck_product(partial_f, partial_g, len, challenge);
     FrVec local = r.sums;
     local.push_back(r.last_g);

@@ -6,8 +6,10 @@
 // The `*_q` functions below run their kernels now, queue their MSMs and return a closure that produces the reference's
 // return value once the queue has run; every party calls them, the queue and the closures in the same order.  Every output
 // is bit-identical to the one-call-at-a-time forms of dist_primitive.hpp (same field / group elements).
-// Lifetimes: the closures refer to the backend, the queue, the net and the sharing parameters they were made with -- call them
-// while those are alive (a protocol step makes, runs and finishes its queue inside one function, hyperplonk.hpp).
+// Lifetimes: a closure OWNS what it reads of the queue -- a shared handle on the pass its items were added to (MsmPass), so it
+// stays valid after the MsmQueue object is gone or has been re-armed by a later pass, and it throws (instead of reading someone
+// else's points) when called before that pass was collected.  Sharing-parameter values are captured by value.  The backend
+// and the net are the party's long-lived objects (one Ctx and one Net per party for the whole run) and are referred to.
 #pragma once
 #include <functional>
 #include <map>
@@ -17,12 +19,24 @@
 
 namespace zkhost {
 
+// the results of ONE pass of a queue, shared between the queue and the closures whose items ran in it
+struct MsmPass {
+    G1Vec res;  // in insertion order
+    bool collected = false;
+    const G1 &at(size_t i) const {
+        if (!collected) throw ZkError(ZK_ERR_INVALID, "MsmQueue: a result was read before its pass was run / finished");
+        return res.at(i);
+    }
+};
+using MsmPassRef = std::shared_ptr<MsmPass>;
+
 class MsmQueue {
   public:
-    G1Vec res;                  // results of the last pass, in insertion order
     std::vector<DevPtr> keep;  // buffers that must outlive the pass
 
-    explicit MsmQueue(Ctx &be, bool dedup = true) : be_(be), dedup_(dedup) {}
+    explicit MsmQueue(Ctx &be, bool dedup = true) : be_(be), dedup_(dedup), pass_(std::make_shared<MsmPass>()) {}
+    // the pass the items added NOW will run in: what a closure keeps (by value) to read its results later
+    MsmPassRef ticket() const { return pass_; }
 
     // -> indices of the items' results in `res`.  Identical items -- same level, same scalar buffer, same length -- are
     // computed ONCE (the two opens of V in step 2.d, dhyperplonk.rs:307-320, commit the same first quotient q_0 = V_hi - V_lo:
@@ -57,29 +71,29 @@ class MsmQueue {
     }
     bool empty() const { return lens_.empty(); }
     void run() {
-        res = lens_.empty() ? G1Vec{} : be_.msm_g1_batch(detail::raw(srs_), bufs_, lens_);
-        close();
+        close(lens_.empty() ? G1Vec{} : be_.msm_g1_batch(detail::raw(srs_), bufs_, lens_));
     }
     // the same in two halves: start() enqueues the pass and returns, finish() collects the points.  Between the two the
     // caller enqueues the NEXT step's kernels and does its own host work (the exchange closures of a step are host
     // arithmetic on a few hundred points, during which the GPU would otherwise idle).
     void start() {
         if (lens_.empty()) {
-            res.clear();
-            close();
+            close(G1Vec{});
         } else {
             job_ = be_.msm_g1_batch_async(detail::raw(srs_), bufs_, lens_);
         }
     }
     void finish() {
-        if (job_.pending()) {
-            res = be_.msm_wait(job_);
-            close();
-        }
+        if (job_.pending()) close(be_.msm_wait(job_));
     }
 
   private:
-    void close() {  // the pass is over: drop the owners and, with them, the keys that named their addresses
+    // the pass is over: publish its points to the closures that hold its ticket, drop the owners and, with them, the keys
+    // that named their addresses, and arm a fresh pass for whatever is added next
+    void close(G1Vec &&points) {
+        pass_->res = std::move(points);
+        pass_->collected = true;
+        pass_ = std::make_shared<MsmPass>();
         keep.clear(), index_.clear(), scaled_.clear(), srs_.clear(), bufs_.clear(), lens_.clear();
     }
     Ctx &be_;
@@ -90,12 +104,13 @@ class MsmQueue {
     std::map<std::tuple<const void *, const void *, size_t>, size_t> index_;
     std::map<std::tuple<const void *, size_t, uint64_t, uint64_t, uint64_t, uint64_t>, DevPtr> scaled_;
     Ctx::MsmJob job_;
+    MsmPassRef pass_;
 };
 
 namespace detail {
-inline G1Vec pick(const MsmQueue &q, const std::vector<size_t> &idx) {
+inline G1Vec pick(const MsmPassRef &pass, const std::vector<size_t> &idx) {
     G1Vec out;
-    for (size_t i : idx) out.push_back(q.res.at(i));
+    for (size_t i : idx) out.push_back(pass->at(i));
     return out;
 }
 }  // namespace detail
@@ -108,17 +123,18 @@ inline std::function<G1Vec()> d_msm_q(Ctx &be, MsmQueue &q, const std::vector<Sr
     if (!k) return [] { return G1Vec{}; };
     if (!prescale || net.echo) {
         std::vector<size_t> sl = q.add(bases, scalars, lens);
-        return [&be, &q, &net, &pp, sl, k, p] {
-            std::vector<G1Vec> got = net.all_gather_g1(detail::pick(q, sl));
-            return be.g1_lincomb_batch(detail::by_item(got), detail::canonical(pp.dmsm_coeffs(p)), k);
+        FrVec coeffs = detail::canonical(pp.dmsm_coeffs(p));
+        return [&be, pass = q.ticket(), &net, coeffs, sl, k] {
+            std::vector<G1Vec> got = net.all_gather_g1(detail::pick(pass, sl));
+            return be.g1_lincomb_batch(detail::by_item(got), coeffs, k);
         };
     }
     Fr lam = pp.lambda(p), cp = pp.c(p);
     std::vector<DevPtr> scaled;
     for (size_t i = 0; i < k; ++i) scaled.push_back(q.scale(scalars[i], lam, lens[i]));
     std::vector<size_t> sl = q.add(bases, scaled, lens);
-    return [&be, &q, &net, sl, k, n, cp] {
-        std::vector<G1Vec> got = net.all_gather_g1(detail::pick(q, sl));
+    return [&be, pass = q.ticket(), &net, sl, k, n, cp] {
+        std::vector<G1Vec> got = net.all_gather_g1(detail::pick(pass, sl));
         G1Vec sums = be.g1_lincomb_batch(detail::by_item(got), FrVec(n, Fr{{1, 0, 0, 0}}), k);
         return be.g1_lincomb_batch(sums, FrVec{cp.to_canonical()}, k);
     };
@@ -126,7 +142,7 @@ inline std::function<G1Vec()> d_msm_q(Ctx &be, MsmQueue &q, const std::vector<Sr
 
 inline std::function<G1()> commit_q(MsmQueue &q, const PowersOfG &pg, const DevPtr &peval, size_t len) {
     std::vector<size_t> sl = q.add({detail::level_for(pg, len)}, {peval}, {len});
-    return [&q, sl] { return q.res.at(sl[0]); };
+    return [pass = q.ticket(), sl] { return pass->at(sl[0]); };
 }
 
 inline std::function<G1Vec()> c_commit_q(Ctx &be, MsmQueue &q, const PowersOfG &pg, const std::vector<DevPtr> &pevals, const std::vector<size_t> &lens,
@@ -143,8 +159,8 @@ inline std::function<G1Vec()> d_commit_many_q(Ctx &be, MsmQueue &q, const Powers
     std::vector<SrsPtr> srs;
     for (size_t n : lens) srs.push_back(detail::level_for(pg, n));
     std::vector<size_t> sl = q.add(srs, pevals, lens);
-    return [&be, &q, &net, sl, k] {
-        std::vector<G1Vec> got = net.all_gather_g1(detail::pick(q, sl));
+    return [&be, pass = q.ticket(), &net, sl, k] {
+        std::vector<G1Vec> got = net.all_gather_g1(detail::pick(pass, sl));
         return be.g1_lincomb_batch(detail::by_item(got), FrVec(net.n_parties, Fr{{1, 0, 0, 0}}), k);
     };
 }
@@ -180,9 +196,9 @@ inline OpensInFlight open_many_q(Ctx &be, MsmQueue &q, const PowersOfG &pg, cons
         q.keep.push_back(rounds[i].out);  // the q buffers must outlive the batched MSM
     }
     std::vector<Fr> vals = out.values;
-    out.finish = [&q, cuts, vals] {
+    out.finish = [pass = q.ticket(), cuts, vals] {
         std::vector<Opening> res;
-        for (size_t i = 0; i < vals.size(); ++i) res.push_back({vals[i], detail::pick(q, (*cuts)[i])});
+        for (size_t i = 0; i < vals.size(); ++i) res.push_back({vals[i], detail::pick(pass, (*cuts)[i])});
         return res;
     };
     return out;
@@ -280,12 +296,12 @@ inline std::function<std::vector<Opening>()> c_open_many_q(Ctx &be, MsmQueue &q,
         t.value = cur[0];
         tails->push_back(t);
     }
-    return [&q, f_com, tails, cuts, k] {
+    return [pass = q.ticket(), f_com, tails, cuts, k] {
         G1Vec com = f_com();
         std::vector<Opening> out;
         for (size_t i = 0; i < k; ++i) {
             Opening o{(*tails)[i].value, G1Vec(com.begin() + cuts[i], com.begin() + cuts[i + 1])};
-            for (size_t it : (*tails)[i].items) o.proofs.push_back(q.res.at(it));
+            for (size_t it : (*tails)[i].items) o.proofs.push_back(pass->at(it));
             out.push_back(o);
         }
         return out;
@@ -298,7 +314,10 @@ inline std::vector<std::vector<Triple>> c_sumcheck_product_many(Ctx &be, const s
                                                                 const PackedSharingParams &pp, Net &net) {
     size_t n = Ctx::log2_exact(len);
     std::vector<ScRequest> reqs;
-    for (auto &fg : pairs) reqs.push_back({ScRequest::Product, fg.first, fg.second, len, FrVec(challenge.begin(), challenge.begin() + n)});
+    for (auto &fg : pairs) {
+        detail::trace(be, 'c', fg.first, fg.second, len, challenge, n);
+        reqs.push_back({ScRequest::Product, fg.first, fg.second, len, FrVec(challenge.begin(), challenge.begin() + n)});
+    }
     std::vector<std::vector<Triple>> out;
     for (ScResult &r : be.sumcheck_batch(reqs)) {
         std::vector<Triple> tr = detail::triples_of(r.sums);
@@ -327,6 +346,7 @@ inline std::function<std::vector<std::vector<Triple>>()> d_sumcheck_product_many
     for (auto &it : items) {
         size_t n = Ctx::log2_exact(it.len);
         if (it.challenge.size() < n + s) throw ZkError(ZK_ERR_INVALID, "d_sumcheck_product: fewer challenges than local + party rounds");
+        detail::trace(be, 'd', it.f, it.g, it.len, it.challenge, n + s);
         ns->push_back(n);
         chals->push_back(it.challenge);
         reqs.push_back({ScRequest::Product, it.f, it.g, it.len, FrVec(it.challenge.begin(), it.challenge.begin() + n)});

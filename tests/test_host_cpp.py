@@ -25,7 +25,15 @@ NATIVE = os.path.join(ROOT, "tests", "native")
 R = po.R_MOD
 
 
+def _need_gxx():
+    import shutil
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ on this box: the C++ host is not built (libzkhip.so and the Python host do not depend on it)")
+
+
 def _build():
+    _need_gxx()
     subprocess.check_call(["make", "-C", NATIVE, "-s", "host_mirror"])
     return os.path.join(NATIVE, "host_mirror")
 
@@ -404,6 +412,7 @@ def test_cpp_protocol_drivers_equal_the_python_drivers(tmp_path, which, l, n, ec
 # the example binary (host/examples/hyperplonk.cpp: the reference's hyperplonk/examples/*.rs in one program)
 # ---------------------------------------------------------------------------------------
 def _example():
+    _need_gxx()
     host = os.path.join(ROOT, "scalable-collaborative-zksnark_amd", "host")
     subprocess.check_call(["make", "-C", host, "-s"])
     return os.path.join(host, "bin", "hyperplonk")
@@ -489,9 +498,72 @@ def test_cpp_host_full_size_proof_has_the_python_hosts_digest(which, n):
 
 
 # ---------------------------------------------------------------------------------------
+# `hyperplonk --check`: the compiled host verifies its own proofs (zkhost/verify.hpp) -- no Python, no oracle in the loop
+# ---------------------------------------------------------------------------------------
+def _check_lines(r):
+    return [l for l in r.stdout.splitlines() if l.startswith("check: party ")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,parties,transcripts", [
+    (["--l", "1", "--n", "12"], 1, 6 + 1 + 3 + 3 * 9 + 3),                          # leader echo: every chain of the proof
+    (["--l", "1", "--n", "10", "--mode", "threads"], 8, 6 + 1 + 3 + 3 * 7 + 3),     # 8 party threads: the leader's d_ chains use all parties' values
+    (["--l", "2", "--n", "9", "--mode", "threads"], 16, 6 + 1 + 3 + 3 * 5 + 3),     # l = 2: the c_ tails have one clear round
+    (["--l", "1", "--n", "9", "--which", "dpermcheck"], 1, 1 + 3 + 3 * 6 + 3),
+    (["--l", "2", "--n", "9", "--mode", "threads", "--which", "cpermcheck"], 16, 6),
+    (["--l", "1", "--n", "9", "--which", "data-parallel", "--no-tables"], 1, 6 + 1 + 3 + 3 * 6 + 3),
+])
+def test_cpp_example_checks_its_own_proofs(args, parties, transcripts):
+    r = subprocess.run([_example()] + args + ["--reps", "2", "--check"], capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+    lines = _check_lines(r)
+    assert len(lines) == parties and all(" ok -- anchored" in l and "flipped limb rejected as" in l for l in lines), r.stdout[-2500:]
+    leader = [l for l in lines if l.startswith("check: party 0 ")]
+    assert len(leader) == 1 and f", {transcripts} transcripts pinned at both ends" in leader[0], leader
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["--l", "1", "--n", "12"], ["--l", "1", "--n", "10", "--mode", "threads"]])
+def test_cpp_example_rejects_a_flipped_limb(args):
+    """--tamper: one limb of one t2 of the transcript under test is flipped; the self-check must fail (exit code 3) on every party"""
+    r = subprocess.run([_example()] + args + ["--reps", "1", "--tamper"], capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 3, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    lines = _check_lines(r)
+    assert lines and all("FAILED [gate[3]]" in l for l in lines), lines
+    assert "the self-check failed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_example_checks_the_n20_proof_with_8_party_threads():
+    """BASELINE configs[3] per-party work, the real 8-party exchanges (threads sharing GPU 0), verified by the compiled host itself"""
+    r = subprocess.run([_example(), "--l", "1", "--n", "20", "--mode", "threads", "--reps", "1", "--check"], capture_output=True, text=True, timeout=1800,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+    lines = _check_lines(r)
+    assert len(lines) == 8 and all(" ok -- anchored" in l for l in lines), lines
+
+
+@pytest.mark.gpu
+def test_cpp_example_checks_the_n24_proof():
+    """BASELINE configs[4]'s per-party work (leader mode, 2^24 constraints) -- behind a memory guard"""
+    import zkhip
+
+    probe = zkhip.Ctx(0)
+    free, _total = probe.mem_info()
+    probe.close()
+    if free < (96 << 30):
+        pytest.skip(f"only {free >> 30} GiB of HBM free: the n = 24 run wants ~70 GiB")
+    r = subprocess.run([_example(), "--l", "1", "--n", "24", "--reps", "1", "--check"], capture_output=True, text=True, timeout=1800, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+    lines = _check_lines(r)
+    assert len(lines) == 1 and " ok -- anchored" in lines[0] and f", {6 + 1 + 3 + 3 * 21 + 3} transcripts pinned" in lines[0], lines
+
+
+# ---------------------------------------------------------------------------------------
 # the reference's own unit tests restated for the C++ host (tests/native/host_props.cpp): oracle-free properties
 # ---------------------------------------------------------------------------------------
 def _props():
+    _need_gxx()
     subprocess.check_call(["make", "-C", NATIVE, "-s", "host_props"])
     return os.path.join(NATIVE, "host_props")
 
