@@ -62,12 +62,14 @@ def transcript_sha256(res) -> str:
     return hashlib.sha256(b(*gp) + b"".join(b(c, v, prf) for c, (v, prf) in gc) + b(*wp) + b(*wc) + b"".join(b(v, prf) for v, prf in wo)).hexdigest()
 
 
-def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None):
+def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = False, serial_rep: bool = False, timeout: int = 900):
     """
     The same proof driven by the COMPILED host (scalable-collaborative-zksnark_amd/host: zkhost/hyperplonk.hpp, the C++ mirror of the
     reference's Rust crates above the C ABI) in its own process: leader mode, the SplitMix64 parameter set of the e2e leg (seed 100,
-    challenges 4242), best of `reps`.  Self-check: its transcript digest must equal `want_digest`, the digest of the Python driver's
-    transcript on the same parameter set -- the run the anchored check of the e2e leg has just verified.
+    challenges 4242), best of `reps`.  Self-checks: (want_digest) its transcript digest must equal the digest of the Python driver's
+    transcript on the same parameter set -- the run the anchored check of the e2e leg has just verified; (check) the host's own
+    anchored verifier (`--check`, zkhost/verify.hpp: no Python, no oracle in the loop) must print `ok`.  A figure that fails either
+    is withdrawn.
     """
     import subprocess
 
@@ -75,24 +77,45 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None):
     if not os.path.exists(exe):
         return {"error": "host/bin/hyperplonk is not built (__graft_entry__.build())"}
     try:
-        r = subprocess.run([exe, "--l", "1", "--n", str(n), "--reps", str(reps), "--digest"], capture_output=True, text=True, timeout=900)
+        cmd = [exe, "--l", "1", "--n", str(n), "--reps", str(reps), "--digest"] + (["--check"] if check else []) + (["--serial-rep"] if serial_rep else [])
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        wall = time.perf_counter() - t0
         if r.returncode != 0:
-            return {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
-        runs, comm, digests = [], None, set()
+            return {"error": f"rc {r.returncode}: {(r.stdout[-400:] + r.stderr[-300:])}"}
+        runs, comm, digests, serial, checks, setup = [], None, set(), {}, [], None
         for line in r.stdout.splitlines():
             w = line.split()
             if line.startswith("rep "):
                 runs.append({})
+                setup = float(w[3])
+            elif line.startswith("  End(serial):"):
+                serial[" ".join(w[1:-2])] = float(w[-2])
             elif line.startswith("  End:") and runs:
                 runs[-1][" ".join(w[1:-2])] = float(w[-2])
             elif line.startswith("Comm:"):
                 comm = line[len("Comm: "):]
             elif line.startswith("transcript sha256"):
                 digests.add(w[-1])
+            elif line.startswith("check: party "):
+                checks.append(line[len("check: "):])
         best = min(runs, key=lambda t: t.get("Distributed HyperPlonk", 1e9))
         out = {"timers_s": best, "first_proof_s": runs[0].get("Distributed HyperPlonk"), "comm_per_proof": comm, "reps": reps, "transcript_sha256": sorted(digests),
+               "setup_s": setup, "process_wall_s": wall,
+               "timers_note": "'Commit' / 'Wire identity' / 'Open' of timers_s are OVERLAPPED sections (a step's MSM pass is started asynchronously and collected later; the kernel phase of "
+                              "the Open step runs inside 'Wire identity'): they are not the reference's phases of the same name, only 'Distributed HyperPlonk' is comparable. "
+                              "timers_s_serial_steps (when present) runs every pass to completion inside its own step",
                "first_proof_note": "the first proof of a process also allocates the library's MSM arenas and job lanes (sized by demand); later proofs reuse them",
                "what": "the same call sequence on the same parameter set from the compiled C++ host (zkhost/hyperplonk.hpp) in its own process, leader mode"}
+        if serial:
+            out["timers_s_serial_steps"] = serial
+        if check:
+            ok = len(checks) == 1 and " ok -- anchored" in checks[0] and "flipped limb rejected" in checks[0] and len(digests) == 1
+            out["self_check"] = checks[0] if checks else "no check line"
+            out["self_check_ok"] = ok
+            out["transcript_check_kind"] = "anchored by the compiled host itself (hyperplonk --check): every chain pinned at both ends by independent kernels, c_ tails and sampled commits / opens recomputed, flipped limb rejected"
+            if not ok:
+                out["timers_s"] = None
         if want_digest is not None:
             out["transcript_equals_python_host"] = digests == {want_digest}
             if digests != {want_digest}:
@@ -243,6 +266,7 @@ def parse_args():
     ap.add_argument("--no-precompute", action="store_true", help="time the MSM without the SRS window table (zk_srs_precompute)")
     ap.add_argument("--no-extra", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (counter-collection runs)")
+    ap.add_argument("--no-e2e-n24", action="store_true", help="skip the n = 24 end-to-end leg (C++ host, ~25 s)")
     ap.add_argument("--big", type=int, default=24, help="log2 size of the large strong-scaling / sumcheck legs")
     ap.add_argument("--e2e-n", type=int, default=20, help="log2 constraints of the end-to-end leg (BASELINE configs[3]: 20)")
     ap.add_argument("--party-threads", action="store_true",
@@ -561,6 +585,30 @@ def run_rank(args, grp, gpu: int, ctx, net):
         watchdog.start()
 
     extra = {}
+    # ---- the north-star size: collaborative HyperPlonk l = 1, n = 24 (BASELINE configs[4]: one party's full work on one GPU) ----
+    # from the compiled host in its own process, self-checked by the host's own anchored verifier.  It runs BEFORE the other legs:
+    # the n = 24 parameter set with its window tables and pass arenas wants most of the device, and this process holds only the
+    # headline's 2^20-point level at this point.  Skipped -- and said so -- when the free HBM is below the footprint.
+    if world == 1 and not args.no_extra and not args.no_e2e and not args.no_e2e_n24:
+        try:
+            ctx.trim()
+            free_b, total_b = ctx.mem_info()
+            need_b = 200 << 30
+            if free_b < need_b:
+                extra["e2e_n24"] = {"skipped": f"{free_b >> 30} GiB of HBM free, the n = 24 parameter set with its window tables and pass arenas wants ~{need_b >> 30} GiB"}
+            else:
+                r24 = cpp_host_e2e(24, reps=2, check=True, serial_rep=True, timeout=1500)
+                ref24 = 398458791  # SURVEY.md 8(d), derived from dhyperplonk.rs:198-553
+                comp24 = ref24 - (1 << 25)  # the two opens of V share their first quotient's commitment (computed once)
+                t24 = (r24.get("timers_s") or {}).get("Distributed HyperPlonk")
+                r24.update({"n": 24, "l": 1, "parties": 8, "mode": "leader (party 0's full work, no-comm echo net), compiled C++ host, own process",
+                            "parameter_set": "SplitMix64 tables (seed 100), challenges 4242", "hbm_free_before_GiB": free_b >> 30,
+                            "scalar_muls_per_proof_reference_count": ref24, "scalar_muls_computed": comp24,
+                            "scalar_muls_computed_per_s": (comp24 / t24) if t24 else None})
+                extra["e2e_n24"] = r24
+        except Exception as ex:
+            extra["e2e_n24"] = {"error": repr(ex)}
+
     if not args.no_extra:
         try:
             # ---- strong scaling of ONE primitive over the ranks (total work fixed) ----
@@ -602,6 +650,10 @@ def run_rank(args, grp, gpu: int, ctx, net):
             strong[f"sumcheck_product_2p{big}"] = {"ms": tt * 1e3, "fr_field_ops_per_s": 18.0 * (1 << big) / tt, "hbm_algorithmic_GBps": 64.0 * (1 << big) / tt / 1e9,
                                                   "elements_per_rank": per, "layout": "cyclic (index i on rank i mod N)"}
             extra["strong"] = dict(strong, note="total size fixed, split over the ranks; N = 1 is the monolithic call")
+            r24 = extra.get("e2e_n24") or {}
+            single = (strong.get("msm_2p24") or {}).get("scalar_muls_per_s")  # one blocking 2^24-point MSM of this run
+            if r24.get("scalar_muls_computed_per_s") and single:
+                r24["fraction_of_single_2p24_msm_rate"] = r24["scalar_muls_computed_per_s"] / single
 
             # ---- the sumcheck family against the HBM roofline (rank-local; reported at N = 1) ----
             if world == 1:
@@ -781,7 +833,8 @@ def run_rank(args, grp, gpu: int, ctx, net):
             except Exception as ex:  # the headline must survive a failure of this leg
                 extra["e2e"] = {"error": repr(ex)}
             if world == 1 and isinstance(extra.get("e2e"), dict) and "error" not in extra["e2e"]:
-                extra["e2e"]["cpp_host"] = cpp_host_e2e(args.e2e_n, want_digest=extra["e2e"].get("transcript_sha256") if extra["e2e"].get("transcript_checks") == "ok" else None)
+                extra["e2e"]["cpp_host"] = cpp_host_e2e(args.e2e_n, want_digest=extra["e2e"].get("transcript_sha256") if extra["e2e"].get("transcript_checks") == "ok" else None, check=True,
+                                                        serial_rep=True)
                 # one figure per proof: the faster of the two verified hosts (same inputs, same transcript)
                 cand = {"python": (extra["e2e"].get("timers_s") or {}).get("Distributed HyperPlonk"),
                         "cpp": (extra["e2e"]["cpp_host"].get("timers_s") or {}).get("Distributed HyperPlonk") if extra["e2e"]["cpp_host"].get("transcript_equals_python_host") else None}
@@ -789,6 +842,12 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 if cand:
                     best_host = min(cand, key=cand.get)
                     extra["e2e"]["proof_s"] = {"host": best_host, "seconds": cand[best_host], "all": cand}
+                    comp = extra["e2e"].get("scalar_muls_computed")
+                    if comp and out.get("value"):
+                        # how close the proof's mix of 794 MSMs (2^10 .. 2^22 points) runs to the rate of ONE 2^20-point MSM (`value`)
+                        extra["e2e"]["msm_mix_efficiency"] = {"proof_scalar_muls_per_s": comp / cand[best_host], "single_2p20_msm_scalar_muls_per_s": out["value"],
+                                                              "ratio": comp / cand[best_host] / out["value"],
+                                                              "note": "scalar-muls the proof computes / its wall time (sumchecks, exchanges and host arithmetic included), over the headline rate"}
 
         # ---- G2: `d_msm` is generic over CurveGroup (dmsm.rs:9), powers_of_g2 are G2 points (dpoly_comm.rs:27,59-62) ----
         if world == 1:

@@ -108,6 +108,8 @@ struct Tuning {
     long msm_debug = 0;       // class geometry on stderr
     long msm_serial = 0;      // all classes on the ctx stream
     long msm_size_classes = 1;  // window-table items: one class per power-of-two length
+    // SRS / PSS maps on points (zk_srs.hip)
+    long g1_map_by_column = 1;  // zk_g1_apply_matrix: one lane per (output, column) when there are few outputs of many terms (0: always one lane per output)
 };
 Tuning& tuning();
 int tune_set(const char* key, long value);  // 0, or ZK_ERR_INVALID for an unknown key

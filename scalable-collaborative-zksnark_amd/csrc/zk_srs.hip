@@ -205,6 +205,34 @@ __global__ void __launch_bounds__(kBlk) k_g1_apply_matrix(const u32* __restrict_
     }
     xyzz30_store(out_xyzz, t, acc);
 }
+// The same map with ONE LANE PER (output, column): every lane is a single scalar multiplication M[r][c] * P_c, the `cols` terms
+// of an output are then added pairwise (k_xyzz_pair_sums, log2(cols) tiny launches).  ~3x the point operations of the joint form
+// (no shared doublings), but cols times the parallelism: the large-l maps of the leader -- unpack2 on 8l shares into l secrets
+// for a handful of vectors (dmsm.rs:30-39 at l = 16: 16 outputs of 128 terms each) -- are latency chains of 255 doublings + ~128
+// additions instead of 255 + ~16 000.  terms[(t * cols) + c], t = r * k + j.
+__global__ void __launch_bounds__(kBlk) k_g1_scale_cols(const u32* __restrict__ M, size_t rows, size_t cols, int topbit, const void* __restrict__ in,
+                                                      size_t isv, size_t isc, size_t k, void* __restrict__ terms) {
+    const size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (i >= rows * k * cols) return;
+    const size_t c = i % cols, t = i / cols, r = t / k, j = t % k;
+    const u32* m = M + (r * cols + c) * 8;
+    const Aff30 p = aff30_load(in, j * isv + c * isc);
+    Xyzz30 acc;
+    xyzz30_set_inf(acc);
+    for (int b = topbit; b >= 0; b--) {
+        acc = xyzz30_dbl(acc);
+        if ((m[b >> 5] >> (b & 31)) & 1u) xyzz30_madd(acc, p, false);
+    }
+    xyzz30_store(terms, i, acc);
+}
+// out[t * half + h] = in[t * width + 2h] + in[t * width + 2h + 1] (the odd one out is copied), half = ceil(width / 2)
+__global__ void __launch_bounds__(kBlk) k_xyzz_pair_sums(const void* __restrict__ in, size_t n, size_t width, void* __restrict__ out) {
+    const size_t half = (width + 1) / 2, i = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n * half) return;
+    const size_t t = i / half, h = i % half;
+    const Xyzz30 a = xyzz30_load(in, t * width + 2 * h);
+    xyzz30_store(out, i, (2 * h + 1 < width) ? xyzz30_add(a, xyzz30_load(in, t * width + 2 * h + 1)) : a);
+}
 __global__ void __launch_bounds__(kBlk) k_copy96_strided(const void* __restrict__ in, void* __restrict__ out, size_t rows, size_t k,
                                                        size_t osv, size_t osr) {
     const size_t t = (size_t)blockIdx.x * kBlk + threadIdx.x;
@@ -228,14 +256,18 @@ int g1_apply_matrix_internal(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows,
                 break;
             }
     const size_t total = rows * k;
-    void *d_m = nullptr, *d_x = nullptr, *d_a = nullptr;
+    // few outputs of many terms each: one lane per term (see k_g1_scale_cols); otherwise one lane per output
+    const bool by_column = cols >= 8 && total < 16384 && total * cols <= ((size_t)1 << 22) && tuning().g1_map_by_column != 0;
+    void *d_m = nullptr, *d_x = nullptr, *d_a = nullptr, *d_t = nullptr;
     auto cleanup = [&] {
         if (d_m) hipFree(d_m);
         if (d_x) hipFree(d_x);
         if (d_a) hipFree(d_a);
+        if (d_t) hipFree(d_t);
     };
     hipError_t e = device_alloc(ctx, &d_m, std::max<size_t>(rows * cols * 32, 32));
-    if (e == hipSuccess) e = device_alloc(ctx, &d_x, ((total + 63) & ~(size_t)63) * 192);
+    if (e == hipSuccess) e = device_alloc(ctx, &d_x, ((total * (by_column ? (cols + 1) / 2 : 1) + 63) & ~(size_t)63) * 192);
+    if (e == hipSuccess && by_column) e = device_alloc(ctx, &d_t, ((total * cols + 63) & ~(size_t)63) * 192);
     if (e == hipSuccess) e = device_alloc(ctx, &d_a, total * 96);
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, h_matrix, rows * cols * 32, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // h_matrix is caller memory
@@ -243,9 +275,22 @@ int g1_apply_matrix_internal(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows,
         cleanup();
         return hip_fail(ctx, e, "g1_apply_matrix: allocation");
     }
-    hipLaunchKernelGGL(k_g1_apply_matrix, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const u32*)d_m, rows, cols, top,
-                       d_in, isv, isc, k, d_x);
-    int rc = xyzz_to_affine_batch(ctx, d_x, total, d_a);
+    void* d_sum = d_x;
+    if (by_column) {
+        hipLaunchKernelGGL(k_g1_scale_cols, dim3((unsigned)((total * cols + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const u32*)d_m, rows, cols, top,
+                           d_in, isv, isc, k, d_t);
+        void *src = d_t, *dst = d_x;  // (both hold ceil(width / 2) terms per output from the first pass on)
+        for (size_t width = cols; width > 1; width = (width + 1) / 2) {
+            hipLaunchKernelGGL(k_xyzz_pair_sums, dim3((unsigned)((total * ((width + 1) / 2) + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)src, total, width,
+                               dst);
+            std::swap(src, dst);
+        }
+        d_sum = src;
+    } else {
+        hipLaunchKernelGGL(k_g1_apply_matrix, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const u32*)d_m, rows, cols, top,
+                           d_in, isv, isc, k, d_x);
+    }
+    int rc = xyzz_to_affine_batch(ctx, d_sum, total, d_a);
     if (!rc) {
         hipLaunchKernelGGL(k_copy96_strided, dim3((unsigned)((total + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)d_a, d_out, rows, k,
                            osv, osr);

@@ -3,7 +3,7 @@
 // run the collaborative proof on the GPU(s), print the reference's timer labels and its `Comm: (up, down)` line (:564).
 //
 //   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2]
-//              [--digest] [--check] [--tamper]
+//              [--digest] [--check] [--tamper] [--serial-rep]
 //     leader   party 0 on the no-`comm` echo net (the reference's `-F leader` build: one party's full work; default)
 //     threads  all 8 l parties as threads of this process, one ctx each, exchanges through host memory (LocalTestNet); the
 //              parties share the visible GPUs round-robin
@@ -16,6 +16,8 @@
 //              forms, the repetitions and the traced run must agree bit for bit, and a copy of the transcript with one limb
 //              flipped must be rejected under exactly its label.  Prints one `check: ...` line per party; exit code 3 when any
 //              party fails.  --tamper flips that limb in the transcript under test instead (the run must then FAIL: exit 3).
+//     --serial-rep  after the timed repetitions, one more proof with every MSM pass run to completion inside the step that owns
+//              it (`End(serial):` lines): the per-step timers of the timed repetitions are OVERLAPPED sections
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -31,15 +33,15 @@ using namespace zkhost;
 struct Args {
     size_t l = 1, n = 12, reps = 3, table_max = 24;
     std::string mode = "leader", which = "dhyperplonk";
-    bool tables = true, digest = false, check = false, tamper = false;
+    bool tables = true, digest = false, check = false, tamper = false, serial_rep = false;
 };
 
 static std::atomic<int> g_failed{0};  // parties whose self-check failed
 
-static Transcript run_once(const Args &a, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers &tm) {
+static Transcript run_once(const Args &a, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers &tm, bool serial_steps = false) {
     if (a.which == "cpermcheck") return cpermcheck(a.n, pk, pp, be, net, &tm);
     if (a.which == "dpermcheck") return dpermcheck(a.n, pk, pp, be, net, &tm);
-    return dhyperplonk(a.n, pk, pp, be, net, &tm, a.which == "data-parallel");
+    return dhyperplonk(a.n, pk, pp, be, net, &tm, a.which == "data-parallel", serial_steps);
 }
 
 // SHA-256 over the transcript in the reference's order: gate proofs, (commitment, value, proofs) of the six gate openings, wiring
@@ -133,6 +135,10 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
     }
     be.sync();
     double setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (net.is_leader()) {
+        size_t fr = 0, tot = 0;
+        if (!zk_mem_info(be.handle(), &fr, &tot)) std::printf("setup %.3f s; HBM after setup: %.1f GiB free of %.1f GiB\n", setup, fr / 1073741824.0, tot / 1073741824.0);
+    }
     std::vector<std::string> digests;
     for (size_t r = 0; r < a.reps; ++r) {
         Timers tm;
@@ -144,6 +150,18 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
                         t.gate_commitments.size(), t.wiring_commits.size(), t.wiring_opens.size());
             for (auto &kv : tm.t) std::printf("  End: %-28s %.6f s\n", kv.first.c_str(), kv.second);
             std::printf("Comm: (%llu, %llu)\n", (unsigned long long)(net.upload - up0), (unsigned long long)(net.download - down0));
+            if (a.digest) std::printf("transcript sha256 %s\n", transcript_digest(t).c_str());
+        }
+    }
+    if (a.serial_rep && (a.which == "dhyperplonk" || a.which == "data-parallel")) {
+        // one more proof with every MSM pass run to completion inside its own step: per-step timers that cover what the
+        // reference's labels cover (the timed repetitions above overlap their steps); same transcript
+        Timers tm;
+        Transcript t = run_once(a, pk, pp, be, net, tm, true);
+        if (a.check) digests.push_back(transcript_digest(t));
+        if (net.is_leader()) {
+            std::printf("serial-steps rep:\n");
+            for (auto &kv : tm.t) std::printf("  End(serial): %-28s %.6f s\n", kv.first.c_str(), kv.second);
             if (a.digest) std::printf("transcript sha256 %s\n", transcript_digest(t).c_str());
         }
     }
@@ -169,10 +187,11 @@ int main(int argc, char **argv) {
         else if (k == "--no-tables") a.tables = false;
         else if (k == "--digest") a.digest = true;
         else if (k == "--check") a.check = true;
+        else if (k == "--serial-rep") a.serial_rep = true;
         else if (k == "--tamper") a.check = a.tamper = true;
         else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
         else {
-            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--digest] [--check] [--tamper]\n");
+            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--digest] [--check] [--tamper] [--serial-rep]\n");
             return 64;
         }
     }

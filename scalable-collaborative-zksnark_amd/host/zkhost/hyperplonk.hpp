@@ -228,7 +228,7 @@ inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedPr
 // dhyperplonk.rs:159-571 (data_parallel: dhyperplonk_data_parallel :573-960, which differs only at step 2.a -- `s` is local
 // random data, no exchange, :603)
 inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, Timers *tm_out = nullptr,
-                              bool data_parallel = false) {
+                              bool data_parallel = false, bool serial_steps = false) {
     size_t l = pp.l, M = size_t(1) << n, Ml = M / l;
     const PowersOfG &cc = pk.c_commitment, &dc = pk.d_commitment;
     Timers tm;
@@ -246,7 +246,18 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     MsmQueue q(be);
     auto f_c = c_commit_q(be, q, cc, tc, lc, pp, net);
     auto f_d = d_commit_many_q(be, q, dc, td, ld, net);
-    q.start();
+    G1Vec com;
+    auto collect_commit = [&] {
+        com = f_c();
+        G1Vec com_d = f_d();
+        com.insert(com.end(), com_d.begin(), com_d.end());
+    };
+    if (serial_steps) {
+        q.run();
+        collect_commit();
+    } else {
+        q.start();
+    }
     tm.end();
 
     // Step 3: gate identity (:223-260): the six sumchecks are independent -- one batched phase 1, then the hand-offs in order
@@ -257,30 +268,50 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
                                                    {pk.T("S2"), pk.T("a_evals")}, {pk.T("eq"), sum_ci}}, Ml, pk.challenge, pp, net);
     tm.end();
 
-    // Step 2: wiring identity (shared with dpermcheck).  The kernel phase of the Open step (:517-553) depends on nothing the
-    // wiring step produces, so it runs BEFORE the wiring pass is started: both passes are then in flight back to back.
-    tm.start("Wire identity");
     MsmQueue q_w(be), q_o(be);
-    auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel);
     std::vector<FrVec> pts3(3, pk.challenge);
-    auto f_co = c_open_many_q(be, q_o, cc, tc, lc, pts3, pp, net);
-    auto f_do = d_open_many_q(be, q_o, dc, td, ld, pts3, net);
-    q_w.start();
-    q_o.start();
-    q.finish();  // (host: exchange + point combinations of step 1, beside the passes on the GPU)
-    G1Vec com = f_c(), com_d = f_d();
-    com.insert(com.end(), com_d.begin(), com_d.end());
-    tm.end();
+    std::vector<Opening> ops;
+    if (serial_steps) {
+        // every MSM pass runs to completion inside the step that owns it: the timers cover what the reference's labels cover
+        // (same transcript; the measurement form, `hyperplonk --serial-rep`)
+        tm.start("Wire identity");
+        auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel);
+        q_w.run();
+        finalize_wiring(out);
+        tm.end();
+        tm.start("Open");
+        auto f_co = c_open_many_q(be, q_o, cc, tc, lc, pts3, pp, net);
+        auto f_do = d_open_many_q(be, q_o, dc, td, ld, pts3, net);
+        q_o.run();
+        ops = f_co();
+        std::vector<Opening> ops_d = f_do();
+        ops.insert(ops.end(), ops_d.begin(), ops_d.end());
+        tm.end();
+    } else {
+        // Step 2: wiring identity (shared with dpermcheck).  The kernel phase of the Open step (:517-553) depends on nothing the
+        // wiring step produces, so it runs BEFORE the wiring pass is started: both passes are then in flight back to back.
+        // (The labels below are therefore OVERLAPPED sections, not the reference's steps: only the total is comparable.)
+        tm.start("Wire identity");
+        auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel);
+        auto f_co = c_open_many_q(be, q_o, cc, tc, lc, pts3, pp, net);
+        auto f_do = d_open_many_q(be, q_o, dc, td, ld, pts3, net);
+        q_w.start();
+        q_o.start();
+        q.finish();  // (host: exchange + point combinations of step 1, beside the passes on the GPU)
+        collect_commit();
+        tm.end();
 
-    // Open (:517-553): collection of both passes
-    tm.start("Open");
-    q_w.finish();
-    finalize_wiring(out);
-    q_o.finish();
-    std::vector<Opening> ops = f_co(), ops_d = f_do();
-    ops.insert(ops.end(), ops_d.begin(), ops_d.end());
+        // Open (:517-553): collection of both passes
+        tm.start("Open");
+        q_w.finish();
+        finalize_wiring(out);
+        q_o.finish();
+        ops = f_co();
+        std::vector<Opening> ops_d = f_do();
+        ops.insert(ops.end(), ops_d.begin(), ops_d.end());
+        tm.end();
+    }
     for (size_t i = 0; i < 6; ++i) out.gate_commitments.push_back({com[i], ops[i]});
-    tm.end();
     tm.end();
     if (tm_out) *tm_out = tm;
     return out;

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import pyoracle as po
-from helpers import jac_norm_to_affine, pt_ints, pt_mont, rand_fr
+from helpers import jac_norm_to_affine, pt_ints, pt_mont, rand_fr  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -98,6 +98,128 @@ def test_g1_pss_maps_on_device(ctx, l):
     for j in range(k):
         exp = opp.pack_from_public_g1(secrets[j * l : (j + 1) * l])
         assert [pt_ints(out[p * k + j]) for p in range(pp.n)] == exp
+
+
+def _oracle_map(co, matrix_rows, vec):
+    """sum_c M[r][c] * P_c per row through the C oracle's group arithmetic (matrix: python ints, vec: [cols, 12] affine Montgomery)"""
+    return [pt_ints(co.msm_g1(vec, _mont(row))) for row in matrix_rows]
+
+
+@pytest.mark.parametrize("l", [8, 16])
+def test_g1_pss_maps_on_device_at_64_and_128_parties(ctx, co, l):
+    """
+    pack_from_public / unpack / unpack2 on vectors of POINTS (pss.rs:93-171 with G: DomainCoeff) at the party counts the reference
+    sweeps (handle_server.sh:26-31: l up to 32): zk_g1_apply_matrix with the host mirror's matrices against the ORACLE's
+    matrices (derived from its own domain code) applied with the C oracle's group law; at l = 8 one vector also against the
+    oracle's literal group FFTs.  Both kernel forms (one lane per output / one lane per term) must give the same bits; the time of
+    the leader's map of d_msm (dmsm.rs:30-39: unpack2 of 8l points into l) is printed for both.
+    """
+    import time
+
+    from helpers import synthetic_bases
+    from zkhip.pss import PackedSharingParams
+
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    k = 3
+    pts = synthetic_bases(k * pp.n, 40 + l)[0].copy()
+    pts[5] = 0  # an infinity among the inputs
+    d_in = ctx.to_device(pts)
+    o_unpack2, o_unpack, o_pack = opp.unpack2_matrix(), opp.unpack_matrix(), opp.pack_matrix()
+    times = {}
+    for name, mine, theirs in (("unpack2", pp.unpack2_matrix, o_unpack2), ("unpack", pp.unpack_matrix, o_unpack)):
+        m = _canon([v for row in mine for v in row]).reshape(l, pp.n, 4)
+        outs = {}
+        for form in (1, 0):
+            ctx.dbg_tune("g1_map_by_column", form)
+            try:
+                ctx.g1_apply_matrix(m, d_in, pp.n, 1, k, l, 1)  # (first call of a form: allocations)
+                ctx.sync()
+                t0 = time.perf_counter()
+                outs[form] = ctx.g1_apply_matrix(m, d_in, pp.n, 1, k, l, 1).download((k * l, 12))
+                times[(name, form)] = (time.perf_counter() - t0) * 1e3
+            finally:
+                ctx.dbg_tune("g1_map_by_column", 1)
+        assert (outs[0] == outs[1]).all(), name
+        for j in range(k):
+            exp = _oracle_map(co, theirs, pts[j * pp.n : (j + 1) * pp.n])
+            assert [pt_ints(r) for r in outs[1][j * l : (j + 1) * l]] == exp, (name, j)
+    if l == 8:  # the definition itself: ifft on the share domain, fft on the secret2 coset, every second slot
+        got = ctx.g1_apply_matrix(_canon([v for row in pp.unpack2_matrix for v in row]).reshape(l, pp.n, 4), d_in, pp.n, 1, 1, l, 1).download((l, 12))
+        assert [pt_ints(r) for r in got] == opp.unpack2_g1([pt_ints(r) for r in pts[: pp.n]])
+    # pack_from_public: vectors of l secrets -> n shares, written party-major (out[p*k + j])
+    secrets = pts[: k * l]
+    d_s = ctx.to_device(secrets)
+    mp = _canon([pp.pack_matrix[p][j] for p in range(pp.n) for j in range(l)]).reshape(pp.n, l, 4)
+    out = ctx.g1_apply_matrix(mp, d_s, l, 1, k, 1, k).download((pp.n * k, 12))
+    for j in range(k):
+        exp = _oracle_map(co, [row[:l] for row in o_pack], secrets[j * l : (j + 1) * l])
+        assert [pt_ints(out[p * k + j]) for p in range(pp.n)] == exp
+    print(f"\nzk_g1_apply_matrix at l = {l} ({pp.n} parties), {k} vectors, ms per call: " + ", ".join(f"{n} {'per-term' if f else 'per-output'} {t:.2f}" for (n, f), t in sorted(times.items())))
+    assert times[("unpack2", 1)] < 10.0 * k, "the leader's point map must stay below 10 ms per item"
+
+
+@pytest.mark.parametrize("l", [8, 16])
+def test_srs_to_packed_at_64_and_128_parties(ctx, co, l):
+    """PolynomialCommitmentCub::to_packed (dpoly_comm.rs:164-194) for single parties at l = 8, 16: every l-chunk of a level -> pack_from_public"""
+    from zkhip.pss import PackedSharingParams
+
+    rng = po.SplitMix64(300 + l)
+    n = 6
+    s = rng.fr_vec(n)
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    o_pack = opp.pack_matrix()
+    levels = ctx.srs_powers(_mont(s))
+    for party in (0, 5, pp.n - 1):
+        row = _canon([pp.pack_matrix[party][j] for j in range(l)])
+        for k in (n - 1, n):  # levels of 2^k points: 2^k / l chunks (the short levels pad with infinity, exercised at l = 1, 2, 4)
+            pts = levels[k].download()
+            got = ctx.srs_to_packed(levels[k], row, l).download()
+            assert len(got) == max(1, (1 << k) // l)
+            for c in range(len(got)):
+                chunk = pts[c * l : (c + 1) * l]
+                if len(chunk) < l:
+                    chunk = np.concatenate([chunk, np.zeros((l - len(chunk), 12), dtype=np.uint64)])
+                assert pt_ints(got[c]) == _oracle_map(co, [o_pack[party][:l]], chunk)[0], (party, k, c)
+
+
+def test_d_msm_with_64_real_party_threads(ctx, co):
+    """
+    d_msm (dmsm.rs:9-43) at l = 8 with all 64 parties as threads of this process, a ctx each on GPU 0 -- no echo shortcut: every
+    party's local MSM, the all-gather of the 64 results, and the public map on the gathered points.  The reference's identity
+    (dmsm.rs:92-138): packed bases x packed scalars -> the shares of [MSM; l], i.e. unpack over the 64 outputs == the plain MSM.
+    """
+    import zkhip
+    from helpers import synthetic_bases
+    from zkhip import dist_primitive as dp
+    from zkhip.net import LocalTestNet
+    from zkhip.pss import PackedSharingParams
+
+    l, m = 8, 64  # m secrets -> m / l packed chunks per party
+    pp, opp = PackedSharingParams(l), po.PackedSharingParams(l)
+    o_pack = opp.pack_matrix()
+    bases = synthetic_bases(m, 71)[0]
+    rng = po.SplitMix64(72)
+    scal = rng.fr_vec(m)
+    plain = co.msm_g1(bases, _mont(scal))
+    # party p's share of chunk c: pack_from_public of the chunk's l bases (points) and of its l scalars
+    sh_b = [np.array([pt_mont(_oracle_map(co, [o_pack[p][:l]], bases[c * l : (c + 1) * l])[0]) for c in range(m // l)]) for p in range(pp.n)]
+    sh_s = [[] for _ in range(pp.n)]
+    for c in range(m // l):
+        for p, v in enumerate(opp.pack_from_public(list(scal[c * l : (c + 1) * l]))):
+            sh_s[p].append(v)
+
+    def party(net):
+        be = zkhip.Ctx(0)
+        try:
+            srs = be.srs_register(sh_b[net.party_id])
+            return dp.d_msm(be, [srs], [be.to_device(_mont(sh_s[net.party_id]))], [m // l], pp, net)[0]
+        finally:
+            be.close()
+
+    outs = LocalTestNet.simulate_network_round(pp.n, party)
+    shares = np.array([jac_norm_to_affine(o) for o in outs])
+    got = _oracle_map(co, opp.unpack_matrix(), shares)  # unpack over the parties' outputs: [MSM; l]
+    assert got == [pt_ints(plain)] * l
 
 
 def test_packed_commitment_shares_recombine(ctx):
