@@ -440,6 +440,13 @@ int zk_msm_g1_batch_async(zk_ctx* ctx, size_t count, const zk_srs* const* srs, c
     for (size_t k = 0; k < count; k++) items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, d_scalars[k], n[k]};
     return msm_g1_batch_async(ctx, items.data(), count, job);
 }
+int zk_msm_set_share(zk_ctx* ctx, int percent) {
+    if (!ctx) return ZK_ERR_INVALID;
+    if (percent < 1 || percent > 100) return zk::fail(ctx, ZK_ERR_INVALID, "zk_msm_set_share: percent must be in 1..100");
+    const int prev = ctx->msm_share_pct;
+    ctx->msm_share_pct = percent;
+    return prev;
+}
 int zk_msm_wait(zk_ctx* ctx, zk_msm_job* job, uint64_t* h_out) {
     NEED(ctx, job);
     return msm_job_wait(ctx, job, h_out);

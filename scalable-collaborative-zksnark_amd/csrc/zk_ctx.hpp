@@ -36,6 +36,7 @@ struct zk_ctx {
     void* h_pinned = nullptr;  // pinned host staging
     size_t h_pinned_cap = 0;
     int msm_window_override = 0;
+    int msm_share_pct = 100;  // zk_msm_set_share: slots the accumulation of the passes enqueued from now on may fill
     float msm_ms[6] = {0, 0, 0, 0, 0, 0};
     float sc_ms[2] = {0, 0};  // tuning sc_ts = 3: device time of the first stage / of all launches of the last sumcheck-family call
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -608,8 +608,9 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
                                                     const u32* __restrict__ tile_b, size_t ns, u32 nsi, int nsi_shift, size_t nb, u32 T,
                                                     size_t tiles_per_w, size_t total_tiles, void* __restrict__ buckets,
                                                     void* __restrict__ heads, void* __restrict__ tails) {
-    const size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x;
-    if (g >= total_tiles) return;
+  // one tile per lane; with a capped grid (zk_msm_set_share: a pass that leaves workgroup slots to other kernels) a lane
+  // takes every gridDim.x * kBlk-th tile
+  for (size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x; g < total_tiles; g += (size_t)gridDim.x * kBlk) {
     const size_t w = g / tiles_per_w, t = g % tiles_per_w;  // w = row
     const ItemDesc it = items[w / rows_per_item];
     const void* __restrict__ bases = it.bases;
@@ -625,7 +626,7 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
     const uint2 last = oc[nb - 1];
     const u32 nw = last.x + last.y;  // entries of this window (zero digits are skipped)
     const u32 e0 = (u32)t * T;
-    if (e0 >= nw) return;
+    if (e0 >= nw) continue;
     const u32 e1 = (e0 + T < nw) ? e0 + T : nw;
     u32 b = tile_b[g];  // the bucket holding entry e0 (written by k_part_sort)
     uint2 cur_b = oc[b];
@@ -661,6 +662,7 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
     if (ps == bstart && e1 == bend) Cv::store(buckets, w * nb + b, acc);
     else if (ps == e0) Cv::store(heads, g, acc);  // single run covering the tile from its start
     else Cv::store(tails, g, acc);
+  }
 }
 
 // which bucket rows belong to a window one bit narrower than the widest: row r of the launch is window
@@ -1119,6 +1121,7 @@ struct MsmRun {
     void* buf[10] = {};
     char* hpin = nullptr;
     size_t pinned_bytes = 0;
+    size_t accum_wg_cap = 0;  // workgroups of every k_accum_tiles launch of this pass (0: one lane per tile)
 };
 
 static void msm_release(zk_ctx* ctx, MsmRun& run) {
@@ -1172,6 +1175,11 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<MsmClass>& classes = run.classes;
     const Tuning& tn = tuning();
+    if (ctx->msm_share_pct < 100) {  // zk_msm_set_share: a grid of persistent workgroups that leaves the other slots free
+        static int occ = 0;          // resident workgroups of k_accum_tiles<Cv> per CU (one static per instantiation)
+        if (!occ && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_accum_tiles<Cv>, kBlk, 0) != hipSuccess) occ = 2;
+        run.accum_wg_cap = std::max<size_t>(1, (size_t)ctx->cu_count * (size_t)std::max(occ, 1) * (size_t)ctx->msm_share_pct / 100);
+    }
     const u32 T_env = (u32)tn.msm_tile;
     const bool pair_env = tn.msm_pair != 0;
     const size_t fixq_max = (size_t)tn.msm_fixq;  // buckets per class
@@ -1481,7 +1489,10 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         }
         if (t_first) hipEventRecord(ctx->ev[1], st);
         if (cl.part > 0) hipStreamWaitEvent(st, L.ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
-        hipLaunchKernelGGL((k_accum_tiles<Cv>), dim3((unsigned)((cl.total_tiles + kBlk - 1) / kBlk)), dim3(kBlk), 0, st,
+        // (a pass with a share below 100 % leaves workgroup slots free for the kernels of other streams: zk_msm_set_share)
+        const size_t accum_wgs_full = (cl.total_tiles + kBlk - 1) / kBlk;
+        const size_t accum_wgs = run.accum_wg_cap ? std::min<size_t>(accum_wgs_full, run.accum_wg_cap) : accum_wgs_full;
+        hipLaunchKernelGGL((k_accum_tiles<Cv>), dim3((unsigned)accum_wgs), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const uint2*)oc, (const u32*)tile_b, cl.row_len,
                            (u32)ns, ((ns & (ns - 1)) == 0) ? (int)__builtin_ctzll(ns) : -1, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
         if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(L.ev_part[cl.part % zk_ctx::kParts], st);

@@ -33,7 +33,7 @@ using namespace zkhost;
 struct Args {
     size_t l = 1, n = 12, reps = 3, table_max = 24;
     std::string mode = "leader", which = "dhyperplonk";
-    bool tables = true, digest = false, check = false, tamper = false, serial_rep = false;
+    bool tables = true, digest = false, check = false, tamper = false, serial_rep = false, marks = false;
 };
 
 static std::atomic<int> g_failed{0};  // parties whose self-check failed
@@ -142,6 +142,7 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
     std::vector<std::string> digests;
     for (size_t r = 0; r < a.reps; ++r) {
         Timers tm;
+        tm.keep_marks = a.marks;
         uint64_t up0 = net.upload, down0 = net.download;
         Transcript t = run_once(a, pk, pp, be, net, tm);
         if (a.check) digests.push_back(transcript_digest(t));
@@ -151,13 +152,15 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
             for (auto &kv : tm.t) std::printf("  End: %-28s %.6f s\n", kv.first.c_str(), kv.second);
             std::printf("Comm: (%llu, %llu)\n", (unsigned long long)(net.upload - up0), (unsigned long long)(net.download - down0));
             if (a.digest) std::printf("transcript sha256 %s\n", transcript_digest(t).c_str());
+            for (auto &m : tm.marks) std::printf("  mark %9.3f ms  %s\n", m.second * 1e3, m.first.c_str());
         }
     }
     if (a.serial_rep && (a.which == "dhyperplonk" || a.which == "data-parallel")) {
         // one more proof with every MSM pass run to completion inside its own step: per-step timers that cover what the
         // reference's labels cover (the timed repetitions above overlap their steps); same transcript
         Timers tm;
-        Transcript t = run_once(a, pk, pp, be, net, tm, true);
+        Transcript t = run_once(a, pk, pp, be, net, tm, true);  // (the first blocking pass of the process sizes the ctx's own arenas:
+        t = run_once(a, pk, pp, be, net, tm = Timers(), true);  //  the second run is the steady state, like the timed repetitions)
         if (a.check) digests.push_back(transcript_digest(t));
         if (net.is_leader()) {
             std::printf("serial-steps rep:\n");
@@ -188,6 +191,7 @@ int main(int argc, char **argv) {
         else if (k == "--digest") a.digest = true;
         else if (k == "--check") a.check = true;
         else if (k == "--serial-rep") a.serial_rep = true;
+        else if (k == "--marks") a.marks = true;  // diagnostics: host time stamps of the calls inside a proof
         else if (k == "--tamper") a.check = a.tamper = true;
         else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
         else {

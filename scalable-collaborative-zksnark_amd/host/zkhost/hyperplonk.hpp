@@ -6,6 +6,7 @@
 // keep the reference's positions, the timers keep its labels (only the total is comparable once steps overlap).
 #pragma once
 #include <chrono>
+#include <cstdlib>
 #include <map>
 #include <string>
 
@@ -40,6 +41,15 @@ struct SplitMix64 {
 class Timers {  // wall-clock sections with the reference's labels (mpc-net/src/utils/timer.rs)
   public:
     std::map<std::string, double> t;
+    // diagnostics (`hyperplonk --marks`): host time stamps of the calls inside a proof, seconds since the first mark
+    bool keep_marks = false;
+    std::vector<std::pair<std::string, double>> marks;
+    void mark(const char *what) {
+        if (!keep_marks) return;
+        auto now = std::chrono::steady_clock::now();
+        if (marks.empty()) t0_ = now;
+        marks.push_back({what, std::chrono::duration<double>(now - t0_).count()});
+    }
     void start(const std::string &label) { stack_.push_back({label, std::chrono::steady_clock::now()}); }
     void end() {
         auto [label, t0] = stack_.back();
@@ -49,6 +59,7 @@ class Timers {  // wall-clock sections with the reference's labels (mpc-net/src/
 
   private:
     std::vector<std::pair<std::string, std::chrono::steady_clock::time_point>> stack_;
+    std::chrono::steady_clock::time_point t0_;
 };
 
 // hyperplonk/src/dhyperplonk.rs:19-63; every table is a device buffer of Fr
@@ -142,27 +153,49 @@ struct Transcript {
     std::vector<Opening> wiring_opens;
 };
 
+// Schedule of the overlapped proof.  0: three passes (commit | wiring | open-step).  1..100: TWO passes -- the commitments of
+// step 1 and the openings of step 4 (both depend on the tables only) form the first pass, started before the sumchecks with
+// this share of the chip's workgroup slots (zk_msm_set_share), so that the sumcheck chains of steps 2-3 run beside it instead of
+// behind it; the wiring pass follows at full width.  Same transcript either way.  ZKHOST_FIRST_PASS_SHARE overrides.
+inline int first_pass_share() {
+    static const int v = [] {
+        const char *e = std::getenv("ZKHOST_FIRST_PASS_SHARE");
+        int x = e ? std::atoi(e) : 0;
+        return x < 0 ? 0 : (x > 100 ? 100 : x);
+    }();
+    return v;
+}
+
 namespace detail {
 // step 2 of dhyperplonk (:262-514) == the body of dpermcheck (:992-1245), up to (not including) its one batched MSM pass:
 // every sumcheck / fold / open-round kernel has run, every MSM of the step sits in `q`.  -> finalize(): the exchanges of the
 // MSM results, filling the wiring lists in the reference's order.
 inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, MsmQueue &q,
-                                                        bool data_parallel) {
+                                                        bool data_parallel, Timers *tm = nullptr) {
+    auto mark = [tm](const char *w) {
+        if (tm) tm->mark(w);
+    };
     size_t l = pp.l, np = net.n_parties, M = size_t(1) << n, sbits = log2_floor(np);
     const PowersOfG &cc = pk.c_commitment, &dc = pk.d_commitment;
     const DevPtr &local_s_p = pk.T("local_s_p"), &local_s_l = pk.T("local_s_l");
     auto tr = std::make_shared<Transcript>();
     // 2.a (:268-294): every party broadcasts local_s; s = concatenation over parties (an all-gather that stays in HBM over RCCL)
+    mark("wiring: begin");
     DevPtr s_dev = data_parallel ? pk.T("s_data_parallel") : net.all_gather_device(be, local_s_l, 32 * (4 * M / np / l));
+    mark("2.a all-gather done");
     tr->wiring_proofs.push_back(c_sumcheck_product(be, s_dev, pk.T("V"), 4 * M / l, pk.challenge_r1, pp, net));  // 2.c
+    mark("2.c c_sumcheck_product done");
     // 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
     auto f_copen = c_open_many_q(be, q, cc, {pk.T("V"), pk.T("V")}, {4 * M / l, 4 * M / l}, {pk.challenge_r1, pk.challenge_r2}, pp, net);
+    mark("2.d c_open_many_q (kernels) done");
     // 2.e (:322-340)
     size_t hlen = 4 * M / np;
     DevPtr num = be.fr_axpb(local_s_p, pk.T("sid_p"), pk.alpha, pk.beta, hlen);
     DevPtr den = be.fr_axpb(pk.T("eq_r1_p"), pk.T("ssigma_p"), pk.alpha, pk.beta, hlen);
     DevPtr h_p = be.fr_batch_div(num, den, hlen);
+    mark("2.e num / den / h done");
     auto [sub, top] = d_acc_product(be, h_p, hlen, net);  // :342
+    mark("2.e d_acc_product done");
     q.keep.push_back(sub.tree);  // v1x and the layer slices below are views into it
     DevPtr v1x = sub.tree.fr(hlen);
     auto [vx0, vx1] = be.fr_deinterleave(sub.tree, hlen);  // :344-359
@@ -187,8 +220,11 @@ inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedPr
         for (auto &c : cur) c = c.fr(clen / 2);  // current = current[len/2..]
         clen /= 2;
     }
+    mark("2.e lists built");
     auto f_dsp = d_sumcheck_product_many_q(be, dsp, net);
+    mark("2.e d_sumcheck_product_many_q (kernels) done");
     auto f_dopen = d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net);
+    mark("2.e d_open_many_q (kernels) done");
     // leader-only tail on the N_p-leaf top tree (:480-511)
     auto top_commits = std::make_shared<std::vector<std::function<G1()>>>();
     auto top_opens = std::make_shared<OpensInFlight>();
@@ -207,6 +243,7 @@ inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedPr
         top_proofs->push_back(sumcheck_product(be, pk.T("eq_top"), d0, half, chs));
         top_proofs->push_back(sumcheck_product(be, d0, dd1, half, chs));
     }
+    mark("wiring: leader tail done");
     return [tr, f_dsp, f_copen, f_dcommit, f_dopen, top_commits, top_opens, top_proofs, has_top](Transcript &out) {
         out.wiring_proofs = tr->wiring_proofs;
         for (auto &p : f_dsp()) out.wiring_proofs.push_back(p);  // 2.e: after 2.c, before the leader-tree sumchecks (the reference's order)
@@ -232,9 +269,11 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     size_t l = pp.l, M = size_t(1) << n, Ml = M / l;
     const PowersOfG &cc = pk.c_commitment, &dc = pk.d_commitment;
     Timers tm;
+    if (tm_out) tm.keep_marks = tm_out->keep_marks;
     Transcript out;
     net.sync();
     tm.start("Distributed HyperPlonk");
+    tm.mark("proof begin");
 
     // Step 1: commit (:198-215): both commit families in one batched MSM pass, started here and collected later
     tm.start("Commit");
@@ -252,12 +291,24 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
         G1Vec com_d = f_d();
         com.insert(com.end(), com_d.begin(), com_d.end());
     };
+    std::vector<FrVec> pts3(3, pk.challenge);
+    std::vector<Opening> ops;
+    const int share = serial_steps ? 0 : first_pass_share();
+    std::function<std::vector<Opening>()> f_co1, f_do1;
     if (serial_steps) {
         q.run();
         collect_commit();
+    } else if (share) {
+        // the openings of step 4 (:517-553) join the commitments: their kernel phase (fold rounds, quotients) runs now
+        f_co1 = c_open_many_q(be, q, cc, tc, lc, pts3, pp, net);
+        f_do1 = d_open_many_q(be, q, dc, td, ld, pts3, net);
+        int prev = be.msm_set_share(share);
+        q.start();
+        be.msm_set_share(prev);
     } else {
         q.start();
     }
+    tm.mark("commit pass started");
     tm.end();
 
     // Step 3: gate identity (:223-260): the six sumchecks are independent -- one batched phase 1, then the hand-offs in order
@@ -266,12 +317,31 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     DevPtr sum_ci = be.fr_sub(pk.T("I"), pk.T("c_evals"), Ml);        // -c + I  :251-256
     out.gate_proofs = c_sumcheck_product_many(be, {{pk.T("eq"), pk.T("S1")}, {pk.T("S1"), sum_ab}, {pk.T("eq"), pk.T("S2")}, {pk.T("a_evals"), pk.T("b_evals")},
                                                    {pk.T("S2"), pk.T("a_evals")}, {pk.T("eq"), sum_ci}}, Ml, pk.challenge, pp, net);
+    tm.mark("gate sumchecks done");
     tm.end();
 
     MsmQueue q_w(be), q_o(be);
-    std::vector<FrVec> pts3(3, pk.challenge);
-    std::vector<Opening> ops;
-    if (serial_steps) {
+    if (share) {
+        // two passes: the first one (commit + open-step) is in flight since step 1; the wiring pass follows at full width
+        tm.start("Wire identity");
+        auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel, &tm);
+        q_w.start();
+        tm.mark("wiring pass started");
+        q.finish();  // (host: exchanges + point combinations of steps 1 and 4, beside the wiring pass on the GPU)
+        tm.mark("first pass finished");
+        collect_commit();
+        ops = f_co1();
+        std::vector<Opening> ops_d = f_do1();
+        ops.insert(ops.end(), ops_d.begin(), ops_d.end());
+        tm.mark("first pass collected");
+        tm.end();
+        tm.start("Open");
+        q_w.finish();
+        tm.mark("wiring pass finished");
+        finalize_wiring(out);
+        tm.mark("wiring finalized");
+        tm.end();
+    } else if (serial_steps) {
         // every MSM pass runs to completion inside the step that owns it: the timers cover what the reference's labels cover
         // (same transcript; the measurement form, `hyperplonk --serial-rep`)
         tm.start("Wire identity");
@@ -292,20 +362,27 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
         // wiring step produces, so it runs BEFORE the wiring pass is started: both passes are then in flight back to back.
         // (The labels below are therefore OVERLAPPED sections, not the reference's steps: only the total is comparable.)
         tm.start("Wire identity");
-        auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel);
+        auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel, &tm);
         auto f_co = c_open_many_q(be, q_o, cc, tc, lc, pts3, pp, net);
         auto f_do = d_open_many_q(be, q_o, dc, td, ld, pts3, net);
+        tm.mark("open-step kernels done");
         q_w.start();
+        tm.mark("wiring pass started");
         q_o.start();
+        tm.mark("open pass started");
         q.finish();  // (host: exchange + point combinations of step 1, beside the passes on the GPU)
         collect_commit();
+        tm.mark("commit pass collected");
         tm.end();
 
         // Open (:517-553): collection of both passes
         tm.start("Open");
         q_w.finish();
+        tm.mark("wiring pass finished");
         finalize_wiring(out);
+        tm.mark("wiring finalized");
         q_o.finish();
+        tm.mark("open pass finished");
         ops = f_co();
         std::vector<Opening> ops_d = f_do();
         ops.insert(ops.end(), ops_d.begin(), ops_d.end());

@@ -69,16 +69,26 @@ def main():
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")) for r in csv.DictReader(open(sys.argv[1]))]
     skip = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rows.sort()
-    # segments: runs of kernels separated by >= 300 us without any kernel
-    segs, cur, end = [], [], None
+    # a proof = the kernels around ONE k_batch_div (step 2.e runs it once per proof), cut at the longest kernel-free gaps between
+    # consecutive anchors (the host work between two repetitions: transcript assembly, digest) and at >= 5 ms gaps at both ends
+    anchors = [s for s, _, n in rows if "k_batch_div" in n]
+    gaps, end = [], None  # (gap length, time the gap starts, time it ends)
     for s, e, n in rows:
-        if end is not None and s > end + 300_000:
-            segs.append(cur)
-            cur = []
-        cur.append((s, e, n))
+        if end is not None and s > end:
+            gaps.append((s - end, end, s))
         end = e if end is None else max(end, e)
-    segs.append(cur)
-    proofs = [sg for sg in segs if sum("k_batch_div" in n for _, _, n in sg) == 1 and sum("k_accum_tiles" in n for _, _, n in sg) > 10]
+    cuts = []
+    for a0, a1 in zip(anchors, anchors[1:]):
+        between = [g for g in gaps if a0 < g[1] and g[2] < a1]
+        if between:
+            cuts.append(max(between))
+    bounds = []
+    for i, a0 in enumerate(anchors):
+        lo = cuts[i - 1][2] if i > 0 else max([g[2] for g in gaps if g[2] <= a0 and g[0] > 5_000_000] or [rows[0][0]])
+        hi = cuts[i][1] if i < len(cuts) else min([g[1] for g in gaps if g[1] >= a0 and g[0] > 5_000_000] or [max(e for _, e, _ in rows)])
+        bounds.append((lo, hi))
+    segs = [[r for r in rows if lo <= r[0] and r[1] <= hi] for lo, hi in bounds]
+    proofs = [sg for sg in segs if sum("k_accum_tiles" in n for _, _, n in sg) > 10]
     print(f"{len(rows)} dispatches, {len(segs)} segments, {len(proofs)} proofs found; skipping the first {skip}")
     for pi, sg in enumerate(proofs[skip:]):
         t0, t1 = min(s for s, _, _ in sg), max(e for _, e, _ in sg)
