@@ -221,14 +221,6 @@ typedef struct zk_msm_job zk_msm_job;
 int zk_msm_g1_batch_async(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets,
                           const void *const *d_scalars, const size_t *n, zk_msm_job **job);
 int zk_msm_wait(zk_ctx *ctx, zk_msm_job *job, uint64_t *h_out);
-/* Share of the chip the MSM passes ENQUEUED FROM NOW ON may fill with their accumulation kernel: percent of the resident
- * workgroup slots (1..100; 100 = default: every slot).  A proof's first pass (the commitments of step 1 and the openings of
- * step 4, hyperplonk/src/dhyperplonk.rs:198-215,517-553: independent of the sumchecks) runs beside the sumcheck chains of
- * steps 2-3 (:223-514); the accumulation's workgroups live ~0.6 ms and fill every slot, so the chains' ~300 small dependent
- * launches would each wait for slots to drain.  A pass with a share below 100 runs its accumulation as a grid of that many
- * persistent workgroups and the other slots stay free for the chains.  Same results (the kernel only walks its tiles in
- * another order); sticky per ctx; returns the previous value, or ZK_ERR_INVALID. */
-int zk_msm_set_share(zk_ctx *ctx, int percent);
 /* ---- G2: `d_msm` / `G::msm` are generic over CurveGroup (dmsm.rs:9,23); the reference's parameters carry G2 points
  * in powers_of_g2 (dpoly_comm.rs:27,59-62).  Same pipeline, coordinates in Fq2 = Fq[u]/(u^2 + 1).
  * Layouts (ark-bls12-381): G2Affine = { x: Fq2{c0, c1}, y: Fq2, infinity } -> 192-byte records x.c0|x.c1|y.c0|y.c1,

@@ -23,7 +23,7 @@ static const TuneKey kTuneKeys[] = {
     {"msm_table_dc", &Tuning::msm_table_dc}, {"msm_qstep", &Tuning::msm_qstep}, {"msm_tile", &Tuning::msm_tile}, {"msm_pair", &Tuning::msm_pair},
     {"msm_fixq", &Tuning::msm_fixq}, {"msm_quad", &Tuning::msm_quad}, {"msm_stage", &Tuning::msm_stage}, {"msm_split", &Tuning::msm_split},
     {"msm_np", &Tuning::msm_np}, {"msm_debug", &Tuning::msm_debug}, {"msm_serial", &Tuning::msm_serial}, {"msm_size_classes", &Tuning::msm_size_classes},
-    {"g1_map_by_column", &Tuning::g1_map_by_column},
+    {"g1_map_by_column", &Tuning::g1_map_by_column}, {"msm_share", &Tuning::msm_share},
 };
 static Tuning g_tuning;
 int tune_set(const char* key, long value) {
@@ -439,13 +439,6 @@ int zk_msm_g1_batch_async(zk_ctx* ctx, size_t count, const zk_srs* const* srs, c
     std::vector<MsmItem> items(count);
     for (size_t k = 0; k < count; k++) items[k] = MsmItem{srs[k], offsets ? offsets[k] : 0, d_scalars[k], n[k]};
     return msm_g1_batch_async(ctx, items.data(), count, job);
-}
-int zk_msm_set_share(zk_ctx* ctx, int percent) {
-    if (!ctx) return ZK_ERR_INVALID;
-    if (percent < 1 || percent > 100) return zk::fail(ctx, ZK_ERR_INVALID, "zk_msm_set_share: percent must be in 1..100");
-    const int prev = ctx->msm_share_pct;
-    ctx->msm_share_pct = percent;
-    return prev;
 }
 int zk_msm_wait(zk_ctx* ctx, zk_msm_job* job, uint64_t* h_out) {
     NEED(ctx, job);

@@ -36,7 +36,6 @@ struct zk_ctx {
     void* h_pinned = nullptr;  // pinned host staging
     size_t h_pinned_cap = 0;
     int msm_window_override = 0;
-    int msm_share_pct = 100;  // zk_msm_set_share: slots the accumulation of the passes enqueued from now on may fill
     float msm_ms[6] = {0, 0, 0, 0, 0, 0};
     float sc_ms[2] = {0, 0};  // tuning sc_ts = 3: device time of the first stage / of all launches of the last sumcheck-family call
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -109,6 +108,7 @@ struct Tuning {
     long msm_debug = 0;       // class geometry on stderr
     long msm_serial = 0;      // all classes on the ctx stream
     long msm_size_classes = 1;  // window-table items: one class per power-of-two length
+    long msm_share = 100;     // EXPERIMENT (profiles/r05g): percent of the resident workgroup slots k_accum_tiles may fill (persistent grid below 100)
     // SRS / PSS maps on points (zk_srs.hip)
     long g1_map_by_column = 1;  // zk_g1_apply_matrix: one lane per (output, column) when there are few outputs of many terms (0: always one lane per output)
 };

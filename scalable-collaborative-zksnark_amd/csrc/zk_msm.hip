@@ -608,7 +608,7 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
                                                     const u32* __restrict__ tile_b, size_t ns, u32 nsi, int nsi_shift, size_t nb, u32 T,
                                                     size_t tiles_per_w, size_t total_tiles, void* __restrict__ buckets,
                                                     void* __restrict__ heads, void* __restrict__ tails) {
-  // one tile per lane; with a capped grid (zk_msm_set_share: a pass that leaves workgroup slots to other kernels) a lane
+  // one tile per lane; with a capped grid (tuning knob msm_share: a pass that leaves workgroup slots to other kernels) a lane
   // takes every gridDim.x * kBlk-th tile
   for (size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x; g < total_tiles; g += (size_t)gridDim.x * kBlk) {
     const size_t w = g / tiles_per_w, t = g % tiles_per_w;  // w = row
@@ -1175,10 +1175,10 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<MsmClass>& classes = run.classes;
     const Tuning& tn = tuning();
-    if (ctx->msm_share_pct < 100) {  // zk_msm_set_share: a grid of persistent workgroups that leaves the other slots free
+    if (tn.msm_share > 0 && tn.msm_share < 100) {  // experiment knob: a grid of persistent workgroups that leaves the other slots free
         static int occ = 0;          // resident workgroups of k_accum_tiles<Cv> per CU (one static per instantiation)
         if (!occ && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_accum_tiles<Cv>, kBlk, 0) != hipSuccess) occ = 2;
-        run.accum_wg_cap = std::max<size_t>(1, (size_t)ctx->cu_count * (size_t)std::max(occ, 1) * (size_t)ctx->msm_share_pct / 100);
+        run.accum_wg_cap = std::max<size_t>(1, (size_t)ctx->cu_count * (size_t)std::max(occ, 1) * (size_t)tn.msm_share / 100);
     }
     const u32 T_env = (u32)tn.msm_tile;
     const bool pair_env = tn.msm_pair != 0;
@@ -1489,7 +1489,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         }
         if (t_first) hipEventRecord(ctx->ev[1], st);
         if (cl.part > 0) hipStreamWaitEvent(st, L.ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
-        // (a pass with a share below 100 % leaves workgroup slots free for the kernels of other streams: zk_msm_set_share)
+        // (a pass with a share below 100 % leaves workgroup slots free for the kernels of other streams: knob msm_share)
         const size_t accum_wgs_full = (cl.total_tiles + kBlk - 1) / kBlk;
         const size_t accum_wgs = run.accum_wg_cap ? std::min<size_t>(accum_wgs_full, run.accum_wg_cap) : accum_wgs_full;
         hipLaunchKernelGGL((k_accum_tiles<Cv>), dim3((unsigned)accum_wgs), dim3(kBlk), 0, st,

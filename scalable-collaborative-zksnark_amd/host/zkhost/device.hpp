@@ -352,12 +352,6 @@ class Ctx {
         check(rc);
         return out;
     }
-    // share of the chip's workgroup slots the accumulation of the passes enqueued from now on may fill (zk_msm_set_share) -> previous value
-    int msm_set_share(int percent) {
-        int prev = zk_msm_set_share(h_, percent);
-        if (prev < 0) check(prev);
-        return prev;
-    }
     // the whole of d_msm in one call over the ctx's communicator (zk_d_msm)
     G1Vec d_msm(const std::vector<const Srs *> &srs, const std::vector<DevPtr> &scalars, const std::vector<size_t> &lens, const Fr *lambda_mont,
                 const FrVec &coeffs_canonical) {

@@ -6,7 +6,6 @@
 // keep the reference's positions, the timers keep its labels (only the total is comparable once steps overlap).
 #pragma once
 #include <chrono>
-#include <cstdlib>
 #include <map>
 #include <string>
 
@@ -153,19 +152,6 @@ struct Transcript {
     std::vector<Opening> wiring_opens;
 };
 
-// Schedule of the overlapped proof.  0: three passes (commit | wiring | open-step).  1..100: TWO passes -- the commitments of
-// step 1 and the openings of step 4 (both depend on the tables only) form the first pass, started before the sumchecks with
-// this share of the chip's workgroup slots (zk_msm_set_share), so that the sumcheck chains of steps 2-3 run beside it instead of
-// behind it; the wiring pass follows at full width.  Same transcript either way.  ZKHOST_FIRST_PASS_SHARE overrides.
-inline int first_pass_share() {
-    static const int v = [] {
-        const char *e = std::getenv("ZKHOST_FIRST_PASS_SHARE");
-        int x = e ? std::atoi(e) : 0;
-        return x < 0 ? 0 : (x > 100 ? 100 : x);
-    }();
-    return v;
-}
-
 namespace detail {
 // step 2 of dhyperplonk (:262-514) == the body of dpermcheck (:992-1245), up to (not including) its one batched MSM pass:
 // every sumcheck / fold / open-round kernel has run, every MSM of the step sits in `q`.  -> finalize(): the exchanges of the
@@ -293,18 +279,9 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     };
     std::vector<FrVec> pts3(3, pk.challenge);
     std::vector<Opening> ops;
-    const int share = serial_steps ? 0 : first_pass_share();
-    std::function<std::vector<Opening>()> f_co1, f_do1;
     if (serial_steps) {
         q.run();
         collect_commit();
-    } else if (share) {
-        // the openings of step 4 (:517-553) join the commitments: their kernel phase (fold rounds, quotients) runs now
-        f_co1 = c_open_many_q(be, q, cc, tc, lc, pts3, pp, net);
-        f_do1 = d_open_many_q(be, q, dc, td, ld, pts3, net);
-        int prev = be.msm_set_share(share);
-        q.start();
-        be.msm_set_share(prev);
     } else {
         q.start();
     }
@@ -321,27 +298,7 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     tm.end();
 
     MsmQueue q_w(be), q_o(be);
-    if (share) {
-        // two passes: the first one (commit + open-step) is in flight since step 1; the wiring pass follows at full width
-        tm.start("Wire identity");
-        auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel, &tm);
-        q_w.start();
-        tm.mark("wiring pass started");
-        q.finish();  // (host: exchanges + point combinations of steps 1 and 4, beside the wiring pass on the GPU)
-        tm.mark("first pass finished");
-        collect_commit();
-        ops = f_co1();
-        std::vector<Opening> ops_d = f_do1();
-        ops.insert(ops.end(), ops_d.begin(), ops_d.end());
-        tm.mark("first pass collected");
-        tm.end();
-        tm.start("Open");
-        q_w.finish();
-        tm.mark("wiring pass finished");
-        finalize_wiring(out);
-        tm.mark("wiring finalized");
-        tm.end();
-    } else if (serial_steps) {
+    if (serial_steps) {
         // every MSM pass runs to completion inside the step that owns it: the timers cover what the reference's labels cover
         // (same transcript; the measurement form, `hyperplonk --serial-rep`)
         tm.start("Wire identity");

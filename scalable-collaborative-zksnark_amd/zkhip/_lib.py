@@ -61,7 +61,6 @@ SYMBOLS = [
     ("zk_msm_g1_batch", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("zk_msm_g1_batch_async", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _pp]),
     ("zk_msm_wait", _i, [_vp, _vp, _vp]),
-    ("zk_msm_set_share", _i, [_vp, _i]),
     ("zk_srs_register_g2", _i, [_vp, _vp, _sz, _sz, _pp]),
     ("zk_msm_g2", _i, [_vp, _vp, _sz, _vp, _sz, _vp]),
     ("zk_msm_g2_batch", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp]),
