@@ -6,7 +6,6 @@
 // keep the reference's positions, the timers keep its labels (only the total is comparable once steps overlap).
 #pragma once
 #include <chrono>
-#include <cstdlib>
 #include <map>
 #include <string>
 
@@ -157,12 +156,8 @@ namespace detail {
 // step 2 of dhyperplonk (:262-514) == the body of dpermcheck (:992-1245), up to (not including) its one batched MSM pass:
 // every sumcheck / fold / open-round kernel has run, every MSM of the step sits in `q`.  -> finalize(): the exchanges of the
 // MSM results, filling the wiring lists in the reference's order.
-// q_early (optional): the MSMs that exist before the step's sumcheck chains -- the quotient commitments of the two opens of V
-// and the nine d_commits, 70 % of the step's scalar-muls -- go to this queue, which is STARTED here, as soon as they are queued;
-// the caller finishes it before calling finalize.
 inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, MsmQueue &q,
-                                                        bool data_parallel, Timers *tm = nullptr, MsmQueue *q_early = nullptr) {
-    MsmQueue &qe = q_early ? *q_early : q;
+                                                        bool data_parallel, Timers *tm = nullptr) {
     auto mark = [tm](const char *w) {
         if (tm) tm->mark(w);
     };
@@ -177,7 +172,7 @@ inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedPr
     tr->wiring_proofs.push_back(c_sumcheck_product(be, s_dev, pk.T("V"), 4 * M / l, pk.challenge_r1, pp, net));  // 2.c
     mark("2.c c_sumcheck_product done");
     // 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
-    auto f_copen = c_open_many_q(be, qe, cc, {pk.T("V"), pk.T("V")}, {4 * M / l, 4 * M / l}, {pk.challenge_r1, pk.challenge_r2}, pp, net);
+    auto f_copen = c_open_many_q(be, q, cc, {pk.T("V"), pk.T("V")}, {4 * M / l, 4 * M / l}, {pk.challenge_r1, pk.challenge_r2}, pp, net);
     mark("2.d c_open_many_q (kernels) done");
     // 2.e (:322-340)
     size_t hlen = 4 * M / np;
@@ -195,11 +190,7 @@ inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedPr
     std::vector<DevPtr> com_tabs = {local_s_p};
     com_tabs.insert(com_tabs.end(), tabs8.begin(), tabs8.end());
     std::vector<size_t> com_lens(9, hlen);
-    auto f_dcommit = d_commit_many_q(be, qe, dc, com_tabs, com_lens, net);  // 2.b, then :363-380
-    if (q_early) {
-        q_early->start();
-        mark("early wiring pass started");
-    }
+    auto f_dcommit = d_commit_many_q(be, q, dc, com_tabs, com_lens, net);  // 2.b, then :363-380
     std::vector<DevPtr> lay_tabs(com_tabs.begin(), com_tabs.begin() + 6);   // 2.d, then :383-407
     std::vector<size_t> lay_lens(6, hlen);
     std::vector<FrVec> lay_pts(6, pk.challenge_r2);
@@ -307,37 +298,7 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     tm.end();
 
     MsmQueue q_w(be), q_o(be);
-    static const bool early_wiring = [] {
-        const char *e = std::getenv("ZKHOST_EARLY_WIRING");
-        return e && std::atoi(e) != 0;
-    }();
-    if (early_wiring && !serial_steps) {
-        // EXPERIMENT: the wiring pass in two parts -- the part whose scalars exist before the sumcheck chains is started inside
-        // wiring_enqueue, the rest together with the open-step MSMs afterwards
-        tm.start("Wire identity");
-        MsmQueue q_w1(be);
-        auto finalize_wiring = detail::wiring_enqueue(n, pk, pp, be, net, q_w, data_parallel, &tm, &q_w1);
-        auto f_co = c_open_many_q(be, q_w, cc, tc, lc, pts3, pp, net);
-        auto f_do = d_open_many_q(be, q_w, dc, td, ld, pts3, net);
-        tm.mark("open-step kernels done");
-        q_w.start();
-        tm.mark("late pass started");
-        q.finish();
-        collect_commit();
-        tm.mark("commit pass collected");
-        tm.end();
-        tm.start("Open");
-        q_w1.finish();
-        tm.mark("early wiring pass finished");
-        q_w.finish();
-        tm.mark("late pass finished");
-        finalize_wiring(out);
-        ops = f_co();
-        std::vector<Opening> ops_d = f_do();
-        ops.insert(ops.end(), ops_d.begin(), ops_d.end());
-        tm.mark("finalized");
-        tm.end();
-    } else if (serial_steps) {
+    if (serial_steps) {
         // every MSM pass runs to completion inside the step that owns it: the timers cover what the reference's labels cover
         // (same transcript; the measurement form, `hyperplonk --serial-rep`)
         tm.start("Wire identity");
