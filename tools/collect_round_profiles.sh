@@ -13,10 +13,15 @@ for n in 12 16 20 24; do python tools/hyperplonk_bench.py --n $n --reps 3 | tail
 for n in 12 16 20; do python tools/hyperplonk_bench.py --n $n --party-threads | tail -1; done > gpurun_out/${T}_e2e_party_threads.jsonl 2>&1
 # the same proofs from the compiled C++ host (host/examples/hyperplonk.cpp): leader mode n = 12 .. 24, 8 party threads on the one GPU, cpermcheck
 { B=scalable-collaborative-zksnark_amd/host/bin/hyperplonk
-  for n in 12 16 20 24; do echo "== hyperplonk --l 1 --n $n --reps 4 (leader)"; $B --l 1 --n $n --reps 4 | tail -7; done
-  for n in 12 16 20; do echo "== hyperplonk --l 1 --n $n --mode threads --reps 3 (8 party threads, ONE GPU does the work of eight)"; $B --l 1 --n $n --mode threads --reps 3 | tail -7; done
-  echo "== hyperplonk --l 2 --n 16 --which cpermcheck --reps 3 (leader)"; $B --l 2 --n 16 --which cpermcheck --reps 3 | tail -3
+  # (--check: every run verified by the compiled host itself, zkhost/verify.hpp; --serial-rep: per-step timers with every pass inside its step)
+  for n in 12 16 20 24; do echo "== hyperplonk --l 1 --n $n --reps 4 --check --serial-rep (leader)"; $B --l 1 --n $n --reps 4 --check --serial-rep | tail -14; done
+  for n in 12 16 20; do echo "== hyperplonk --l 1 --n $n --mode threads --reps 3 --check (8 party threads, ONE GPU does the work of eight)"; $B --l 1 --n $n --mode threads --reps 3 --check | tail -15; done
+  echo "== hyperplonk --l 2 --n 16 --which cpermcheck --reps 3 --check (leader)"; $B --l 2 --n 16 --which cpermcheck --reps 3 --check | tail -4
+  echo "== hyperplonk --l 1 --n 12 --reps 1 --tamper (must fail: exit code 3)"; $B --l 1 --n 12 --reps 1 --tamper > /tmp/tamper.out 2>&1; RC=$?; tail -2 /tmp/tamper.out; echo "exit code $RC"
 } > gpurun_out/${T}_e2e_cpp_host.txt 2>&1
+tools/profile_timeline.sh $T 20 5 > /dev/null 2>&1
+tools/profile_batch_affine.sh $T > /dev/null 2>&1
+tools/sc_valu.sh $T product 20 > /dev/null 2>&1
 python tools/g2_time.py 17 0 > gpurun_out/${T}_g2.txt 2>&1
 python tools/cpermcheck_time.py 20 3 > gpurun_out/${T}_cpermcheck.jsonl 2>&1
 python tools/sc_batch_time.py 18 > gpurun_out/${T}_sc_batch.txt 2>&1
@@ -26,4 +31,6 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0 ZK_BENCH_DEADLINE_S=600
 for N in 2 8; do ZK_BENCH_BACKEND=gloo python bench.py --gpus $N --steps 3 --warmup 1 --no-cpu --e2e-n $((N == 8 ? 16 : 20)) 2>gpurun_out/${T}_gloo$N.err | tail -1; done > gpurun_out/${T}_bench_gloo_ranks_sharing_one_gpu.jsonl
 ZK_BENCH_BACKEND=local python bench.py --gpus 8 --party-threads --steps 3 --warmup 1 --no-cpu 2>gpurun_out/${T}_threads8.err | tail -1 > gpurun_out/${T}_bench_party_threads_sharing_one_gpu.jsonl
 python bench.py --gpus 2 --no-cpu 2>/dev/null | tail -1 > gpurun_out/${T}_bench_gpus2_on_a_one_gpu_box_error_line.json
-tail -3 gpurun_out/${T}_e2e.jsonl; cat gpurun_out/${T}_g2.txt
+# randomised differential runs against the C oracle, new seeds
+{ STRESS_SEED=6061 python tools/stress_msm.py 120 | tail -1; STRESS_SEED=6062 STRESS_TABLE=1 python tools/stress_msm.py 120 | tail -1; STRESS_SEED=6063 python tools/stress_sumcheck.py 180 | tail -1; } > gpurun_out/${T}_stress.txt 2>&1
+tail -3 gpurun_out/${T}_e2e.jsonl; cat gpurun_out/${T}_g2.txt; cat gpurun_out/${T}_stress.txt
