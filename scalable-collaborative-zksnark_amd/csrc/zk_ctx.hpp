@@ -108,7 +108,6 @@ struct Tuning {
     long msm_debug = 0;       // class geometry on stderr
     long msm_serial = 0;      // all classes on the ctx stream
     long msm_size_classes = 1;  // window-table items: one class per power-of-two length
-    long msm_small_streams = 1;  // batches: classes sorted by work, the small ones on streams of their own (0: order of appearance, round-robin)
     long msm_share = 100;     // EXPERIMENT (profiles/r05g): percent of the resident workgroup slots k_accum_tiles may fill (persistent grid below 100)
     // SRS / PSS maps on points (zk_srs.hip)
     long g1_map_by_column = 1;  // zk_g1_apply_matrix: one lane per (output, column) when there are few outputs of many terms (0: always one lane per output)

@@ -1330,31 +1330,6 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         cl.pinned_off = pinned_bytes;
         pinned_bytes += ((cl.rows * (size_t)cl.npair * Cv::kJacBytes + 255) & ~(size_t)255) + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
     }
-    // ---- stream plan of a batch.  Classes run concurrently on the lane's streams, one after another on each stream.  In the
-    // order of appearance (a proof's items come largest first) the small classes -- latency chains of ~25 dependent launches that
-    // need a handful of workgroup slots -- ended up LAST on every stream and ran after the big ones, with the chip nearly empty
-    // (an n = 20 proof: 2.6 + 3.1 ms at the end of its two long passes, profiles/r05j_timeline_n20.txt).  Now: classes sorted by
-    // work; the big ones share the first streams, the small ones get streams of their own and run beside the big accumulations. ----
-    std::vector<int> stream_of(classes.size(), -1);  // -1: the lane's main stream, k >= 0: aux[k]
-    {
-        bool parts = false;
-        for (auto& cl : classes) parts = parts || cl.nparts > 1;
-        const size_t small_max = (size_t)1 << 22;  // entries (rows x row_len): ~0.5 ms of accumulation
-        if (!parts && classes.size() > 1 && tn.msm_small_streams != 0) {
-            std::stable_sort(classes.begin(), classes.end(), [](const MsmClass& a, const MsmClass& b) { return a.rows * a.row_len > b.rows * b.row_len; });
-            size_t nbig = 0;
-            for (auto& cl : classes) nbig += cl.rows * cl.row_len > small_max;
-            const int big_streams = (nbig == classes.size() || nbig == 0) ? 1 + zk_ctx::kAux : 3;  // main + aux[0], aux[1] | everything
-            size_t bi = 0, si = 0;
-            for (size_t i = 0; i < classes.size(); i++) {
-                const bool big = classes[i].rows * classes[i].row_len > small_max || big_streams == 1 + zk_ctx::kAux;
-                if (big) stream_of[i] = (int)(bi++ % big_streams) - 1;
-                else stream_of[i] = (big_streams - 1) + (int)(si++ % (zk_ctx::kAux - (big_streams - 1)));
-            }
-        } else {
-            for (size_t i = 0; i < classes.size(); i++) stream_of[i] = i == 0 ? -1 : (int)((i - 1) % zk_ctx::kAux);
-        }
-    }
     const bool dbg_classes = tn.msm_debug != 0;
     if (dbg_classes)
         for (auto& cl : classes) {
@@ -1462,7 +1437,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
     for (auto& cl : classes) {
         const size_t nitems = cl.idx.size(), ns = cl.ns, nb = cl.nb, total = cl.total;
         const bool t_first = timers && (cls_i == 0), t_last = timers && (cls_i + 1 == (size_t)classes[0].nparts);  // the first class's parts carry the timers
-        hipStream_t st = (!multi || stream_of[cls_i] < 0) ? L.main : L.aux[stream_of[cls_i]];
+        hipStream_t st = (!multi || cls_i == 0) ? L.main : L.aux[(cls_i - 1) % zk_ctx::kAux];
         u32* digits = (u32*)((char*)buf[0] + cl.off[0]);
         u32* sorted = digits;  // the digits are dead once partitioned: the sorted entries take their place
         u32* part_idx = (u32*)((char*)buf[1] + cl.off[1]);
