@@ -55,7 +55,8 @@ inline FrVec pss2ss(const Fr &share, const PackedSharingParams &pp, Net &net) {
     FrVec shares;
     for (auto &g : got) shares.push_back(g[0]);
     FrVec secrets = pp.unpack(shares), out;
-    for (const Fr &s : secrets) out.push_back(pp.pack_single(s)[net.party_id]);
+    const Fr &w = pp.pack_single_of_one()[net.party_id];  // pack_single(s)[p] = s * pack_single(1)[p]
+    for (const Fr &s : secrets) out.push_back(s * w);
     return out;
 }
 

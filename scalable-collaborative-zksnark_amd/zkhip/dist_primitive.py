@@ -37,7 +37,8 @@ def pss2ss(share: np.ndarray, pp: PackedSharingParams, net: Net) -> np.ndarray:
     """returns this party's Vec<F> of length l as [l,4] limbs"""
     shares = _fr_vec_to_ints(np.stack(net.all_gather(np.asarray(share, dtype=np.uint64).reshape(4))))
     secrets = pp.unpack(shares)
-    return _ints_to_fr([pp.pack_single(v)[net.party_id] for v in secrets])
+    w = pp.pack_single_of_one()[net.party_id]  # pack_single(s)[p] = s * pack_single(1)[p]
+    return _ints_to_fr([v * w % R_MOD for v in secrets])
 
 
 # ---------------------------------------------------------------------------------------
