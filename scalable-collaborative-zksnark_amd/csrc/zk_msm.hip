@@ -186,6 +186,10 @@ static int msm_pick_window_full(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     int c = lg <= 15 ? lg + 2 : (lg <= 18 ? 17 : lg - 1);
+    // two common widths for the short levels: in a batch (a proof's passes hold ~11 items of every size 2^6 .. 2^14) items of one
+    // table width and up to 2^msm_size_class_min points form ONE class, i.e. two launch chains instead of nine at the end of
+    // every pass; a single short MSM is a latency chain either way (tools/msm_time.py: within 5 %)
+    if (tuning().msm_small_table_widths != 0 && lg <= 14) c = lg <= 10 ? 12 : 14;
     c += (int)tuning().msm_table_dc;  // (sweeps)
     if (c < 4) c = 4;
     if (c > 20) c = 20;
@@ -1208,7 +1212,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         // passes walk the padded rows)
         int lgn = 0;
         while (((size_t)1 << lgn) < it.n) lgn++;
-        const int size_key = (shared && tn.msm_size_classes) ? lgn : 0;
+        const int size_key = (shared && tn.msm_size_classes) ? std::max(lgn, (int)tn.msm_size_class_min) : 0;  // (items of up to 2^msm_size_class_min points share a class)
         MsmClass* cl = nullptr;
         for (auto& x : classes)
             if (x.key_c == c && x.shared == shared && x.size_key == size_key) cl = &x;

@@ -116,7 +116,7 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
     if (const char *e = std::getenv("ZK_TABLE_POLICY")) {
         std::string spec = e;
         policy = [spec](size_t len) {
-            int lg = (int)log2_floor(len), c = lg <= 15 ? lg + 2 : (lg <= 18 ? 17 : lg - 1);  // the library's single-MSM pick (csrc/zk_msm.hip msm_pick_window_full)
+            int lg = (int)log2_floor(len), c = lg <= 10 ? 12 : (lg <= 14 ? 14 : (lg == 15 ? 17 : (lg <= 18 ? 17 : lg - 1)));  // the library's pick (csrc/zk_msm.hip msm_pick_window_full)
             const char *q = spec.c_str();
             int lo, hi, d, used;
             while (std::sscanf(q, "%d:%d:%d%n", &lo, &hi, &d, &used) == 3) {
@@ -155,6 +155,9 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
             for (auto &m : tm.marks) std::printf("  mark %9.3f ms  %s\n", m.second * 1e3, m.first.c_str());
         }
     }
+    if (net.is_leader() && a.reps && (a.which == "dhyperplonk" || a.which == "data-parallel"))
+        std::printf("note: 'Commit' / 'Wire identity' / 'Open' above are OVERLAPPED sections (a step's MSM pass is started asynchronously and collected later; the Open step's "
+                    "kernels run inside 'Wire identity'): they are not the reference's phases of the same name -- only 'Distributed HyperPlonk' is; --serial-rep prints the per-step form\n");
     if (a.serial_rep && (a.which == "dhyperplonk" || a.which == "data-parallel")) {
         // one more proof with every MSM pass run to completion inside its own step: per-step timers that cover what the
         // reference's labels cover (the timed repetitions above overlap their steps); same transcript

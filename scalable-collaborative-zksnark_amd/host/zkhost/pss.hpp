@@ -93,7 +93,7 @@ struct PackedSharingParams {
     Domain share, secret, secret2;
     // share_i = sum_j pack[i][j] secret_j (secrets zero-padded to 2l);  secret_j = sum_i unpack[j][i] share_i
     std::vector<FrVec> pack_matrix, unpack_matrix, unpack2_matrix;
-    mutable FrVec single_one_;  // pack_single(1), computed on first use
+    FrVec single_one_;  // pack_single(1)
 
     explicit PackedSharingParams(size_t l_) : l(l_), n(8 * l_), t(l_ - 1) {
         if (!l || (l & (l - 1))) throw std::invalid_argument("PackedSharingParams: l must be a power of two");
@@ -119,6 +119,7 @@ struct PackedSharingParams {
                 unpack2_matrix[j][i] = c2[j];
             }
         }
+        single_one_ = pack_single(Fr::one());
     }
 
     // pss.rs:69-73,93-99
@@ -127,10 +128,8 @@ struct PackedSharingParams {
     FrVec pack_single(const Fr &s) const { return pack_from_public(share.fft(secret.ifft(FrVec{s}))); }
     // pack_single is linear in its one argument: pack_single(s)[p] = s * pack_single(1)[p].  pss2ss (unpack.rs:72-97) needs entry p of
     // pack_single of every unpacked secret: one multiplication each instead of four transforms
-    const FrVec &pack_single_of_one() const {
-        if (single_one_.empty()) single_one_ = pack_single(Fr::one());
-        return single_one_;
-    }
+    // (computed in the constructor: one PackedSharingParams is shared by all party threads of a process)
+    const FrVec &pack_single_of_one() const { return single_one_; }
     // pss.rs:117-120,132-149
     FrVec unpack(const FrVec &shares) const {
         FrVec e = secret.fft(share.ifft(shares));
