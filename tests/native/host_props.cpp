@@ -12,7 +12,7 @@
 #include <cstring>
 #include <numeric>
 
-#include "zkhost/hyperplonk.hpp"
+#include "zkhost/verify.hpp"  // the shipped verifiers (check_sumcheck, check_sumcheck_product, product_round_target) + hyperplonk.hpp
 
 using namespace zkhost;
 
@@ -79,6 +79,32 @@ static void operator_test_transpose() {  // utils/operator.rs:42-49
     std::vector<std::vector<int>> m = {{1, 2, 3}, {4, 5, 6}, {7, 8, 9}}, e = {{1, 4, 7}, {2, 5, 8}, {3, 6, 9}};
     CHECK(transpose(m) == e);
 }
+static void verifier_accepts_and_rejects() {  // dsumcheck.rs:541-588 on host-made transcripts: right ones pass, a flipped limb anywhere fails
+    const size_t n = 6;
+    FrVec f = random_vec(size_t(1) << n, 71), g = random_vec(size_t(1) << n, 72), ch = random_vec(n, 73);
+    Fr claim = sum(hadamard(f, g)), claim_plain = sum(f);
+    std::vector<Triple> pr;
+    std::vector<Pair> pp_;
+    FrVec a = f, b = g, c = f;
+    for (size_t i = 0; i < n; ++i) pr.push_back(detail::round_product(a, b, ch[i])), pp_.push_back(detail::round_plain(c, ch[i]));
+    Fr fin = a[0] * b[0];
+    pr.push_back({Fr::zero(), fin, Fr::zero()});
+    pp_.push_back({Fr::zero(), c[0]});
+    CHECK(check_sumcheck_product(claim, pr, ch, n) && check_sumcheck(claim_plain, pp_, ch, n));
+    CHECK(sumcheck_product_chain(pr, ch, n, &claim, &fin));
+    CHECK(!check_sumcheck_product(claim + Fr::one(), pr, ch, n) && !check_sumcheck(claim_plain + Fr::one(), pp_, ch, n));
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            std::vector<Triple> bad = pr;
+            bad[i][k].v[1] ^= 4;
+            Fr wrong = fin + Fr::one();
+            CHECK(!sumcheck_product_chain(bad, ch, n, &claim, &fin));  // both ends pinned: every single flip is caught
+            CHECK(!sumcheck_product_chain(pr, ch, n, &claim, &wrong));
+        }
+    std::vector<Pair> badp = pp_;
+    badp[n][1].v[0] ^= 1;  // the closing (0, last) row is the evaluation the reference's comment leaves out
+    CHECK(!check_sumcheck(claim_plain, badp, ch, n));
+}
 static void dacc_product_sub_index_test() {  // dacc_product.rs:442-448
     CHECK(sub_index(26) == std::make_pair(size_t(20), size_t(21)));
 }
@@ -97,27 +123,8 @@ static void dsumcheck_local_test() {  // dsumcheck.rs:591-621: the halves' sums 
 }
 
 // ------------------------------------------------------------------------------------------------------------ verifier side of the sumchecks
-// dsumcheck.rs:541-558 with the query its comment leaves out: the last row carries the evaluation (0, last)
-static bool check_sumcheck(const Fr &h, const std::vector<Pair> &proof, const FrVec &ch, size_t rounds) {
-    if (proof[0][0] + proof[0][1] != h) return false;
-    for (size_t i = 1; i < rounds; ++i) {
-        Fr target = (proof[i - 1][1] - proof[i - 1][0]) * ch[i - 1] + proof[i - 1][0];
-        if (proof[i][0] + proof[i][1] != target) return false;
-    }
-    return true;
-}
-// dsumcheck.rs:559-588: the quadratic through (0, t0), (1, t1), (2, t2) evaluated at the challenge is the next claim
-static Fr quadratic_at(const Triple &t, const Fr &x) {
-    Fr half = Fr::from_u64(2).inverse();
-    Fr c = t[0], b = (-t[2] + t[1] * Fr::from_u64(4) - t[0] * Fr::from_u64(3)) * half, a = (t[2] - t[1] * Fr::from_u64(2) + t[0]) * half;
-    return a * x * x + b * x + c;
-}
-static bool check_sumcheck_product(const Fr &h, const std::vector<Triple> &proof, const FrVec &ch, size_t rounds) {
-    if (proof[0][0] + proof[0][1] != h) return false;
-    for (size_t i = 1; i < rounds; ++i)
-        if (proof[i][0] + proof[i][1] != quadratic_at(proof[i - 1], ch[i - 1])) return false;
-    return true;
-}
+// (check_sumcheck / check_sumcheck_product of dsumcheck.rs:541-588 are the library's own: zkhost/verify.hpp)
+static Fr quadratic_at(const Triple &t, const Fr &x) { return product_round_target(t, x); }
 static Fr mle_at(FrVec tab, const FrVec &point) {  // fold from the top variable, as fix_variable does (mle.rs:95-103)
     for (size_t i = 0; tab.size() > 1; ++i) {
         size_t h = tab.size() / 2;
@@ -334,6 +341,7 @@ int main(int argc, char **argv) {
             RUN(pss_test_multiplication);
             RUN(operator_test_transpose);
             RUN(dacc_product_sub_index_test);
+            RUN(verifier_accepts_and_rejects);
             RUN(dsumcheck_local_test);
         } else {
             if (zk_device_count() <= 0) return std::fprintf(stderr, "host_props: no GPU visible -- no CPU fallback\n"), 2;

@@ -569,9 +569,9 @@ def _props():
 
 
 def test_cpp_reference_unit_tests_host_part():
-    """pss.rs tests, utils/operator.rs:42-49, dacc_product.rs:442-448, dsumcheck.rs:591-621 -- no GPU needed"""
+    """pss.rs tests, utils/operator.rs:42-49, dacc_product.rs:442-448, dsumcheck.rs:541-588 (the shipped verifiers accept and reject), :591-621 -- no GPU needed"""
     r = subprocess.run([_props(), "host"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "0 failure(s)" in r.stdout and r.stdout.count(" ok\n") == 6, r.stdout + r.stderr
+    assert r.returncode == 0 and "0 failure(s)" in r.stdout and r.stdout.count(" ok\n") == 7, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
