@@ -181,6 +181,41 @@ def test_msm_batch_matches_individual(ctx, co):
     assert (jac_norm_to_affine(got[1]) == co.msm_g1(bases[1024:1536], sc[1024:1536])).all()
 
 
+def test_msm_batch_of_window_table_items_of_many_sizes(ctx, co):
+    """
+    the short items of a proof's passes (dpoly_comm.rs:401-464: an open commits quotients of 2^k, 2^(k-1), .. points): levels of
+    64 .. 2^15 points with the library's own table widths (two common widths up to 2^14 points), items shorter than their level and
+    at offsets, all in ONE batch -- items of one width and up to 2^14 points share a class whose rows are as long as its longest
+    item.  Same bits as the oracle, with the merged classes (default) and with a class per size / a width per size.
+    """
+    sizes = [64, 100, 128, 500, 1 << 10, 1500, 1 << 11, 3000, 1 << 12, 1 << 13, 10000, 1 << 14, 20000, 1 << 15, 1 << 12, 64, 1 << 14]
+    use = [64, 70, 128, 257, 1 << 10, 1, 1 << 11, 2999, 4000, 1 << 13, 9999, 1 << 14, 16385, 1 << 15, 1 << 12, 3, 12345]
+    off = [0, 30, 0, 100, 0, 1499, 0, 1, 96, 0, 1, 0, 3615, 0, 0, 61, 4039]
+    for knobs in ((), (("msm_size_class_min", 0), ("msm_small_table_widths", 0)), (("msm_size_class_min", 11),)):
+        for k, v in knobs:
+            ctx.dbg_tune(k, v)
+        try:
+            srs, scal, exp = [], [], []
+            for i, n in enumerate(sizes):
+                bases, _ = synthetic_bases(n, 900 + i)
+                sc = rand_fr(n, 950 + i)
+                lv = ctx.srs_register(bases).precompute(0)
+                srs.append(lv)
+                scal.append(ctx.to_device(sc).at(32 * off[i]))
+                exp.append(co.msm_g1(bases[off[i] : off[i] + use[i]], sc[off[i] : off[i] + use[i]]))
+            widths = {len(lv): lv.table_window for lv in srs}
+            if not knobs:
+                assert widths[64] == widths[1 << 10] == 12 and widths[1 << 11] == widths[1 << 14] == 14 and widths[1 << 15] == 17, widths
+            got = ctx.msm_g1_batch(srs, scal, use, offsets=off)
+            for i in range(len(sizes)):
+                assert (jac_norm_to_affine(got[i]) == exp[i]).all(), (knobs, i, sizes[i], use[i], off[i])
+            for lv in srs:
+                lv.free()
+        finally:
+            ctx.dbg_tune("msm_size_class_min", 14)
+            ctx.dbg_tune("msm_small_table_widths", 1)
+
+
 @pytest.mark.parametrize("n,c", [(1, 0), (100, 5), (5000, 0), (5000, 13), (1 << 15, 0), (1 << 15, 16)])
 def test_msm_precomputed_srs_matches_oracle(ctx, co, n, c):
     """shared-bucket mode (zk_srs_precompute): same result as the oracle, also on sub-ranges and in batches"""
