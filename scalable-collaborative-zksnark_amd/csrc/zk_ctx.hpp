@@ -108,7 +108,7 @@ struct Tuning {
     long msm_debug = 0;       // class geometry on stderr
     long msm_serial = 0;      // all classes on the ctx stream
     long msm_size_classes = 1;  // window-table items: one class per power-of-two length
-    long msm_size_class_min = 14;  // window-table items of up to 2^k points (and one table width) share one size class: fewer launch chains for the short items of a batch
+    long msm_size_class_min = 16;  // window-table items of up to 2^k points (and one table width) share one size class: fewer launch chains for the short items of a batch
     long msm_small_table_widths = 1;  // zk_srs_precompute's own pick: 12 bits up to 2^10 points, 14 bits for 2^11 .. 2^14 (0: log2 n + 2)
     long msm_share = 100;     // EXPERIMENT (profiles/r05g): percent of the resident workgroup slots k_accum_tiles may fill (persistent grid below 100)
     // SRS / PSS maps on points (zk_srs.hip)

@@ -347,7 +347,8 @@ static __global__ void __launch_bounds__(kBlk) k_digits(const ItemDesc* __restri
     const ItemDesc it = items[blockIdx.y];
     const size_t row_len = endo ? 2 * ns : ns;
     u32* digits = digits_all + (size_t)blockIdx.y * wc * row_len;
-    if (i >= it.n) {  // padding up to the (class-wide) row stride
+    if (i >= it.n) {  // padding: only up to the item's own length rounded up to 4 -- the sort never reads beyond it (struct RowReal)
+        if (i >= (((size_t)it.n + 3) & ~(size_t)3)) return;
         for (int w = 0; w < wc; w++) {
             digits[(size_t)w * row_len + i] = kSkip;
             if (endo) digits[(size_t)w * row_len + ns + i] = kSkip;
@@ -383,8 +384,20 @@ static constexpr int kSortThreads = 1024;
 static constexpr u32 kMaxParts = 1024;
 static constexpr u32 kMaxLow = 2048;  // buckets per partition (nb / np), nb <= 2^19
 
+// A row is `copies` segments of ns slots (ns = the class-wide stride: the longest item, a multiple of 4); an item of n points
+// fills the first n slots of every segment.  The sort walks a row in uint4 steps and skips the steps that lie in the padding of
+// their segment without touching memory: a class may then hold items of very different lengths (one launch chain for all
+// window-table items of one table width) at the price of idle loop iterations, not of traffic.
+struct RowReal {
+    const ItemDesc* items;
+    u32 rpi, ns;
+    // slots [4 i4, 4 i4 + 4) of `row`: n4 = the item's length rounded up to 4; pos = offset of the step inside its segment
+    __device__ __forceinline__ u32 n4(u32 row) const { return (items[row / rpi].n + 3u) & ~3u; }
+    __device__ __forceinline__ u32 pos(size_t i4) const { return (u32)((4 * i4) % ns); }
+};
+
 static __global__ void __launch_bounds__(kSortThreads) k_part_hist(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
-                                                          u32 np, int low_bits, u32* __restrict__ hist) {
+                                                          u32 np, int low_bits, u32* __restrict__ hist, RowReal rr) {
     __shared__ u32 cnt[kMaxParts];
     const u32 chunk = blockIdx.x % nchunks, row = blockIdx.x / nchunks;
     for (u32 i = threadIdx.x; i < np; i += kSortThreads) cnt[i] = 0u;
@@ -392,7 +405,13 @@ static __global__ void __launch_bounds__(kSortThreads) k_part_hist(const u32* __
     const size_t c0 = (size_t)chunk * chunk_len;                              // multiple of 4
     const size_t c1 = (c0 + chunk_len < row_len) ? c0 + chunk_len : row_len;  // row_len multiple of 4
     const uint4* row4 = reinterpret_cast<const uint4*>(digits + (size_t)row * row_len);
+    const u32 n4 = rr.n4(row), step = (u32)((4u * kSortThreads) % rr.ns);
+    u32 pos = rr.pos((c0 >> 2) + threadIdx.x);
     for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
+        const bool real = pos < n4;
+        pos += step;
+        if (pos >= rr.ns) pos -= rr.ns;
+        if (!real) continue;
         uint4 d4 = row4[i4];
         u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
@@ -449,7 +468,7 @@ static __global__ void __launch_bounds__(kScanThreads) k_part_bases(const u32* _
 static __global__ void __launch_bounds__(kSortThreads) k_part_scatter(const u32* __restrict__ digits, size_t row_len, size_t chunk_len, u32 nchunks,
                                                              u32 np, int low_bits, const u32* __restrict__ hist,
                                                              const u32* __restrict__ base, int idx_bits, u32* __restrict__ part_idx,
-                                                             unsigned short* __restrict__ part_low) {
+                                                             unsigned short* __restrict__ part_low, RowReal rr) {
     __shared__ u32 cur[kMaxParts];
     const u32 chunk = blockIdx.x % nchunks, row = blockIdx.x / nchunks;
     for (u32 p = threadIdx.x; p < np; p += kSortThreads)
@@ -461,7 +480,13 @@ static __global__ void __launch_bounds__(kSortThreads) k_part_scatter(const u32*
     u32* oi = part_idx + (size_t)row * row_len;
     unsigned short* ol = part_low + (size_t)row * row_len;
     const u32 low_mask = (1u << low_bits) - 1u;
+    const u32 n4 = rr.n4(row), step = (u32)((4u * kSortThreads) % rr.ns);
+    u32 seg = rr.pos((c0 >> 2) + threadIdx.x);
     for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
+        const bool real = seg < n4;
+        seg += step;
+        if (seg >= rr.ns) seg -= rr.ns;
+        if (!real) continue;
         uint4 d4 = row4[i4];
         u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
@@ -489,7 +514,7 @@ static constexpr u32 kStageChunk = 16384;
 static __global__ void __launch_bounds__(kSortThreads) k_part_scatter_staged(const u32* __restrict__ digits, size_t row_len, size_t chunk_len,
                                                                     u32 nchunks, u32 np, int low_bits, const u32* __restrict__ hist,
                                                                     const u32* __restrict__ base, int idx_bits,
-                                                                    u32* __restrict__ part_idx, unsigned short* __restrict__ part_low) {
+                                                                    u32* __restrict__ part_idx, unsigned short* __restrict__ part_low, RowReal rr) {
     extern __shared__ u32 sm[];
     u32* cnt = sm;                    // [kMaxParts] entries of this chunk per partition, then fill cursors
     u32* loc = cnt + kMaxParts;       // [kMaxParts] start of the partition's run inside the stage
@@ -503,7 +528,13 @@ static __global__ void __launch_bounds__(kSortThreads) k_part_scatter_staged(con
     const size_t c0 = (size_t)chunk * chunk_len;
     const size_t c1 = (c0 + chunk_len < row_len) ? c0 + chunk_len : row_len;
     const uint4* row4 = reinterpret_cast<const uint4*>(digits + (size_t)row * row_len);
+    const u32 n4 = rr.n4(row), step = (u32)((4u * kSortThreads) % rr.ns);
+    u32 seg = rr.pos((c0 >> 2) + threadIdx.x);
     for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
+        const bool real = seg < n4;
+        seg += step;
+        if (seg >= rr.ns) seg -= rr.ns;
+        if (!real) continue;
         uint4 d4 = row4[i4];
         u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
@@ -523,7 +554,12 @@ static __global__ void __launch_bounds__(kSortThreads) k_part_scatter_staged(con
     __syncthreads();
     const u32 staged = sh[0];
     const u32 low_mask = (1u << low_bits) - 1u;
+    seg = rr.pos((c0 >> 2) + threadIdx.x);
     for (size_t i4 = (c0 >> 2) + threadIdx.x; i4 < (c1 >> 2); i4 += kSortThreads) {
+        const bool real = seg < n4;
+        seg += step;
+        if (seg >= rr.ns) seg -= rr.ns;
+        if (!real) continue;
         uint4 d4 = row4[i4];
         u32 dd[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
@@ -1475,18 +1511,19 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
             u32* pbase = ptotal + cl.rows * (size_t)cl.np;
             u32* rowtot = pbase + cl.rows * (size_t)cl.np;
             const dim3 g_chunks((unsigned)(cl.nchunks * cl.rows)), g_parts((unsigned)(cl.np * cl.rows));
+            const RowReal rr{(const ItemDesc*)d_items, (u32)cl.rpi, (u32)ns};
             hipLaunchKernelGGL(k_part_hist, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, cl.np,
-                               cl.low_bits, hist);
+                               cl.low_bits, hist, rr);
             hipLaunchKernelGGL(k_part_scan, dim3((unsigned)(cl.rows * cl.np)), dim3(128), 0, st, hist, cl.nchunks, ptotal);  // <= 512 chunks per row
             hipLaunchKernelGGL(k_part_bases, dim3((unsigned)cl.rows), dim3(cl.np <= 256 ? 256 : kScanThreads), 0, st, (const u32*)ptotal, cl.np, pbase, rowtot);
             if (cl.staged_scatter) {
                 const size_t lds = (3 * (size_t)kMaxParts + kSortThreads + 2 * (size_t)kStageChunk) * 4;
                 hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL(k_part_scatter_staged, g_chunks, dim3(kSortThreads), lds, st, (const u32*)digits, cl.row_len, cl.chunk_len,
-                                   cl.nchunks, cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low);
+                                   cl.nchunks, cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low, rr);
             } else {
                 hipLaunchKernelGGL(k_part_scatter, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks,
-                                   cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low);
+                                   cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low, rr);
             }
             hipLaunchKernelGGL(k_part_sort, g_parts, dim3(cl.row_len / cl.np >= 4096 ? kSortThreads : 256), 0, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len,
                                cl.np, cl.low_bits, cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, oc, cl.T, cl.tiles_per_w, tile_b, sorted);

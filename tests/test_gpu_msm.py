@@ -191,7 +191,7 @@ def test_msm_batch_of_window_table_items_of_many_sizes(ctx, co):
     sizes = [64, 100, 128, 500, 1 << 10, 1500, 1 << 11, 3000, 1 << 12, 1 << 13, 10000, 1 << 14, 20000, 1 << 15, 1 << 12, 64, 1 << 14]
     use = [64, 70, 128, 257, 1 << 10, 1, 1 << 11, 2999, 4000, 1 << 13, 9999, 1 << 14, 16385, 1 << 15, 1 << 12, 3, 12345]
     off = [0, 30, 0, 100, 0, 1499, 0, 1, 96, 0, 1, 0, 3615, 0, 0, 61, 4039]
-    for knobs in ((), (("msm_size_class_min", 0), ("msm_small_table_widths", 0)), (("msm_size_class_min", 11),)):
+    for knobs in ((), (("msm_size_class_min", 0), ("msm_small_table_widths", 0)), (("msm_size_class_min", 11),), (("msm_size_class_min", 30),)):
         for k, v in knobs:
             ctx.dbg_tune(k, v)
         try:
@@ -212,7 +212,7 @@ def test_msm_batch_of_window_table_items_of_many_sizes(ctx, co):
             for lv in srs:
                 lv.free()
         finally:
-            ctx.dbg_tune("msm_size_class_min", 14)
+            ctx.dbg_tune("msm_size_class_min", 16)
             ctx.dbg_tune("msm_small_table_widths", 1)
 
 
