@@ -8,7 +8,7 @@
 //     threads  all 8 l parties as threads of this process, one ctx each, exchanges through host memory (LocalTestNet); the
 //              parties share the visible GPUs round-robin
 //     rccl     all 8 l parties as threads, party p on GPU p, exchanges over RCCL / xGMI inside the ctx (zk_comm_init_all);
-//              needs 8 l GPUs
+//              needs 8 l GPUs (--share-gpus: fewer, for runs against the test double tests/native/fake_rccl only)
 //     --check  SELF-CHECKING run, no Python and no oracle in the loop (zkhost/verify.hpp): one more run with the operands of every
 //              product sumcheck traced; every transcript chain (dsumcheck.rs:558-588) is pinned at both ends by values from
 //              kernels the product sumcheck does not use (every party's values for the leader's d_ chains), the c_ tails are
@@ -33,7 +33,7 @@ using namespace zkhost;
 struct Args {
     size_t l = 1, n = 12, reps = 3, table_max = 24;
     std::string mode = "leader", which = "dhyperplonk";
-    bool tables = true, digest = false, check = false, tamper = false, serial_rep = false, marks = false;
+    bool tables = true, digest = false, check = false, tamper = false, serial_rep = false, marks = false, share_gpus = false;
 };
 
 static std::atomic<int> g_failed{0};  // parties whose self-check failed
@@ -195,6 +195,7 @@ int main(int argc, char **argv) {
         else if (k == "--check") a.check = true;
         else if (k == "--serial-rep") a.serial_rep = true;
         else if (k == "--marks") a.marks = true;  // diagnostics: host time stamps of the calls inside a proof
+        else if (k == "--share-gpus") a.share_gpus = true;  // --mode rccl with fewer GPUs than parties: only the test double of librccl accepts it
         else if (k == "--tamper") a.check = a.tamper = true;
         else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
         else {
@@ -220,10 +221,12 @@ int main(int argc, char **argv) {
                 party(a, pp, be, net);
             });
         } else if (a.mode == "rccl") {
-            if ((size_t)ngpu < pp.n) throw std::invalid_argument("--mode rccl needs one GPU per party (" + std::to_string(pp.n) + "), found " + std::to_string(ngpu));
+            // (--share-gpus: the real RCCL refuses two ranks on one device; tests/native/fake_rccl -- a test double first in
+            // LD_LIBRARY_PATH -- does not, and lets the whole RCCL path of the library and of this host run on a one-GPU box)
+            if ((size_t)ngpu < pp.n && !a.share_gpus) throw std::invalid_argument("--mode rccl needs one GPU per party (" + std::to_string(pp.n) + "), found " + std::to_string(ngpu));
             std::vector<std::unique_ptr<Ctx>> ctxs;
             std::vector<zk_ctx *> raw;
-            for (size_t p = 0; p < pp.n; ++p) ctxs.push_back(std::make_unique<Ctx>((int)p)), raw.push_back(ctxs.back()->handle());
+            for (size_t p = 0; p < pp.n; ++p) ctxs.push_back(std::make_unique<Ctx>((int)(p % (size_t)ngpu))), raw.push_back(ctxs.back()->handle());
             ctxs[0]->check(zk_comm_init_all(raw.data(), (int)pp.n));
             // every party on its own host thread (the collectives block until all parties have entered them)
             LocalTestNet::simulate_network_round(pp.n, [&](size_t p, LocalTestNet &) {

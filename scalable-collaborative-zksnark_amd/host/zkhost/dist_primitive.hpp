@@ -105,6 +105,7 @@ inline G1Vec d_msm(Ctx &be, const std::vector<SrsPtr> &bases, const std::vector<
     if (auto *rn = dynamic_cast<RcclNet *>(&net); rn && rn->owns(be)) {
         // the communicator lives in the same ctx: the whole of d_msm is ONE C-ABI call
         FrVec coeffs(n, cp.to_canonical());
+        rn->account(144 * k);  // (the all-gather of the k results happens inside zk_d_msm)
         return be.d_msm(srs, scalars, lens, &lam, coeffs);
     }
     std::vector<DevPtr> scaled;

@@ -277,6 +277,8 @@ class RcclNet : public Net {
     }
     // zk_d_msm applies when the exchange of d_msm can run inside the library
     bool owns(const Ctx &be) const { return &be == &ctx_; }
+    // byte accounting of an exchange the library ran itself (zk_d_msm: one all-gather of `bytes` per party)
+    void account(size_t bytes) { count(bytes); }
 
   private:
     void same(const Ctx &be) const {

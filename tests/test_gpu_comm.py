@@ -252,20 +252,14 @@ def _party_body(ctx, net, co):
     return True
 
 
-def test_comm_init_all_one_process_party_threads(co):
-    """
-    zk_comm_init_all (the reference's one-task-per-party model, mpc-net/src/multi.rs:330-352): ONE process, a ctx per
-    visible GPU (1 on the builder's boxes, 8 on the real node), one host thread per party running the same protocol
-    primitives as the torchrun worker -- exchanges through the communicator in each ctx.
-    """
+def _init_all_world(world, devices, co):
+    """`world` parties as threads of this process, party p on devices[p], communicators from zk_comm_init_all; every party runs _party_body"""
     import threading
 
     import zkhip
     from zkhip.net import RcclNet
 
-    ndev = zkhip.lib().zk_device_count()
-    world = 8 if ndev >= 8 else (4 if ndev >= 4 else (2 if ndev >= 2 else 1))
-    ctxs = [zkhip.Ctx(d) for d in range(world)]
+    ctxs = [zkhip.Ctx(d) for d in devices]
     try:
         nets = RcclNet.from_init_all(ctxs)
         assert [c.comm_rank for c in ctxs] == list(range(world)) and all(c.comm_size == world for c in ctxs)
@@ -288,3 +282,79 @@ def test_comm_init_all_one_process_party_threads(co):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_comm_init_all_one_process_party_threads(co):
+    """
+    zk_comm_init_all (the reference's one-task-per-party model, mpc-net/src/multi.rs:330-352): ONE process, a ctx per
+    visible GPU (1 on the builder's boxes, 8 on the real node), one host thread per party running the same protocol
+    primitives as the torchrun worker -- exchanges through the communicator in each ctx.
+    """
+    import zkhip
+
+    ndev = zkhip.lib().zk_device_count()
+    world = 8 if ndev >= 8 else (4 if ndev >= 4 else (2 if ndev >= 2 else 1))
+    _init_all_world(world, list(range(world)), co)
+
+
+# ---------------------------------------------------------------------------------------
+# world size 8 on a ONE-GPU box: the library's RCCL calls against a test double of librccl.so.1 (tests/native/fake_rccl.cpp:
+# the entry points csrc/zk_comm.cpp resolves, with the real semantics, between host threads that share the GPU -- the real RCCL
+# refuses two ranks on one device).  Everything of ours around the collectives runs as on the 8-GPU node; the wire does not.
+# ---------------------------------------------------------------------------------------
+FAKE_DIR = os.path.join(ROOT, "tests", "native", "fake_rccl")
+
+
+def _fake_env():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "native"), "-s", "fake_rccl/librccl.so.1"])
+    return dict(os.environ, LD_LIBRARY_PATH=FAKE_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "scalable-collaborative-zksnark_amd")]))
+
+
+def test_world8_protocol_primitives_over_the_rccl_test_double():
+    """gather / scatter with a remote root, all-to-all, the HBM all-gather, d_sumcheck_product, a sharded MSM, the 8-party zk_d_msm and
+    its error propagation -- _party_body at world 8, eight ctxs on GPU 0, in a process of its own (no torch: its bundled RCCL must
+    not be the copy the library finds)"""
+    code = ("import sys, coracle; import test_gpu_comm as t\n"
+            "assert 'torch' not in sys.modules\n"
+            "t._init_all_world(8, [0] * 8, coracle)\n"
+            "print('WORLD8_OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1200, env=_fake_env(), cwd=os.path.join(ROOT, "tests"))
+    assert r.returncode == 0 and "WORLD8_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "[fake_rccl] the test double of librccl.so.1 is in use: 8 ranks" in r.stderr
+
+
+def _hyperplonk(args, env, timeout=1200):
+    host = os.path.join(ROOT, "scalable-collaborative-zksnark_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    return subprocess.run([os.path.join(host, "bin", "hyperplonk")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.parametrize("args,parties", [
+    (["--l", "1", "--n", "12"], 8),                             # dhyperplonk: zk_d_msm, the HBM all-gather of step 2.a, every typed exchange
+    (["--l", "1", "--n", "10", "--which", "cpermcheck"], 8),    # c_acc_product_and_share: zk_alltoall on device buffers
+    (["--l", "2", "--n", "10"], 16),                            # 16 parties
+])
+def test_cpp_host_rccl_mode_over_the_test_double_equals_thread_mode(args, parties):
+    """`hyperplonk --mode rccl` (party p = a ctx with an in-ctx communicator, zkhost::RcclNet) on ONE GPU against the test double:
+    every party's self-check passes and the transcript digest equals the one of --mode threads (exchanges through host memory)"""
+    env = _fake_env()
+    r = _hyperplonk(args + ["--mode", "rccl", "--share-gpus", "--reps", "2", "--check", "--digest"], env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert f"[fake_rccl] the test double of librccl.so.1 is in use: {parties} ranks" in r.stderr
+    checks = [l for l in r.stdout.splitlines() if l.startswith("check: party ")]
+    assert len(checks) == parties and all(" ok -- anchored" in l for l in checks), r.stdout[-3000:]
+    dig = {l.split()[-1] for l in r.stdout.splitlines() if l.startswith("transcript sha256")}
+    t = _hyperplonk(args + ["--mode", "threads", "--reps", "1", "--digest"], dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert t.returncode == 0, t.stdout[-2000:] + t.stderr[-2000:]
+    dig_t = {l.split()[-1] for l in t.stdout.splitlines() if l.startswith("transcript sha256")}
+    assert len(dig) == 1 and dig == dig_t, (dig, dig_t)
+    comm_r = {l for l in r.stdout.splitlines() if l.startswith("Comm: ")}
+    comm_t = {l for l in t.stdout.splitlines() if l.startswith("Comm: ")}
+    assert len(comm_r) == 1 and comm_r == comm_t, (comm_r, comm_t)  # the same bytes exchanged
+
+
+def test_cpp_host_rccl_mode_rejects_a_flipped_limb_on_every_party():
+    r = _hyperplonk(["--l", "1", "--n", "10", "--mode", "rccl", "--share-gpus", "--reps", "1", "--tamper"], _fake_env())
+    checks = [l for l in r.stdout.splitlines() if l.startswith("check: party ")]
+    assert r.returncode == 3 and len(checks) == 8 and all("FAILED [gate[3]]" in l for l in checks), (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
