@@ -324,6 +324,68 @@ def test_world8_protocol_primitives_over_the_rccl_test_double():
     assert "[fake_rccl] the test double of librccl.so.1 is in use: 8 ranks" in r.stderr
 
 
+_PY_PROTOCOL = r"""
+import hashlib, sys, threading
+import numpy as np
+import zkhip
+from zkhip.hyperplonk import PackedProvingParameters, cpermcheck, dhyperplonk
+from zkhip.net import LocalTestNet, RcclNet
+from zkhip.pss import PackedSharingParams
+from zkhip.field import random_fr
+assert 'torch' not in sys.modules
+n, which = int(sys.argv[1]), sys.argv[2]
+pp = PackedSharingParams(1)
+
+def digest(res):
+    h = hashlib.sha256()
+    def feed(x):
+        if isinstance(x, np.ndarray): h.update(np.ascontiguousarray(x, dtype=np.uint64).tobytes())
+        elif isinstance(x, (list, tuple)):
+            for e in x: feed(e)
+    feed(res)
+    return h.hexdigest()
+
+def party(ctx, net):
+    pk = PackedProvingParameters.new_splitmix(n, pp, ctx, seed=100 + net.party_id, chal_seed=4242)
+    if which == 'cpermcheck':
+        res = cpermcheck(n, pk, pp, ctx, net, seed=3 + net.party_id)[0]  # (the masks are drawn from `seed` on first use)
+    else:
+        res = dhyperplonk(n, pk, pp, ctx, net, seed=7 + net.party_id)[0]
+    return digest(res), (net.upload, net.download)
+
+def over(nets_of):
+    ctxs = [zkhip.Ctx(0) for _ in range(8)]
+    nets = nets_of(ctxs)
+    out, errs = [None] * 8, []
+    def run(p):
+        try: out[p] = party(ctxs[p], nets[p])
+        except BaseException as e: errs.append((p, repr(e)))
+    th = [threading.Thread(target=run, args=(p,)) for p in range(8)]
+    [t.start() for t in th]; [t.join(900) for t in th]
+    assert not errs and not any(t.is_alive() for t in th), errs
+    for c in ctxs: c.close()
+    return out
+
+a = over(RcclNet.from_init_all)
+from zkhip.net import _LocalHub
+lh = _LocalHub(8)
+b = over(lambda ctxs: [LocalTestNet(lh, p) for p in range(8)])
+assert [x[0] for x in a] == [x[0] for x in b], 'transcripts over RcclNet differ from the thread net'
+assert a[0][1] == b[0][1], ('bytes', a[0][1], b[0][1])
+print('PY_WORLD8_OK', a[0][0][:16], a[0][1])
+"""
+
+
+@pytest.mark.parametrize("n,which", [(10, "dhyperplonk"), (9, "cpermcheck")])
+def test_python_host_protocol_over_the_rccl_test_double_equals_thread_net(n, which):
+    """the Python host's drivers with zkhip.net.RcclNet (zk_comm_init_all, eight ctxs on GPU 0) against the test double: every party's
+    transcript and the leader's byte counters equal the run over LocalTestNet -- zk_d_msm, zk_allgather (HBM), zk_alltoall (the
+    device-resident c_acc_product_and_share) at world 8"""
+    r = subprocess.run([sys.executable, "-c", _PY_PROTOCOL, str(n), which], capture_output=True, text=True, timeout=1500, env=_fake_env(), cwd=os.path.join(ROOT, "tests"))
+    assert r.returncode == 0 and "PY_WORLD8_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "[fake_rccl] the test double of librccl.so.1 is in use: 8 ranks" in r.stderr
+
+
 def _hyperplonk(args, env, timeout=1200):
     host = os.path.join(ROOT, "scalable-collaborative-zksnark_amd", "host")
     subprocess.check_call(["make", "-C", host, "-s"])

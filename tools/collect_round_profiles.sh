@@ -17,6 +17,9 @@ for n in 12 16 20; do python tools/hyperplonk_bench.py --n $n --party-threads | 
   for n in 12 16 20 24; do echo "== hyperplonk --l 1 --n $n --reps 4 --check --serial-rep (leader)"; $B --l 1 --n $n --reps 4 --check --serial-rep | tail -14; done
   for n in 12 16 20; do echo "== hyperplonk --l 1 --n $n --mode threads --reps 3 --check (8 party threads, ONE GPU does the work of eight)"; $B --l 1 --n $n --mode threads --reps 3 --check | tail -15; done
   echo "== hyperplonk --l 2 --n 16 --which cpermcheck --reps 3 --check (leader)"; $B --l 2 --n 16 --which cpermcheck --reps 3 --check | tail -4
+  make -C tests/native -s fake_rccl/librccl.so.1
+  echo "== hyperplonk --l 1 --n 20 --mode rccl --share-gpus --reps 2 --check over the TEST DOUBLE of librccl (tests/native/fake_rccl.cpp: 8 ranks = 8 threads sharing the GPU; no wire)"
+  LD_LIBRARY_PATH=tests/native/fake_rccl:${LD_LIBRARY_PATH:-} $B --l 1 --n 20 --mode rccl --share-gpus --reps 2 --check 2>&1 | grep -E "fake_rccl|Distributed HyperPlonk|Comm|check:"
   echo "== hyperplonk --l 1 --n 12 --reps 1 --tamper (must fail: exit code 3)"; $B --l 1 --n 12 --reps 1 --tamper > /tmp/tamper.out 2>&1; RC=$?; tail -2 /tmp/tamper.out; echo "exit code $RC"
 } > gpurun_out/${T}_e2e_cpp_host.txt 2>&1
 tools/profile_timeline.sh $T 20 5 > /dev/null 2>&1
