@@ -12,7 +12,7 @@ STRESS_SEED=7072 STRESS_TABLE=1 python tools/stress_msm.py $S | tail -1
 STRESS_SEED=7073 python tools/stress_sumcheck.py $S | tail -1
 echo "== 300 consecutive n = 20 proofs, leader mode: one digest, steady time"
 $H --l 1 --n 20 --reps 300 --digest --check > /tmp/soak_leader.txt 2>&1; echo "exit code $?"
-grep -c "transcript sha256" /tmp/soak_leader.txt; grep "transcript sha256" /tmp/soak_leader.txt | sort | uniq -c; grep "Distributed HyperPlonk" /tmp/soak_leader.txt | awk '{print $(NF-1)}' | sort -n | awk '{a[NR]=$1} END {print "proof s: min", a[1], "median", a[int(NR/2)], "p99", a[int(NR*0.99)], "max", a[NR]}'; grep "check:" /tmp/soak_leader.txt
+grep -c "transcript sha256" /tmp/soak_leader.txt; grep "transcript sha256" /tmp/soak_leader.txt | sort | uniq -c; grep "End: Distributed HyperPlonk" /tmp/soak_leader.txt | awk '{print $(NF-1)}' | sort -n | awk '{a[NR]=$1} END {print "proof s: min", a[1], "median", a[int(NR/2)], "p99", a[int(NR*0.99)], "max", a[NR]}'; grep "check:" /tmp/soak_leader.txt
 echo "== 25 runs of the 8-party protocol, n = 16, party threads, every party self-checked"
 ok=0; for i in $(seq 25); do $H --l 1 --n 16 --mode threads --reps 2 --check --digest > /tmp/soak_t.txt 2>&1; rc=$?; c=$(grep -c " ok -- anchored" /tmp/soak_t.txt); d=$(grep "transcript sha256" /tmp/soak_t.txt | sort -u | wc -l); [ $rc -eq 0 ] && [ $c -eq 8 ] && [ $d -eq 1 ] && ok=$((ok+1)) || { echo "run $i: rc=$rc checks=$c digests=$d"; tail -3 /tmp/soak_t.txt; }; done; echo "$ok of 25 runs clean"
 echo "== 15 runs of the 8-party protocol over the RCCL test double (zkhost::RcclNet, zk_d_msm, zk_allgather), n = 16"
