@@ -88,6 +88,7 @@ struct ScRequest {
     DevPtr f, g;
     size_t len;
     FrVec chal;  // the rounds' challenges (Plain / Product / Open: log2 len of them; Fold: any number)
+    DevPtr out;  // optional: the output buffer of a Fold / Open request (allocated by the batch when empty)
 };
 struct ScResult {
     FrVec sums;       // Plain: 2 log2(len); Product: 3 log2(len)
@@ -236,9 +237,9 @@ class Ctx {
                 res[i].sums.resize((q.kind == ScRequest::Plain ? 2 : 3) * n);
                 it.h_sums = n ? res[i].sums[0].v : nullptr;
             } else if (q.kind == ScRequest::Fold) {
-                res[i].out = alloc_fr(q.len >> std::min(n, q.chal.size()));
+                res[i].out = q.out ? q.out : alloc_fr(q.len >> std::min(n, q.chal.size()));
             } else {
-                res[i].out = alloc_fr(q.len - 1);
+                res[i].out = q.out ? q.out : alloc_fr(q.len - 1);
             }
             it.h_last_f = res[i].last_f.v, it.h_last_g = res[i].last_g.v, it.d_out = res[i].out.get();
         }

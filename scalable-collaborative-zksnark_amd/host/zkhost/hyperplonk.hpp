@@ -6,6 +6,7 @@
 // keep the reference's positions, the timers keep its labels (only the total is comparable once steps overlap).
 #pragma once
 #include <chrono>
+#include <cstdlib>
 #include <map>
 #include <string>
 
@@ -246,6 +247,88 @@ inline std::function<void(Transcript &)> wiring_enqueue(size_t n, const PackedPr
         }
     };
 }
+
+// The same step with ALL its sumcheck-family kernels in the caller's batch (pipeline.hpp, ScQueue): phase A enqueues -- the
+// exchanges that need no kernel result (2.a, the roots of the product tree) happen here --, the caller runs the batch, phase B
+// (the returned function) performs the exchanges that need one and returns the finishing closure of wiring_enqueue.
+inline AfterBatch<std::function<void(Transcript &)>> wiring_enqueue_sq(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net,
+                                                                       MsmQueue &q, ScQueue &sq, bool data_parallel, Timers *tm = nullptr) {
+    auto mark = [tm](const char *w) {
+        if (tm) tm->mark(w);
+    };
+    size_t l = pp.l, np = net.n_parties, M = size_t(1) << n, sbits = log2_floor(np);
+    const PowersOfG &cc = pk.c_commitment, &dc = pk.d_commitment;
+    const DevPtr &local_s_p = pk.T("local_s_p"), &local_s_l = pk.T("local_s_l");
+    mark("wiring: begin");
+    DevPtr s_dev = data_parallel ? pk.T("s_data_parallel") : net.all_gather_device(be, local_s_l, 32 * (4 * M / np / l));  // 2.a
+    auto a_2c = c_sumcheck_product_many_sq(be, sq, {{s_dev, pk.T("V")}}, 4 * M / l, pk.challenge_r1, pp, net);              // 2.c
+    auto a_copen = c_open_many_sq(be, sq, q, cc, {pk.T("V"), pk.T("V")}, {4 * M / l, 4 * M / l}, {pk.challenge_r1, pk.challenge_r2}, pp, net);  // 2.d
+    size_t hlen = 4 * M / np;  // 2.e (:322-340)
+    DevPtr num = be.fr_axpb(local_s_p, pk.T("sid_p"), pk.alpha, pk.beta, hlen);
+    DevPtr den = be.fr_axpb(pk.T("eq_r1_p"), pk.T("ssigma_p"), pk.alpha, pk.beta, hlen);
+    DevPtr h_p = be.fr_batch_div(num, den, hlen);
+    auto [sub, top] = d_acc_product(be, h_p, hlen, net);  // :342
+    mark("2.e product tree done");
+    q.keep.push_back(sub.tree);
+    DevPtr v1x = sub.tree.fr(hlen);
+    auto [vx0, vx1] = be.fr_deinterleave(sub.tree, hlen);  // :344-359
+    std::vector<DevPtr> com_tabs = {local_s_p, pk.T("ssigma_p"), pk.T("sid_p"), h_p, num, den, v1x, vx0, vx1};
+    auto f_dcommit = d_commit_many_q(be, q, dc, com_tabs, std::vector<size_t>(9, hlen), net);  // 2.b, then :363-380
+    std::vector<DevPtr> lay_tabs(com_tabs.begin(), com_tabs.begin() + 6);                      // 2.d, then :383-407
+    std::vector<size_t> lay_lens(6, hlen);
+    std::vector<FrVec> lay_pts(6, pk.challenge_r2);
+    std::vector<DsumcheckItem> dsp = {{den, pk.T("eq_r2_p"), hlen, pk.challenge_r2}, {h_p, den, hlen, pk.challenge_r2}, {num, pk.T("eq_r2_p"), hlen, pk.challenge_r2}};  // :411-413
+    DevPtr cur[4] = {v1x, vx0, vx1, pk.T("eq_r2_p")};
+    size_t clen = hlen / 2;
+    for (size_t i = 1; i + sbits <= n; ++i) {  // 2.e.2 layered sumcheck + opens on halving slices (:417-478)
+        FrVec ch(pk.challenge_r2.begin() + i, pk.challenge_r2.end());
+        dsp.push_back({cur[3], cur[0], clen, ch}), dsp.push_back({cur[3], cur[1], clen, ch}), dsp.push_back({cur[1], cur[2], clen, ch});
+        for (int k = 0; k < 3; ++k) lay_tabs.push_back(cur[k]), lay_lens.push_back(clen), lay_pts.push_back(ch);
+        for (auto &c : cur) c = c.fr(clen / 2);
+        clen /= 2;
+    }
+    auto f_dsp = d_sumcheck_product_many_sq(be, sq, dsp, net);
+    auto a_dopen = d_open_many_sq(be, sq, q, dc, lay_tabs, lay_lens, lay_pts, net);
+    // leader-only tail on the N_p-leaf top tree (:480-511)
+    auto top_commits = std::make_shared<std::vector<std::function<G1()>>>();
+    auto top_opens = std::make_shared<OpensInFlight>();
+    auto top_proofs = std::make_shared<std::vector<AfterBatch<std::vector<Triple>>>>();
+    bool has_top = top.has_value();
+    if (has_top) {
+        const FrVec &tt = *top;
+        size_t half = tt.size() / 2;
+        FrVec lv1x(tt.begin() + half, tt.end()), lvx0, lvx1;
+        for (size_t i = 0; i < tt.size(); ++i) (i % 2 ? lvx1 : lvx0).push_back(tt[i]);
+        FrVec chs(pk.challenge_r2.begin(), pk.challenge_r2.begin() + sbits);
+        DevPtr d0 = be.to_device(lvx0), dd1 = be.to_device(lvx1), d1 = be.to_device(lv1x);
+        for (auto &d : {d0, dd1, d1}) top_commits->push_back(commit_q(q, dc, d, half)), q.keep.push_back(d);
+        *top_opens = open_many_sq(sq, q, dc, {d0, dd1, d1}, {half, half, half}, {chs, chs, chs});
+        top_proofs->push_back(sumcheck_product_sq(be, sq, pk.T("eq_top"), d1, half, chs));
+        top_proofs->push_back(sumcheck_product_sq(be, sq, pk.T("eq_top"), d0, half, chs));
+        top_proofs->push_back(sumcheck_product_sq(be, sq, d0, dd1, half, chs));
+    }
+    mark("wiring: everything enqueued");
+    return [a_2c, a_copen, a_dopen, f_dsp, f_dcommit, top_commits, top_opens, top_proofs, has_top]() -> std::function<void(Transcript &)> {
+        auto p2c = std::make_shared<std::vector<std::vector<Triple>>>(a_2c());  // pss2ss of 2.c
+        auto f_copen = a_copen();                                              // pss2ss of the two opens of V
+        auto f_dopen = a_dopen();                                              // the local open values, the leader's root opens
+        return [p2c, f_dsp, f_copen, f_dcommit, f_dopen, top_commits, top_opens, top_proofs, has_top](Transcript &out) {
+            out.wiring_proofs = *p2c;
+            for (auto &p : f_dsp()) out.wiring_proofs.push_back(p);
+            out.wiring_opens = f_copen();
+            out.wiring_commits = f_dcommit();
+            for (auto &o : f_dopen()) out.wiring_opens.push_back(o);
+            if (has_top) {
+                std::vector<Opening> to = top_opens->finish();
+                for (size_t i = 0; i < 3; ++i) {
+                    out.wiring_commits.push_back((*top_commits)[i]());
+                    out.wiring_opens.push_back(to[i]);
+                }
+                for (auto &p : *top_proofs) out.wiring_proofs.push_back(p());
+            }
+        };
+    };
+}
 }  // namespace detail
 
 // dhyperplonk.rs:159-571 (data_parallel: dhyperplonk_data_parallel :573-960, which differs only at step 2.a -- `s` is local
@@ -279,14 +362,68 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     };
     std::vector<FrVec> pts3(3, pk.challenge);
     std::vector<Opening> ops;
+    static const bool late_commit = [] {  // EXPERIMENT: the commit pass is started together with the two long passes
+        const char *e = std::getenv("ZKHOST_LATE_COMMIT");
+        return e && std::atoi(e) != 0;
+    }();
     if (serial_steps) {
         q.run();
         collect_commit();
-    } else {
+    } else if (!late_commit) {
         q.start();
     }
     tm.mark("commit pass started");
     tm.end();
+
+    static const bool one_batch = [] {  // the sumcheck-family kernels of steps 2-4 as ONE batch (pipeline.hpp ScQueue); ZKHOST_ONE_BATCH=0: a batch per call
+        const char *e = std::getenv("ZKHOST_ONE_BATCH");
+        return !e || std::atoi(e) != 0;
+    }();
+    if (one_batch && !serial_steps) {
+        ScQueue sq(be);
+        MsmQueue q_w(be), q_o(be);
+        tm.start("Gate identity");
+        DevPtr sum_ab = be.fr_add(pk.T("a_evals"), pk.T("b_evals"), Ml);  // :233-238
+        DevPtr sum_ci = be.fr_sub(pk.T("I"), pk.T("c_evals"), Ml);        // -c + I  :251-256
+        auto a_gate = c_sumcheck_product_many_sq(be, sq, {{pk.T("eq"), pk.T("S1")}, {pk.T("S1"), sum_ab}, {pk.T("eq"), pk.T("S2")}, {pk.T("a_evals"), pk.T("b_evals")},
+                                                          {pk.T("S2"), pk.T("a_evals")}, {pk.T("eq"), sum_ci}}, Ml, pk.challenge, pp, net);
+        tm.end();
+        tm.start("Wire identity");
+        auto b_wiring = detail::wiring_enqueue_sq(n, pk, pp, be, net, q_w, sq, data_parallel, &tm);
+        auto a_co = c_open_many_sq(be, sq, q_o, cc, tc, lc, pts3, pp, net);  // the kernel phase of step 4 (:517-553) rides in the same batch
+        auto a_do = d_open_many_sq(be, sq, q_o, dc, td, ld, pts3, net);
+        sq.run();
+        tm.mark("the batch ran");
+        out.gate_proofs = a_gate();
+        auto finalize_wiring = b_wiring();
+        auto f_co = a_co();
+        auto f_do = a_do();
+        tm.mark("hand-offs done");
+        if (late_commit) q.start();
+        q_w.start();
+        tm.mark("wiring pass started");
+        q_o.start();
+        tm.mark("open pass started");
+        q.finish();
+        collect_commit();
+        tm.mark("commit pass collected");
+        tm.end();
+        tm.start("Open");
+        q_w.finish();
+        tm.mark("wiring pass finished");
+        finalize_wiring(out);
+        tm.mark("wiring finalized");
+        q_o.finish();
+        tm.mark("open pass finished");
+        ops = f_co();
+        std::vector<Opening> ops_d = f_do();
+        ops.insert(ops.end(), ops_d.begin(), ops_d.end());
+        tm.end();
+        for (size_t i = 0; i < 6; ++i) out.gate_commitments.push_back({com[i], ops[i]});
+        tm.end();
+        if (tm_out) *tm_out = tm;
+        return out;
+    }
 
     // Step 3: gate identity (:223-260): the six sumchecks are independent -- one batched phase 1, then the hand-offs in order
     tm.start("Gate identity");
@@ -323,6 +460,7 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
         auto f_co = c_open_many_q(be, q_o, cc, tc, lc, pts3, pp, net);
         auto f_do = d_open_many_q(be, q_o, dc, td, ld, pts3, net);
         tm.mark("open-step kernels done");
+        if (late_commit) q.start();
         q_w.start();
         tm.mark("wiring pass started");
         q_o.start();
@@ -358,7 +496,10 @@ inline Transcript dpermcheck(size_t n, const PackedProvingParameters &pk, const 
     net.sync();
     tm.start("Distributed Permcheck");
     MsmQueue q(be);
-    auto fin = detail::wiring_enqueue(n, pk, pp, be, net, q, false);
+    ScQueue sq(be);  // the step's sumcheck-family kernels as one batch (pipeline.hpp)
+    auto after = detail::wiring_enqueue_sq(n, pk, pp, be, net, q, sq, false);
+    sq.run();
+    auto fin = after();
     q.run();
     fin(out);
     tm.end();
