@@ -18,6 +18,7 @@
 //              party fails.  --tamper flips that limb in the transcript under test instead (the run must then FAIL: exit 3).
 //     --serial-rep  after the timed repetitions, one more proof with every MSM pass run to completion inside the step that owns
 //              it (`End(serial):` lines): the per-step timers of the timed repetitions are OVERLAPPED sections
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -140,12 +141,15 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
         if (!zk_mem_info(be.handle(), &fr, &tot)) std::printf("setup %.3f s; HBM after setup: %.1f GiB free of %.1f GiB\n", setup, fr / 1073741824.0, tot / 1073741824.0);
     }
     std::vector<std::string> digests;
+    std::vector<double> totals;
     for (size_t r = 0; r < a.reps; ++r) {
         Timers tm;
         tm.keep_marks = a.marks;
         uint64_t up0 = net.upload, down0 = net.download;
         Transcript t = run_once(a, pk, pp, be, net, tm);
         if (a.check) digests.push_back(transcript_digest(t));
+        for (auto &kv : tm.t)
+            if (kv.first.rfind("Distributed", 0) == 0 || kv.first.rfind("Collaborative", 0) == 0) totals.push_back(kv.second);
         if (net.is_leader()) {
             std::printf("rep %zu (setup %.3f s): proofs %zu + %zu, commitments %zu + %zu, openings %zu\n", r, setup, t.gate_proofs.size(), t.wiring_proofs.size(),
                         t.gate_commitments.size(), t.wiring_commits.size(), t.wiring_opens.size());
@@ -154,6 +158,12 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
             if (a.digest) std::printf("transcript sha256 %s\n", transcript_digest(t).c_str());
             for (auto &m : tm.marks) std::printf("  mark %9.3f ms  %s\n", m.second * 1e3, m.first.c_str());
         }
+    }
+    if (net.is_leader() && totals.size() >= 3) {
+        // (the first proof of a process also sizes the library's arenas: left out)
+        std::vector<double> v(totals.begin() + 1, totals.end());
+        std::sort(v.begin(), v.end());
+        std::printf("proofs after the first: min %.6f  median %.6f  max %.6f s over %zu\n", v.front(), v[v.size() / 2], v.back(), v.size());
     }
     if (net.is_leader() && a.reps && (a.which == "dhyperplonk" || a.which == "data-parallel"))
         std::printf("note: 'Commit' / 'Wire identity' / 'Open' above are OVERLAPPED sections (a step's MSM pass is started asynchronously and collected later; the Open step's "

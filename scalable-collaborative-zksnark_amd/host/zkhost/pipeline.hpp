@@ -542,14 +542,45 @@ inline AfterBatch<std::function<std::vector<Opening>()>> d_open_many_sq(Ctx &be,
         std::vector<FrVec> vals = net.all_gather_fr(mine);  // [party][k]
         auto root = std::make_shared<OpensInFlight>();
         if (net.is_leader()) {
-            FrVec tab;  // [k][party]
-            for (size_t i = 0; i < k; ++i)
-                for (size_t p = 0; p < np; ++p) tab.push_back(vals[p][i]);
-            DevPtr d = be.to_device(tab);
-            std::vector<DevPtr> roots;
-            for (size_t i = 0; i < k; ++i) roots.push_back(d.fr(np * i));
-            *root = open_many_q(be, q, pg, roots, std::vector<size_t>(k, np), lo);
-            q.keep.push_back(d);
+            // the root opens (dpoly_comm.rs:372-378: `open` of the N_p gathered values) are tables of 8 l elements: their fold rounds run
+            // here on the host -- the same q = hi - lo, lo + r (hi - lo) -- and only the quotients go to the device for their commitments
+            // (as a batch of their own the k of them were a blocking launch chain of ~0.3 ms)
+            FrVec qall;
+            auto rvals = std::make_shared<std::vector<Fr>>(k);
+            for (size_t i = 0; i < k; ++i) {
+                FrVec cur;
+                for (size_t p = 0; p < np; ++p) cur.push_back(vals[p][i]);
+                for (size_t r = 0; cur.size() > 1; ++r) {
+                    size_t h = cur.size() / 2;
+                    FrVec nx(h);
+                    for (size_t j = 0; j < h; ++j) {
+                        Fr d = cur[j + h] - cur[j];
+                        qall.push_back(d);
+                        nx[j] = cur[j] + lo[i].at(r) * d;
+                    }
+                    cur = nx;
+                }
+                (*rvals)[i] = cur[0];
+            }
+            auto rcuts = std::make_shared<std::vector<std::vector<size_t>>>();
+            if (np > 1) {
+                DevPtr dq = be.to_device(qall);  // [k][N_p - 1]
+                q.keep.push_back(dq);
+                for (size_t i = 0; i < k; ++i) {
+                    std::vector<SrsPtr> srs;
+                    std::vector<DevPtr> bufs;
+                    std::vector<size_t> ls;
+                    detail::open_items(pg, dq.fr((np - 1) * i), np, 1, srs, bufs, ls);
+                    rcuts->push_back(q.add(srs, bufs, ls));
+                }
+            } else {
+                rcuts->assign(k, {});
+            }
+            root->finish = [rpass = q.ticket(), rcuts, rvals, k] {
+                std::vector<Opening> res;
+                for (size_t i = 0; i < k; ++i) res.push_back({(*rvals)[i], detail::pick(rpass, (*rcuts)[i])});
+                return res;
+            };
         }
         return [&be, &net, spass, mpass, idx, cuts, root, k, np] {
             G1Vec flat;
