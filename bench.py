@@ -62,14 +62,16 @@ def transcript_sha256(res) -> str:
     return hashlib.sha256(b(*gp) + b"".join(b(c, v, prf) for c, (v, prf) in gc) + b(*wp) + b(*wc) + b"".join(b(v, prf) for v, prf in wo)).hexdigest()
 
 
-def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = False, serial_rep: bool = False, timeout: int = 900):
+def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = False, serial_rep: bool = False, timeout: int = 900, mode: str = "leader",
+                 share_gpus: bool = False, env: dict = None):
     """
     The same proof driven by the COMPILED host (scalable-collaborative-zksnark_amd/host: zkhost/hyperplonk.hpp, the C++ mirror of the
     reference's Rust crates above the C ABI) in its own process: leader mode, the SplitMix64 parameter set of the e2e leg (seed 100,
     challenges 4242), best of `reps`.  Self-checks: (want_digest) its transcript digest must equal the digest of the Python driver's
     transcript on the same parameter set -- the run the anchored check of the e2e leg has just verified; (check) the host's own
     anchored verifier (`--check`, zkhost/verify.hpp: no Python, no oracle in the loop) must print `ok`.  A figure that fails either
-    is withdrawn.
+    is withdrawn.  mode = "rccl": ONE process, party p on GPU p, exchanges over RCCL (zk_comm_init_all) -- the 8-GPU form of the same
+    binary; every party must print its own `ok` (share_gpus: only the test double of librccl accepts several ranks per device).
     """
     import subprocess
 
@@ -78,8 +80,10 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = F
         return {"error": "host/bin/hyperplonk is not built (__graft_entry__.build())"}
     try:
         cmd = [exe, "--l", "1", "--n", str(n), "--reps", str(reps), "--digest"] + (["--check"] if check else []) + (["--serial-rep"] if serial_rep else [])
+        cmd += (["--mode", mode] if mode != "leader" else []) + (["--share-gpus"] if share_gpus else [])
+        parties = 1 if mode == "leader" else 8
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": f"rc {r.returncode}: {(r.stdout[-400:] + r.stderr[-300:])}"}
@@ -106,12 +110,15 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = F
                               "the Open step runs inside 'Wire identity'): they are not the reference's phases of the same name, only 'Distributed HyperPlonk' is comparable. "
                               "timers_s_serial_steps (when present) runs every pass to completion inside its own step",
                "first_proof_note": "the first proof of a process also allocates the library's MSM arenas and job lanes (sized by demand); later proofs reuse them",
-               "what": "the same call sequence on the same parameter set from the compiled C++ host (zkhost/hyperplonk.hpp) in its own process, leader mode"}
+               "what": "the same call sequence on the same parameter set from the compiled C++ host (zkhost/hyperplonk.hpp) in its own process, "
+                       + ("leader mode" if mode == "leader" else f"--mode {mode}: 8 parties = 8 host threads of one process, party p on GPU p, exchanges over RCCL")}
+        if mode != "leader":
+            out["stderr_tail"] = r.stderr[-300:]
         if serial:
             out["timers_s_serial_steps"] = serial
         if check:
-            ok = len(checks) == 1 and " ok -- anchored" in checks[0] and "flipped limb rejected" in checks[0] and len(digests) == 1
-            out["self_check"] = checks[0] if checks else "no check line"
+            ok = len(checks) == parties and all(" ok -- anchored" in c and "flipped limb rejected" in c for c in checks) and len(digests) == 1
+            out["self_check"] = (sorted(checks)[0] if parties == 1 else sorted(checks)) if checks else "no check line"
             out["self_check_ok"] = ok
             out["transcript_check_kind"] = "anchored by the compiled host itself (hyperplonk --check): every chain pinned at both ends by independent kernels, c_ tails and sampled commits / opens recomputed, flipped limb rejected"
             if not ok:
@@ -812,7 +819,7 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 bad_all = [f"party {p}: {b}" for p, bs in enumerate(grp.all_gather_obj(bad)) for b in bs] if world == 8 else bad
                 ref_count = {12: 97227, 20: 24903603, 24: 398458791}.get(e_n)  # SURVEY.md 8(d), derived from dhyperplonk.rs:198-553
                 computed = (ref_count - (1 << (e_n + 1))) if ref_count else None
-                e_digest = transcript_sha256(res) if world == 1 else None
+                e_digest = transcript_sha256(res) if rank == 0 else None  # (world 8: the leader's transcript)
                 extra["e2e"] = {"n": e_n, "l": 1, "parties": 8, "parameter_set": "SplitMix64 tables (seed 100 + party), challenges 4242", "transcript_sha256": e_digest, "mode": "leader (party 0's full work, no-comm echo net)" if world == 1 else f"8 parties = 8 ranks, exchanges: {type(e_net).__name__} ({backend})",
                                 "setup_s": setup_s, "timers_s": best,
                                 "timers_note": "the MSM pass of a step is started asynchronously and collected later (MsmQueue.start / finish); the kernel phase of the Open step runs before the wiring "
@@ -848,6 +855,28 @@ def run_rank(args, grp, gpu: int, ctx, net):
                         extra["e2e"]["msm_mix_efficiency"] = {"proof_scalar_muls_per_s": comp / cand[best_host], "single_2p20_msm_scalar_muls_per_s": out["value"],
                                                               "ratio": comp / cand[best_host] / out["value"],
                                                               "note": "scalar-muls the proof computes / its wall time (sumchecks, exchanges and host arithmetic included), over the headline rate"}
+
+        # ---- N = 8: the same proofs from the COMPILED host over RCCL (BASELINE configs[3] and configs[4]) ----
+        # hyperplonk --mode rccl is ONE process that drives all 8 GPUs (zk_comm_init_all, a host thread per party): rank 0 starts it
+        # while the ranks of this bench wait at a barrier with their arenas trimmed.  Every party checks its own transcripts
+        # (zkhost/verify.hpp) and the digest must equal the Python host's over the same nets.  ZK_BENCH_CPP_RCCL=share runs the
+        # leg with --share-gpus on a box with fewer GPUs (functional: only the test double of librccl accepts that).
+        cpp_rccl = os.environ.get("ZK_BENCH_CPP_RCCL", "auto")
+        if world == 8 and not args.no_e2e and cpp_rccl != "0" and (backend in ("nccl", "rccl") or cpp_rccl == "share"):
+            try:
+                barrier()
+                if rank == 0:
+                    leg = {}
+                    for e_n in ((args.e2e_n,) if (args.no_e2e_n24 or cpp_rccl == "share") else (args.e2e_n, 24)):
+                        py = extra.get("e2e") or {}
+                        leg[f"n{e_n}"] = cpp_host_e2e(e_n, reps=3 if e_n <= 20 else 2, check=True, mode="rccl", share_gpus=cpp_rccl == "share", timeout=900,
+                                                      want_digest=py.get("transcript_sha256") if (e_n == py.get("n") and py.get("transcript_checks") == "ok") else None)
+                    leg["note"] = ("'Distributed HyperPlonk' of timers_s is the leader's wall time of one proof with all 8 parties running; "
+                                   "self_check lists every party's verdict; a run whose check fails has timers_s = null")
+                    extra["e2e_cpp_rccl"] = leg
+                barrier()
+            except Exception as ex:
+                extra["e2e_cpp_rccl"] = {"error": repr(ex)}
 
         # ---- G2: `d_msm` is generic over CurveGroup (dmsm.rs:9), powers_of_g2 are G2 points (dpoly_comm.rs:27,59-62) ----
         if world == 1:

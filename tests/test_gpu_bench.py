@@ -65,6 +65,24 @@ def test_gpus_8_party_threads_with_anchored_e2e():
     assert e2e["timers_s"]["Distributed HyperPlonk"] > 0 and e2e["timers_s_serial_steps"]["Distributed HyperPlonk"] > 0
 
 
+def test_gpus_8_line_carries_the_compiled_hosts_rccl_mode_proof():
+    """the N = 8 line's e2e_cpp_rccl leg: rank 0 starts `hyperplonk --mode rccl --check` (ONE process for all 8 parties) while the bench's
+    own ranks wait; here over the test double of librccl (--share-gpus), on the node over the real one.  Every party's verdict is in
+    the line and the digest equals the Python host's 8-party run"""
+    fake = os.path.join(ROOT, "tests", "native", "fake_rccl")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "native"), "-s", "fake_rccl/librccl.so.1"])
+    r, line = _bench("--gpus", "8", "--party-threads", "--steps", "2", "--warmup", "1", "--no-cpu", "--log2n", "12", "--big", "14", "--e2e-n", "12",
+                     env={"ZK_BENCH_BACKEND": "local", "ZK_BENCH_CPP_RCCL": "share", "LD_LIBRARY_PATH": fake + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    leg = line["e2e_cpp_rccl"]
+    assert "error" not in leg and set(leg) == {"n12", "note"}, leg
+    c = leg["n12"]
+    assert "error" not in c, c
+    assert c["self_check_ok"] is True and len(c["self_check"]) == 8 and all(" ok -- anchored" in v for v in c["self_check"])
+    assert c["transcript_equals_python_host"] is True and c["transcript_sha256"] == [line["e2e"]["transcript_sha256"]]
+    assert 0 < c["timers_s"]["Distributed HyperPlonk"] < 5 and "fake_rccl" in c["stderr_tail"]
+
+
 def test_single_gpu_line_has_the_record_fields():
     r, line = _bench("--steps", "3", "--warmup", "1", "--no-cpu", "--big", "22", "--e2e-n", "12", timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
