@@ -14,7 +14,10 @@ for n in 12 16 20; do python tools/hyperplonk_bench.py --n $n --party-threads | 
 # the same proofs from the compiled C++ host (host/examples/hyperplonk.cpp): leader mode n = 12 .. 24, 8 party threads on the one GPU, cpermcheck
 { B=scalable-collaborative-zksnark_amd/host/bin/hyperplonk
   # (--check: every run verified by the compiled host itself, zkhost/verify.hpp; --serial-rep: per-step timers with every pass inside its step)
-  for n in 12 16 20 24; do echo "== hyperplonk --l 1 --n $n --reps 4 --check --serial-rep (leader)"; $B --l 1 --n $n --reps 4 --check --serial-rep | tail -14; done
+  for n in 12 16 20 24; do echo "== hyperplonk --l 1 --n $n --reps 4 --check --serial-rep (leader)"; $B --l 1 --n $n --reps 4 --check --serial-rep | tail -15; done
+  # (back-to-back proofs without the digests of --check between them: the steady-state figure)
+  for n in 12 16 20 24; do echo -n "== hyperplonk --l 1 --n $n --reps $((n < 24 ? 25 : 5)) (leader): "; $B --l 1 --n $n --reps $((n < 24 ? 25 : 5)) | grep "proofs after"; done
+  for l in 2 8; do echo -n "== hyperplonk --l $l --n 20 --reps 13 (leader): "; $B --l $l --n 20 --reps 13 | grep "proofs after"; done
   for n in 12 16 20; do echo "== hyperplonk --l 1 --n $n --mode threads --reps 3 --check (8 party threads, ONE GPU does the work of eight)"; $B --l 1 --n $n --mode threads --reps 3 --check | tail -15; done
   echo "== hyperplonk --l 2 --n 16 --which cpermcheck --reps 3 --check (leader)"; $B --l 2 --n 16 --which cpermcheck --reps 3 --check | tail -4
   make -C tests/native -s fake_rccl/librccl.so.1
