@@ -519,19 +519,49 @@ inline Transcript cpermcheck(size_t n, const PackedProvingParameters &pk, const 
     tm.start("Collaborative Permcheck");
     DevPtr num = be.fr_axpb(pk.T("V"), pk.T("sid"), pk.alpha, pk.beta, G4);          // :1277-1279
     DevPtr den = be.fr_axpb(pk.T("eq_r1"), pk.T("ssigma"), pk.alpha, pk.beta, G4);  // :1280-1282
-    auto commit_open = [&](const DevPtr &tab) {
-        out.wiring_commits.push_back(c_commit(be, cc, {tab}, {G4}, pp, net)[0]);
-        out.wiring_opens.push_back(c_open(be, cc, tab, G4, pk.challenge_r1, pp, net));
-    };
-    commit_open(pk.T("ssigma")), commit_open(pk.T("sid"));  // :1289-1308
-    for (const DevPtr &ev : {num, den}) {
-        auto sh = c_acc_product_and_share(be, ev, pk.T("mask"), pk.T("unmask0"), pk.T("unmask1"), pk.T("unmask2"), G4, pp, net);
-        if (sh[0].len != G4 || sh[1].len != G4 || sh[2].len != G4) throw ZkError(ZK_ERR_INVALID, "cpermcheck: share vectors of unexpected length");
-        commit_open(ev), commit_open(sh[0].buf), commit_open(sh[1].buf), commit_open(sh[2].buf);  // :1324-1363
-        out.wiring_proofs.push_back(c_sumcheck_product(be, pk.T("eq_r1"), sh[2].buf, G4, pk.challenge_r1, pp, net));  // :1365-1369
-        out.wiring_proofs.push_back(c_sumcheck_product(be, pk.T("eq_r1"), sh[0].buf, G4, pk.challenge_r1, pp, net));
-        out.wiring_proofs.push_back(c_sumcheck_product(be, sh[0].buf, sh[1].buf, G4, pk.challenge_r1, pp, net));
-        out.wiring_opens.push_back(c_open(be, cc, ev, G4, pk.challenge_r1, pp, net));  // :1371-1375
+    // The reference runs 10 c_commit, 12 c_open and 6 c_sumcheck_product one after the other (:1289-1375); none of them feeds another on
+    // the device -- only the two masked product trees produce tables the rest reads.  So: the trees first, then ALL commitments and
+    // quotient commitments as ONE MSM pass (22 x 4 G scalar-muls: the pass runs at the rate of a large MSM instead of 22 blocking
+    // ones) and the fold rounds of the 12 opens + the six product sumchecks as ONE kernel batch.  The second open of num / den (:1371-1375)
+    // is the same table at the same point as the first: c_open_many_sq adds its kernels and MSM items once.  Outputs keep the
+    // reference's positions.
+    static const bool serial = std::getenv("ZKHOST_CPERM_SERIAL") && std::atoi(std::getenv("ZKHOST_CPERM_SERIAL"));  // A/B: the call-by-call form
+    if (serial) {
+        auto commit_open = [&](const DevPtr &tab) {
+            out.wiring_commits.push_back(c_commit(be, cc, {tab}, {G4}, pp, net)[0]);
+            out.wiring_opens.push_back(c_open(be, cc, tab, G4, pk.challenge_r1, pp, net));
+        };
+        commit_open(pk.T("ssigma")), commit_open(pk.T("sid"));  // :1289-1308
+        for (const DevPtr &ev : {num, den}) {
+            auto sh = c_acc_product_and_share(be, ev, pk.T("mask"), pk.T("unmask0"), pk.T("unmask1"), pk.T("unmask2"), G4, pp, net);
+            if (sh[0].len != G4 || sh[1].len != G4 || sh[2].len != G4) throw ZkError(ZK_ERR_INVALID, "cpermcheck: share vectors of unexpected length");
+            commit_open(ev), commit_open(sh[0].buf), commit_open(sh[1].buf), commit_open(sh[2].buf);  // :1324-1363
+            out.wiring_proofs.push_back(c_sumcheck_product(be, pk.T("eq_r1"), sh[2].buf, G4, pk.challenge_r1, pp, net));  // :1365-1369
+            out.wiring_proofs.push_back(c_sumcheck_product(be, pk.T("eq_r1"), sh[0].buf, G4, pk.challenge_r1, pp, net));
+            out.wiring_proofs.push_back(c_sumcheck_product(be, sh[0].buf, sh[1].buf, G4, pk.challenge_r1, pp, net));
+            out.wiring_opens.push_back(c_open(be, cc, ev, G4, pk.challenge_r1, pp, net));  // :1371-1375
+        }
+    } else {
+        std::vector<DevPtr> com_tabs{pk.T("ssigma"), pk.T("sid")}, open_tabs{pk.T("ssigma"), pk.T("sid")};  // :1289-1308
+        std::vector<std::pair<DevPtr, DevPtr>> pairs;
+        for (const DevPtr &ev : {num, den}) {
+            auto sh = c_acc_product_and_share(be, ev, pk.T("mask"), pk.T("unmask0"), pk.T("unmask1"), pk.T("unmask2"), G4, pp, net);
+            if (sh[0].len != G4 || sh[1].len != G4 || sh[2].len != G4) throw ZkError(ZK_ERR_INVALID, "cpermcheck: share vectors of unexpected length");
+            for (const DevPtr &t : {ev, sh[0].buf, sh[1].buf, sh[2].buf}) com_tabs.push_back(t), open_tabs.push_back(t);  // :1324-1363
+            pairs.push_back({pk.T("eq_r1"), sh[2].buf}), pairs.push_back({pk.T("eq_r1"), sh[0].buf}), pairs.push_back({sh[0].buf, sh[1].buf});  // :1365-1369
+            open_tabs.push_back(ev);  // :1371-1375
+        }
+        MsmQueue q(be);
+        ScQueue sq(be);
+        auto f_com = c_commit_q(be, q, cc, com_tabs, std::vector<size_t>(com_tabs.size(), G4), pp, net);
+        auto a_open = c_open_many_sq(be, sq, q, cc, open_tabs, std::vector<size_t>(open_tabs.size(), G4), std::vector<FrVec>(open_tabs.size(), pk.challenge_r1), pp, net);
+        auto a_sc = c_sumcheck_product_many_sq(be, sq, pairs, G4, pk.challenge_r1, pp, net);
+        sq.run();
+        auto f_open = a_open();
+        out.wiring_proofs = a_sc();
+        q.run();
+        out.wiring_commits = f_com();
+        out.wiring_opens = f_open();
     }
     tm.end();
     if (tm_out) *tm_out = tm;

@@ -611,6 +611,7 @@ inline AfterBatch<std::function<std::vector<Opening>()>> c_open_many_sq(Ctx &be,
                                                                         const PackedSharingParams &pp, Net &net) {
     size_t k = lens.size();
     std::map<std::pair<const void *, size_t>, DevPtr> first;
+    std::map<std::tuple<const void *, size_t, std::vector<uint64_t>>, size_t> same;
     std::vector<SrsPtr> srs;
     std::vector<DevPtr> bufs;
     std::vector<size_t> ms;
@@ -619,7 +620,15 @@ inline AfterBatch<std::function<std::vector<Opening>()>> c_open_many_sq(Ctx &be,
     for (size_t i = 0; i < k; ++i) {
         size_t n = Ctx::log2_exact(lens[i]);
         if (points[i].size() < n) throw ZkError(ZK_ERR_INVALID, "c_open: the point is shorter than the polynomial's variables");
-        size_t j = sq.add({ScRequest::Open, pevals[i], DevPtr(), lens[i], FrVec(points[i].begin(), points[i].begin() + n), DevPtr()});
+        // (the same table at the same point again -- cpermcheck opens num / den twice, dhyperplonk.rs:1324 and :1371 -- is the same
+        // request: its kernels run once, and its MSM items name the same quotient buffers, which the MsmQueue computes once)
+        FrVec pt(points[i].begin(), points[i].begin() + n);
+        std::vector<uint64_t> raw;
+        for (const Fr &x : pt) raw.insert(raw.end(), x.v, x.v + 4);
+        auto same_key = std::make_tuple((const void *)pevals[i].get(), lens[i], raw);
+        auto seen = same.find(same_key);
+        size_t j = seen != same.end() ? seen->second : sq.add({ScRequest::Open, pevals[i], DevPtr(), lens[i], pt, DevPtr()});
+        same.emplace(same_key, j);
         idx->push_back(j);
         const DevPtr &qbuf = sq.out_of(j);
         DevPtr q0 = first.emplace(std::make_pair((const void *)pevals[i].get(), lens[i]), qbuf).first->second;

@@ -649,7 +649,16 @@ def c_open_many_q(be, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence
     k = len(lens)
     pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
     vals, bufs, ms, cuts = [], [], [], [0]
-    rounds = _sc_batch(be, [("open", pe, length, pt[: length.bit_length() - 1]) for pe, length, pt in zip(pevals, lens, pts)])  # :418-432
+    # the same table at the same point again (cpermcheck opens num / den twice, dhyperplonk.rs:1324 and :1371) is the same request: its
+    # kernels run once and its MSM items name the same quotient buffers, which the MsmQueue computes once
+    keys = [(_addr(pe), length, pt[: length.bit_length() - 1].tobytes()) for pe, length, pt in zip(pevals, lens, pts)]
+    uniq = {}
+    for i, key in enumerate(keys):
+        uniq.setdefault(key, i)
+    order = sorted(set(uniq.values()))
+    rounds_u = _sc_batch(be, [("open", pevals[i], lens[i], pts[i][: lens[i].bit_length() - 1]) for i in order])  # :418-432
+    at = {i: j for j, i in enumerate(order)}
+    rounds = [rounds_u[at[uniq[key]]] for key in keys]
     q0s = _first_quotient_sources(pevals, lens, [qb for qb, _ in rounds])
     for (qb, value), length, q0 in zip(rounds, lens, q0s):
         n = length.bit_length() - 1

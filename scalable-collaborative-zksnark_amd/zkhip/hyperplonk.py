@@ -7,6 +7,7 @@ All tables and SRS levels are resident in HBM; every primitive runs through libz
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Dict, List
@@ -17,6 +18,8 @@ from . import dist_primitive as dp
 from .field import fr_mont, random_fr, splitmix_fr
 from .net import Net
 from .pss import PackedSharingParams
+
+CPERM_SERIAL = os.environ.get("ZKHIP_CPERM_SERIAL", "0") == "1"  # cpermcheck call by call as the reference writes it (A/B switch: same transcript)
 
 
 class Timers:
@@ -382,22 +385,43 @@ def cpermcheck(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be,
     cc = pk.c_commitment
     num = be.fr_axpb(T["V"], T["sid"], pk.alpha, pk.beta, G4)  # :1277-1279
     den = be.fr_axpb(T["eq_r1"], T["ssigma"], pk.alpha, pk.beta, G4)  # :1280-1282
+    # The reference runs 10 c_commit, 12 c_open and 6 c_sumcheck_product one after the other (:1289-1375); none feeds another on the
+    # device -- only the two masked product trees produce tables the rest reads.  So: the trees first, then ALL commitments and quotient
+    # commitments as ONE MSM pass and the fold rounds of the opens / the product sumchecks as one batched call each.  The second open
+    # of num / den (:1371-1375) is the first one again (same table, same point): c_open_many_q runs it once.  Outputs keep the
+    # reference's positions.  CPERM_SERIAL: the call-by-call form (A/B, same transcript).
     proofs, commits, opens = [], [], []
-    ccommit = lambda tab: dp.c_commit(be, cc, [tab], [G4], pp, net)[0]
-    copen = lambda tab: dp.c_open(be, cc, tab, G4, pk.challenge_r1, pp, net)
-    for name in ("ssigma", "sid"):  # :1289-1308
-        commits.append(ccommit(T[name]))
-        opens.append(copen(T[name]))
-    for ev in (num, den):
-        (d0, n0), (d1, n1), (d2, n2) = dp.c_acc_product_and_share(be, ev, T["mask"], T["unmask0"], T["unmask1"], T["unmask2"], G4, pp, net)
-        assert n0 == n1 == n2 == G4  # the three share vectors stay in HBM and feed the commits / opens / sumchecks below
-        for tab in (ev, d0, d1, d2):  # :1324-1363
-            commits.append(ccommit(tab))
-            opens.append(copen(tab))
-        csp = lambda f, g: dp.c_sumcheck_product(be, f, g, G4, pk.challenge_r1, pp, net)
-        proofs.append(csp(T["eq_r1"], d2))  # :1365-1369
-        proofs.append(csp(T["eq_r1"], d0))
-        proofs.append(csp(d0, d1))
-        opens.append(copen(ev))  # :1371-1375
+    if CPERM_SERIAL:
+        ccommit = lambda tab: dp.c_commit(be, cc, [tab], [G4], pp, net)[0]
+        copen = lambda tab: dp.c_open(be, cc, tab, G4, pk.challenge_r1, pp, net)
+        for name in ("ssigma", "sid"):  # :1289-1308
+            commits.append(ccommit(T[name]))
+            opens.append(copen(T[name]))
+        for ev in (num, den):
+            (d0, n0), (d1, n1), (d2, n2) = dp.c_acc_product_and_share(be, ev, T["mask"], T["unmask0"], T["unmask1"], T["unmask2"], G4, pp, net)
+            assert n0 == n1 == n2 == G4  # the three share vectors stay in HBM and feed the commits / opens / sumchecks below
+            for tab in (ev, d0, d1, d2):  # :1324-1363
+                commits.append(ccommit(tab))
+                opens.append(copen(tab))
+            csp = lambda f, g: dp.c_sumcheck_product(be, f, g, G4, pk.challenge_r1, pp, net)
+            proofs.append(csp(T["eq_r1"], d2))  # :1365-1369
+            proofs.append(csp(T["eq_r1"], d0))
+            proofs.append(csp(d0, d1))
+            opens.append(copen(ev))  # :1371-1375
+    else:
+        com_tabs, open_tabs, pairs = [T["ssigma"], T["sid"]], [T["ssigma"], T["sid"]], []  # :1289-1308
+        for ev in (num, den):
+            (d0, n0), (d1, n1), (d2, n2) = dp.c_acc_product_and_share(be, ev, T["mask"], T["unmask0"], T["unmask1"], T["unmask2"], G4, pp, net)
+            assert n0 == n1 == n2 == G4  # the three share vectors stay in HBM and feed the commits / opens / sumchecks below
+            com_tabs += [ev, d0, d1, d2]  # :1324-1363
+            open_tabs += [ev, d0, d1, d2, ev]  # ... and :1371-1375
+            pairs += [(T["eq_r1"], d2), (T["eq_r1"], d0), (d0, d1)]  # :1365-1369
+        q = dp.MsmQueue(be)
+        f_com = dp.c_commit_q(be, q, cc, com_tabs, [G4] * len(com_tabs), pp, net)
+        f_open = dp.c_open_many_q(be, q, cc, open_tabs, [G4] * len(open_tabs), [pk.challenge_r1] * len(open_tabs), pp, net)
+        proofs = dp.c_sumcheck_product_many(be, pairs, G4, pk.challenge_r1, pp, net)
+        q.run()
+        commits = list(f_com())
+        opens = f_open()
     tm.end()
     return (proofs, commits, opens), tm.t

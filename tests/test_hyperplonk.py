@@ -210,6 +210,31 @@ def test_permchecks_structure_cpu():
     assert proofs[0].shape == (n + 2 + 1, 3, 4) and opens[0][1].shape == (n + 2, 18)
 
 
+@pytest.mark.parametrize("l,n", [(1, 5), (2, 6)])
+def test_cpermcheck_pipelined_equals_the_call_by_call_form(l, n, monkeypatch):
+    """cpermcheck queues all commitments / quotient commitments into ONE MSM pass, batches the opens' fold rounds and the product
+    sumchecks, and runs the repeated open of num / den (dhyperplonk.rs:1324, :1371: same table, same point) once; CPERM_SERIAL is
+    the reference's call-by-call order.  Same transcript for every party, and the repeated opens are equal"""
+    from zkhip import hyperplonk as hp
+
+    pp = PackedSharingParams(l)
+
+    def party(net):
+        be = OracleBackend()
+        pk = PackedProvingParameters.new(n, pp, be, seed=900 + net.party_id, chal_seed=77)
+        return hp.cpermcheck(n, pk, pp, be, net, seed=950 + net.party_id)[0]
+
+    got = LocalTestNet.simulate_network_round(pp.n, party)
+    monkeypatch.setattr(hp, "CPERM_SERIAL", True)
+    exp = LocalTestNet.simulate_network_round(pp.n, party)
+    for p in range(pp.n):
+        assert _digest(got[p]) == _digest(exp[p]), f"party {p}"
+    opens = got[0][2]
+    assert len(opens) == 12
+    for a, b in ((2, 6), (7, 11)):  # num, den: opened at :1324 and again at :1371
+        assert (opens[a][0] == opens[b][0]).all() and (opens[a][1] == opens[b][1]).all()
+
+
 @pytest.mark.gpu
 def test_permchecks_gpu_match_oracle_backed_run():
     import zkhip
