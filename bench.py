@@ -63,7 +63,7 @@ def transcript_sha256(res) -> str:
 
 
 def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = False, serial_rep: bool = False, timeout: int = 900, mode: str = "leader",
-                 share_gpus: bool = False, env: dict = None):
+                 share_gpus: bool = False, env: dict = None, which: str = "dhyperplonk"):
     """
     The same proof driven by the COMPILED host (scalable-collaborative-zksnark_amd/host: zkhost/hyperplonk.hpp, the C++ mirror of the
     reference's Rust crates above the C ABI) in its own process: leader mode, the SplitMix64 parameter set of the e2e leg (seed 100,
@@ -80,7 +80,8 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = F
         return {"error": "host/bin/hyperplonk is not built (__graft_entry__.build())"}
     try:
         cmd = [exe, "--l", "1", "--n", str(n), "--reps", str(reps), "--digest"] + (["--check"] if check else []) + (["--serial-rep"] if serial_rep else [])
-        cmd += (["--mode", mode] if mode != "leader" else []) + (["--share-gpus"] if share_gpus else [])
+        cmd += (["--mode", mode] if mode != "leader" else []) + (["--share-gpus"] if share_gpus else []) + (["--which", which] if which != "dhyperplonk" else [])
+        TOT = {"dhyperplonk": "Distributed HyperPlonk", "data-parallel": "Distributed HyperPlonk", "dpermcheck": "Distributed Permcheck", "cpermcheck": "Collaborative Permcheck"}[which]
         parties = 1 if mode == "leader" else 8
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
@@ -103,8 +104,8 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = F
                 digests.add(w[-1])
             elif line.startswith("check: party "):
                 checks.append(line[len("check: "):])
-        best = min(runs, key=lambda t: t.get("Distributed HyperPlonk", 1e9))
-        out = {"timers_s": best, "first_proof_s": runs[0].get("Distributed HyperPlonk"), "comm_per_proof": comm, "reps": reps, "transcript_sha256": sorted(digests),
+        best = min(runs, key=lambda t: t.get(TOT, 1e9))
+        out = {"timers_s": best, "first_proof_s": runs[0].get(TOT), "comm_per_proof": comm, "reps": reps, "transcript_sha256": sorted(digests),
                "setup_s": setup, "process_wall_s": wall,
                "timers_note": "'Commit' / 'Wire identity' / 'Open' of timers_s are OVERLAPPED sections (a step's MSM pass is started asynchronously and collected later; the kernel phase of "
                               "the Open step runs inside 'Wire identity'): they are not the reference's phases of the same name, only 'Distributed HyperPlonk' is comparable. "
@@ -114,6 +115,9 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = F
                        + ("leader mode" if mode == "leader" else f"--mode {mode}: 8 parties = 8 host threads of one process, party p on GPU p, exchanges over RCCL")}
         if mode != "leader":
             out["stderr_tail"] = r.stderr[-300:]
+        if which not in ("dhyperplonk", "data-parallel"):
+            out.pop("timers_note")  # (one section, no overlapped steps)
+            out["what"] = out["what"].replace("the same call sequence", f"`--which {which}`")
         if serial:
             out["timers_s_serial_steps"] = serial
         if check:
@@ -855,6 +859,21 @@ def run_rank(args, grp, gpu: int, ctx, net):
                         extra["e2e"]["msm_mix_efficiency"] = {"proof_scalar_muls_per_s": comp / cand[best_host], "single_2p20_msm_scalar_muls_per_s": out["value"],
                                                               "ratio": comp / cand[best_host] / out["value"],
                                                               "note": "scalar-muls the proof computes / its wall time (sumchecks, exchanges and host arithmetic included), over the headline rate"}
+
+        # ---- the collaborative permutation check alone (dhyperplonk.rs:1249-1385; north_star "dperm/cperm"), n = e2e_n, l = 1, compiled host ----
+        if world == 1 and not args.no_e2e and not args.no_extra:
+            try:
+                ctx.trim()
+                cp = cpp_host_e2e(args.e2e_n, reps=3, check=True, which="cpermcheck", timeout=600)
+                if "error" not in cp and cp.get("timers_s"):
+                    g4 = 4 << args.e2e_n
+                    cp["scalar_muls_reference_count"] = 22 * g4 - 12  # 10 c_commit of 4 * 2^n scalars + 12 c_open of 4 * 2^n - 1 quotient scalars
+                    cp["scalar_muls_computed"] = 20 * g4 - 10           # the repeated opens of num / den (:1324, :1371: same table, same point) are computed once
+                    cp["scalar_muls_computed_per_s"] = cp["scalar_muls_computed"] / cp["timers_s"]["Collaborative Permcheck"]
+                    cp["schedule"] = "the two masked product trees, then ONE MSM pass over all commitments / quotient commitments and one batch of the opens' fold rounds + the six product sumchecks"
+                extra["cpermcheck"] = cp
+            except Exception as ex:
+                extra["cpermcheck"] = {"error": repr(ex)}
 
         # ---- N = 8: the same proofs from the COMPILED host over RCCL (BASELINE configs[3] and configs[4]) ----
         # hyperplonk --mode rccl is ONE process that drives all 8 GPUs (zk_comm_init_all, a host thread per party): rank 0 starts it

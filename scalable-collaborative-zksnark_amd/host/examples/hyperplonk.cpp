@@ -87,6 +87,7 @@ static void self_check(const Args &a, const PackedProvingParameters &pk, const P
         check_dhyperplonk_shape(a.n, t, net, rep);
         check_dhyperplonk_recompute(a.n, pk, pp, be, net, t, rep);
     }
+    if (a.which == "cpermcheck") check_cpermcheck_recompute(a.n, pk, pp, be, net, t, rep);
     // the check has teeth: one limb off in one t2 is rejected, under its own label and no other
     std::string teeth = "skipped (--tamper)";
     if (!a.tamper) {

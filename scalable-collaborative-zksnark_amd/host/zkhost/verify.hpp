@@ -238,4 +238,29 @@ inline void check_dhyperplonk_recompute(size_t n, const PackedProvingParameters 
     expect(t.gate_commitments.size() > 5 && same_open(t.gate_commitments[5].second, d_open(be, pk.d_commitment, pk.T("S2_p"), pk.L("S2_p"), pk.challenge, net)), "d_open(S2_p) differs from the single call");
 }
 
+// the same for a cpermcheck transcript (dhyperplonk.rs:1249-1385): shape, the public wires' and num's commitments / openings against
+// the one-call-at-a-time forms (the driver runs them inside ONE pass and ONE batch), and the repeated opens of num / den (:1324 and
+// :1371: same table, same point -- the driver computes them once) against each other and against a single call.  COLLECTIVE.
+inline void check_cpermcheck_recompute(size_t n, const PackedProvingParameters &pk, const PackedSharingParams &pp, Ctx &be, Net &net, const Transcript &t, CheckReport &rep) {
+    size_t G4 = 4 * ((size_t(1) << n) / pp.l);
+    auto same_open = [](const Opening &a, const Opening &b) { return a.value == b.value && a.proofs == b.proofs; };
+    auto expect = [&](bool ok, const char *what) {
+        ++rep.recomputed;
+        if (!ok) rep.bad.push_back(what);
+    };
+    if (t.wiring_proofs.size() != 6 || t.wiring_commits.size() != 10 || t.wiring_opens.size() != 12) {
+        rep.bad.push_back("cpermcheck: expected 6 proofs, 10 commitments, 12 openings");
+        return;
+    }
+    size_t rounds = Ctx::log2_exact(G4) + log2_floor(pp.l);
+    for (auto &o : t.wiring_opens)
+        if (o.proofs.size() != rounds) rep.bad.push_back("cpermcheck: an opening with the wrong number of proofs");
+    expect(t.wiring_commits[0] == c_commit(be, pk.c_commitment, {pk.T("ssigma")}, {G4}, pp, net)[0], "c_commit(ssigma) differs from the single call");
+    expect(same_open(t.wiring_opens[1], c_open(be, pk.c_commitment, pk.T("sid"), G4, pk.challenge_r1, pp, net)), "c_open(sid) differs from the single call");
+    DevPtr num = be.fr_axpb(pk.T("V"), pk.T("sid"), pk.alpha, pk.beta, G4);  // :1277-1279
+    expect(t.wiring_commits[2] == c_commit(be, pk.c_commitment, {num}, {G4}, pp, net)[0], "c_commit(num) differs from the single call");
+    expect(same_open(t.wiring_opens[6], c_open(be, pk.c_commitment, num, G4, pk.challenge_r1, pp, net)), "the second c_open(num) differs from the single call");
+    expect(same_open(t.wiring_opens[2], t.wiring_opens[6]) && same_open(t.wiring_opens[7], t.wiring_opens[11]), "the two opens of num / den differ");
+}
+
 }  // namespace zkhost

@@ -103,3 +103,7 @@ def test_single_gpu_line_has_the_record_fields():
     assert "error" not in cpp and cpp["transcript_equals_python_host"] is True and len(cpp["transcript_sha256"]) == 1
     assert e2e["proof_s"]["host"] in ("python", "cpp") and e2e["proof_s"]["seconds"] == min(e2e["proof_s"]["all"].values())
     assert 0 < cpp["timers_s"]["Distributed HyperPlonk"] < 1 and cpp["comm_per_proof"] == "(959224, 959224)"
+    # the collaborative permutation check alone, compiled host, self-checked (5 commits / opens recomputed by single calls)
+    cp = line["cpermcheck"]
+    assert "error" not in cp and cp["self_check_ok"] is True and "5 recomputed" in cp["self_check"], cp
+    assert 0 < cp["timers_s"]["Collaborative Permcheck"] < 1 and cp["scalar_muls_computed"] == 20 * (4 << 12) - 10

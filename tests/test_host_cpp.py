@@ -520,6 +520,22 @@ def test_cpp_example_checks_its_own_proofs(args, parties, transcripts):
     assert len(lines) == parties and all(" ok -- anchored" in l and "flipped limb rejected as" in l for l in lines), r.stdout[-2500:]
     leader = [l for l in lines if l.startswith("check: party 0 ")]
     assert len(leader) == 1 and f", {transcripts} transcripts pinned at both ends" in leader[0], leader
+    if "cpermcheck" in args:  # the pipelined driver (one MSM pass, one kernel batch, repeated opens once) against single calls
+        assert all(", 5 recomputed commits / opens" in l for l in lines), lines
+
+
+@pytest.mark.gpu
+def test_cpp_cpermcheck_pipelined_equals_the_call_by_call_form():
+    """ZKHOST_CPERM_SERIAL=1 is the reference's order (10 c_commit, 12 c_open, 6 c_sumcheck_product one after the other): same digest and
+    the same Comm totals as the default schedule, leader mode and 16 party threads"""
+    for args in (["--l", "1", "--n", "12"], ["--l", "2", "--n", "9", "--mode", "threads"]):
+        seen = []
+        for serial in ("0", "1"):
+            r = subprocess.run([_example()] + args + ["--which", "cpermcheck", "--reps", "1", "--digest", "--check"], capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZKHOST_CPERM_SERIAL=serial))
+            assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+            seen.append(sorted({l for l in r.stdout.splitlines() if l.startswith("transcript sha256") or l.startswith("Comm:")}))
+        assert seen[0] == seen[1] and len(seen[0]) == 2, (args, seen)
 
 
 @pytest.mark.gpu
