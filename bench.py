@@ -570,7 +570,7 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 "peak_architectural": MAD_PEAK_ARCH / 1e12,
                 "frac_of_architectural": (madds * MADS_PER_MADD / (accum_ms * 1e-3) / MAD_PEAK_ARCH) if accum_ms > 0 else 0.0,
                 "peak_architectural_note": "256 CU x 128 lanes/clk x 2.4 GHz / 2 (v_mad_u64_u32 issues at half rate); the chip clocks down to ~1.85 GHz under multiply-dense code, which is the gap to the measured peak",
-                "counters": "profiles/r04j_accum_valu_counters.csv (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES of this kernel: 4 410 VALU instructions per mixed addition, 3 055 of them v_mad_u64_u32)",
+                "counters": "profiles/r05z_accum_valu_counters.csv (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES of this kernel: 4 410 VALU instructions per mixed addition, 3 055 of them v_mad_u64_u32)",
                 "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes, "note": "128 B per (point, scalar) pair / the kernel's HIP-event time (SURVEY.md 8d)"},
             },
