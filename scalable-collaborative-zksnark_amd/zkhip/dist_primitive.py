@@ -234,7 +234,7 @@ def _sc_batch(be, reqs):
         elif r[0] == "fold":
             out.append(be.fold(r[1], r[2], r[3]))
         else:
-            out.append(be.open_rounds(r[1], r[2], r[3]))
+            out.append(be.open_rounds(r[1], r[2], r[3], q_out=r[4]) if len(r) > 4 else be.open_rounds(r[1], r[2], r[3]))
     return out
 
 
@@ -364,32 +364,257 @@ def d_sumcheck_product_many_q(be, items: Sequence, net: Net):
     phase1 = _sc_batch(be, [("product", f, g, length, ch[:n]) for (f, g, length, ch), n in zip(items, ns)])
     chals = [np.array(ch, copy=True) for _, _, _, ch in items]
 
-    def fin():
-        locals_ = [np.concatenate([tr, np.stack([lg, lf, ZERO])[None]]) for tr, lf, lg in phase1]  # marker (g, f, 0)  :433
-        cuts = np.cumsum([0] + [len(x) for x in locals_])
-        allp = net.all_gather(np.concatenate(locals_))  # [party][sum(n_i + 1), 3, 4]
-        if not net.is_leader:
-            return [np.zeros((0, 3, 4), dtype=np.uint64) for _ in chals]
-        out = []
-        for k, (challenge, n) in enumerate(zip(chals, ns)):
-            mine = [np.asarray(allp[p])[cuts[k] : cuts[k + 1]] for p in range(net.n_parties)]
-            head = fr_sum_mont([m[:n] for m in mine])  # per-round sums (:440-447)
-            f = [fr_from_mont(m[n][1]) for m in mine]  # :448
-            g = [fr_from_mont(m[n][0]) for m in mine]  # :449
-            ch = _fr_vec_to_ints(challenge[n : n + s])
-            res = []
-            for i in range(s):
-                t, f, g = _round_product(f, g, ch[i])
-                res.append(t)
-            out.append(np.concatenate([head.reshape(-1, 3, 4), _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)]))
-        return out
+    return lambda: _d_sumcheck_leader_rounds(phase1, chals, ns, s, net)
 
-    return fin
+
+def _d_sumcheck_leader_rounds(phase1, chals, ns, s, net):
+    """the exchange (:437, one all-gather of the concatenated payloads) and the leader rounds (:440-507) of several d_sumcheck_product"""
+    locals_ = [np.concatenate([tr, np.stack([lg, lf, ZERO])[None]]) for tr, lf, lg in phase1]  # marker (g, f, 0)  :433
+    cuts = np.cumsum([0] + [len(x) for x in locals_])
+    allp = net.all_gather(np.concatenate(locals_))  # [party][sum(n_i + 1), 3, 4]
+    if not net.is_leader:
+        return [np.zeros((0, 3, 4), dtype=np.uint64) for _ in chals]
+    out = []
+    for k, (challenge, n) in enumerate(zip(chals, ns)):
+        mine = [np.asarray(allp[p])[cuts[k] : cuts[k + 1]] for p in range(net.n_parties)]
+        head = fr_sum_mont([m[:n] for m in mine])  # per-round sums (:440-447)
+        f = [fr_from_mont(m[n][1]) for m in mine]  # :448
+        g = [fr_from_mont(m[n][0]) for m in mine]  # :449
+        ch = _fr_vec_to_ints(challenge[n : n + s])
+        res = []
+        for i in range(s):
+            t, f, g = _round_product(f, g, ch[i])
+            res.append(t)
+        out.append(np.concatenate([head.reshape(-1, 3, 4), _ints_to_fr([x for t in res for x in t]).reshape(-1, 3, 4)]))
+    return out
 
 
 def d_sumcheck_product_many(be, items: Sequence, net: Net) -> List[np.ndarray]:
     """several independent d_sumcheck_product (dsumcheck.rs:359-512) at once: the local phases as one batched call, one exchange"""
     return d_sumcheck_product_many_q(be, items, net)()
+
+
+# =======================================================================================
+# ONE batch for the sumcheck-family kernels of a whole protocol step (the mirror of zkhost/pipeline.hpp ScQueue and its *_sq forms).
+# The *_q forms above run the kernels of one primitive, then do the exchange that depends on them; a step that calls several of them
+# pays a blocking launch chain per call with the chip nearly empty.  Nothing in those chains needs another call's result ON THE
+# DEVICE: every *_sq form splits into phase A -- add the requests (the opens' quotient buffers are allocated at once, so their
+# commitments can be queued) -- and phase B, called after ScQueue.run(), which performs the exchanges that need a kernel result
+# and returns what the *_q form returns.  Same outputs, bit for bit.
+# =======================================================================================
+class ScQueue:
+    def __init__(self, be):
+        self.be, self.reqs, self.res = be, [], None
+
+    def add(self, req) -> int:
+        if req[0] == "open" and len(req) < 5:  # the quotient buffer exists before the batch runs: a later MSM item may name it
+            req = tuple(req) + (self.be.alloc(max(32 * (req[2] - 1), 1)),)
+        self.reqs.append(tuple(req))
+        return len(self.reqs) - 1
+
+    def out_of(self, i: int):
+        return self.reqs[i][4]
+
+    def run(self):
+        self.res = _sc_batch(self.be, self.reqs) if self.reqs else []
+        self.reqs = []
+
+    def at(self, i: int):
+        if self.res is None:
+            raise RuntimeError("ScQueue: a result was read before the batch ran")
+        return self.res[i]
+
+
+def c_sumcheck_product_many_sq(be, sq: ScQueue, pairs: Sequence, length: int, challenge: np.ndarray, pp: PackedSharingParams, net: Net):
+    """c_sumcheck_product_many: A adds the phase-1 loops, B = the pss2ss hand-offs (:224-225) and phase 2, item by item"""
+    n = length.bit_length() - 1
+    idx = []
+    for f, g in pairs:
+        _trace(be, "c", f, g, length, challenge[:n])
+        idx.append(sq.add(("product", f, g, length, challenge[:n])))
+    ch = _fr_vec_to_ints(challenge)
+
+    def phase_b():
+        out = []
+        for i in idx:
+            tr, lf, lg = sq.at(i)
+            vf = _fr_vec_to_ints(pss2ss(lf, pp, net))  # :224
+            vg = _fr_vec_to_ints(pss2ss(lg, pp, net))  # :225
+            extra = []
+            for r in range(pp.l.bit_length() - 1):
+                t, vf, vg = _round_product(vf, vg, ch[r])
+                extra.append(t)
+            extra.append((0, vf[0] * vg[0] % R_MOD, 0))  # :282
+            out.append(np.concatenate([tr, _ints_to_fr([x for t in extra for x in t]).reshape(-1, 3, 4)]))
+        return out
+
+    return phase_b
+
+
+def sumcheck_product_sq(be, sq: ScQueue, ef, eg, length: int, challenge: np.ndarray):
+    """sumcheck_product (dsumcheck.rs:28-90) with its kernels in the batch; -> closure (call after the batch)"""
+    n = length.bit_length() - 1
+    _trace(be, "plain", ef, eg, length, challenge[:n])
+    i = sq.add(("product", ef, eg, length, challenge[:n]))
+
+    def fin():
+        tr, lf, lg = sq.at(i)
+        prod = fr_mont(fr_from_mont(lf) * fr_from_mont(lg) % R_MOD)
+        return np.concatenate([tr, np.stack([ZERO, prod, ZERO])[None]])
+
+    return fin
+
+
+def open_many_sq(be, sq: ScQueue, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray]):
+    """open_many_q: nothing to exchange -- the values are read when the finishing closure runs"""
+    pts = [np.asarray(pt, dtype=np.uint64).reshape(-1, 4) for pt in points]
+    idx = [sq.add(("open", pe, length, pt[: length.bit_length() - 1])) for pe, length, pt in zip(pevals, lens, pts)]
+    qbufs = [sq.out_of(i) for i in idx]
+    q0s = _first_quotient_sources(pevals, lens, qbufs)
+    cuts = []
+    for qb, length, q0 in zip(qbufs, lens, q0s):
+        s_, b_, l_ = _open_msm_items(powers_of_g, qb, length, q0)
+        cuts.append(q.add(s_, b_, l_, keep=[qb]))
+
+    def fin():
+        return [(sq.at(i)[1], q.res[c]) for i, c in zip(idx, cuts)]
+
+    fin.idx = idx
+    return fin
+
+
+def d_open_many_sq(be, sq: ScQueue, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], net: Net):
+    """d_open_many_q in two halves: A = the local opens' kernels and quotient commitments; B = the gather of the local values and, on
+    the leader, the root opens (dpoly_comm.rs:372-378: tables of N_p values -- their fold rounds run on the host, only the quotients
+    go to the device for their commitments); B -> the finishing closure"""
+    k = len(lens)
+    if not k:
+        return lambda: (lambda: [])
+    plog = net.n_parties.bit_length() - 1
+    npar = net.n_parties
+    pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
+    f_local = open_many_sq(be, sq, q, powers_of_g, pevals, lens, [p[plog:] for p in pts])
+
+    def phase_b():
+        vals_mine = np.stack([np.asarray(sq.at(i)[1], dtype=np.uint64).reshape(4) for i in f_local.idx])
+        vals = net.all_gather(vals_mine)  # [party][k, 4]
+        roots = None
+        if net.is_leader:
+            cols = np.stack([np.asarray(v).reshape(-1, 4) for v in vals], axis=1)  # [k][party][4]
+            rvals, qall = [], []
+            for i in range(k):
+                cur = _fr_vec_to_ints(cols[i])
+                lo = _fr_vec_to_ints(pts[i][:plog])
+                for r in range(plog):
+                    h = len(cur) // 2
+                    qall += [(cur[j + h] - cur[j]) % R_MOD for j in range(h)]
+                    cur = [(cur[j] + lo[r] * (cur[j + h] - cur[j])) % R_MOD for j in range(h)]
+                rvals.append(fr_mont(cur[0]))
+            rcuts = [np.zeros(0, dtype=np.int64)] * k
+            if npar > 1:
+                dq = be.to_device(_ints_to_fr(qall))  # [k][N_p - 1]
+                rcuts = []
+                for i in range(k):
+                    s_, b_, l_ = _open_msm_items(powers_of_g, dq.at(32 * (npar - 1) * i), npar)
+                    rcuts.append(q.add(s_, b_, l_, keep=[dq]))
+            roots = (rvals, rcuts)
+
+        def fin():
+            local = f_local()
+            cuts = [0]
+            for _, prf in local:
+                cuts.append(cuts[-1] + len(prf))
+            prfs = net.all_gather(np.concatenate([prf for _, prf in local]) if cuts[-1] else np.zeros((0, 18), dtype=np.uint64))
+            if not net.is_leader:
+                return [(ZERO.copy(), np.zeros((0, 18), dtype=np.uint64)) for _ in range(k)]
+            ones = np.tile(int_to_limbs(1, 4), (npar, 1))
+            total = cuts[-1]
+            pi = be.g1_lincomb_batch(np.stack([np.asarray(g).reshape(-1, 18) for g in prfs], axis=1), ones) if total else np.zeros((0, 18), dtype=np.uint64)
+            out = []
+            for i in range(k):
+                allp = list(q.res[roots[1][i]]) + list(pi[cuts[i] : cuts[i + 1]])  # root proofs FIRST (:379-384)
+                out.append((roots[0][i], np.stack(allp) if allp else np.zeros((0, 18), dtype=np.uint64)))
+            return out
+
+        return fin
+
+    return phase_b
+
+
+def c_open_many_sq(be, sq: ScQueue, q: MsmQueue, powers_of_g, pevals: Sequence, lens: Sequence[int], points: Sequence[np.ndarray], pp: PackedSharingParams, net: Net):
+    """c_open_many_q in two halves: A = the fold rounds; B = the ONE queued d_msm over all quotients (with real parties d_msm_q pre-scales
+    its scalars on the device when it is called, and the quotient buffers are filled by the batch), pss2ss of the last values and the
+    log2(l) extra rounds, whose small MSMs are queued too; B -> the finishing closure"""
+    k = len(lens)
+    pts = [np.asarray(p, dtype=np.uint64).reshape(-1, 4) for p in points]
+    keys = [(_addr(pe), length, pt[: length.bit_length() - 1].tobytes()) for pe, length, pt in zip(pevals, lens, pts)]
+    seen, idx = {}, []
+    for i, key in enumerate(keys):  # (the same table at the same point again is the same request: see c_open_many_q)
+        if key not in seen:
+            seen[key] = sq.add(("open", pevals[i], lens[i], pts[i][: lens[i].bit_length() - 1]))
+        idx.append(seen[key])
+    qbufs = [sq.out_of(i) for i in idx]
+    q0s = _first_quotient_sources(pevals, lens, qbufs)
+    bufs, ms, cuts = [], [], [0]
+    for qb, length, q0 in zip(qbufs, lens, q0s):
+        n = length.bit_length() - 1
+        q.keep.append(qb)
+        off, m = 0, length
+        for r_ in range(n):
+            h = m // 2
+            bufs.append((q0 if r_ == 0 else qb).at(32 * off))
+            ms.append(h)
+            off += h
+            m = h
+        cuts.append(len(ms))
+
+    def phase_b():
+        f_com = c_commit_q(be, q, powers_of_g, bufs, ms, pp, net) if ms else (lambda: np.zeros((0, 18), dtype=np.uint64))
+        tails = []
+        for i in range(k):
+            cur = _fr_vec_to_ints(pss2ss(sq.at(idx[i])[1], pp, net))
+            pt = _fr_vec_to_ints(pts[i])
+            fins = []
+            for r in range(pp.l.bit_length() - 1):
+                h = len(cur) // 2
+                qi = [(cur[j + h] - cur[j]) % R_MOD for j in range(h)]
+                level = (len(qi) * pp.l).bit_length() - 1
+                d_qi = be.to_device(_ints_to_fr(qi))
+                fins.append(q.add([powers_of_g[level]], [d_qi], [len(qi)], keep=[d_qi]))
+                cur = [(cur[j] * (1 - pt[r]) + cur[j + h] * pt[r]) % R_MOD for j in range(h)]
+            tails.append((fr_mont(cur[0]), fins))
+
+        def fin():
+            com = f_com()
+            out = []
+            for i in range(k):
+                res = list(com[cuts[i] : cuts[i + 1]]) + [q.res[sl][0] for sl in tails[i][1]]
+                out.append((tails[i][0], np.stack(res) if res else np.zeros((0, 18), dtype=np.uint64)))
+            return out
+
+        return fin
+
+    return phase_b
+
+
+def d_sumcheck_product_many_sq(be, sq: ScQueue, items: Sequence, net: Net):
+    """d_sumcheck_product_many_q with its local phases in the batch: the returned closure (exchange + leader rounds) is called when
+    the transcript is assembled, after ScQueue.run()"""
+    if not len(items):
+        return lambda: []
+    s = net.n_parties.bit_length() - 1
+    ns = [length.bit_length() - 1 for _, _, length, _ in items]
+    idx = []
+    for (f, g, length, ch), n in zip(items, ns):
+        _trace(be, "d", f, g, length, ch[: n + s])
+        idx.append(sq.add(("product", f, g, length, ch[:n])))
+    chals = [np.array(ch, copy=True) for _, _, _, ch in items]
+
+    def fin():
+        phase1 = [sq.at(i) for i in idx]
+        return _d_sumcheck_leader_rounds(phase1, chals, ns, s, net)
+
+    return fin
 
 
 # ---------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@ from .field import fr_mont, random_fr, splitmix_fr
 from .net import Net
 from .pss import PackedSharingParams
 
+ONE_BATCH = os.environ.get("ZKHIP_ONE_BATCH", "1") != "0"  # the sumcheck-family kernels of a proof's steps 2-4 as ONE batch (dp.ScQueue); 0: a batch per call
 CPERM_SERIAL = os.environ.get("ZKHIP_CPERM_SERIAL", "0") == "1"  # cpermcheck call by call as the reference writes it (A/B switch: same transcript)
 
 
@@ -168,17 +169,26 @@ def _at(buf, byte_off):
 
 def _wiring_identity(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top):
     """step 2 of dhyperplonk (:262-514) == the body of dpermcheck (:992-1245)"""
-    q, finalize = _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top)
+    sq = dp.ScQueue(be) if ONE_BATCH else None  # the step's sumcheck-family kernels as one batch
+    q, phase_b = _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top, sq)
+    if sq is not None:
+        sq.run()
+    finalize = phase_b()
     q.run()
     return finalize()
 
 
-def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top):
+def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top, sq=None):
     """
-    the step up to (not including) its one batched MSM pass: every sumcheck / fold / open-round kernel has run, every MSM of
-    the step sits in the returned queue.  -> (queue, finalize): run (or start / finish) the queue, then finalize() performs the
-    exchanges of the MSM results and returns (wiring_proofs, wiring_commits, wiring_opens) in the reference's order.
+    the step up to (not including) its one batched MSM pass.  -> (queue, phase_b); finalize = phase_b(); run (or start / finish) the
+    queue, then finalize() performs the exchanges of the MSM results and returns (wiring_proofs, wiring_commits, wiring_opens) in the
+    reference's order.
+    sq = None: every sumcheck / fold / open-round kernel runs inside the call that owns it (a blocking batch per call), phase_b()
+    has nothing left to do.  sq = a dp.ScQueue (the mirror of zkhost/hyperplonk.hpp wiring_enqueue_sq): the calls only ADD their
+    kernels; the caller runs the batch, and phase_b() performs the exchanges that need a kernel result (pss2ss of 2.c and of the
+    opens of V, the gather of the local open values, the leader's root opens).  Same outputs.
     """
+    one = sq is not None
     T, L = pk.tables, pk.lens
     l, npar = pp.l, net.n_parties
     M = 1 << n
@@ -205,9 +215,13 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
     # every MSM of the step is queued and runs in ONE batched pass at its end (dp.MsmQueue); the closures below put
     # the results at the reference's positions.  Exchanges keep the reference's order on every party.
     q = dp.MsmQueue(be)
-    wiring_proofs.append(dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net))  # 2.c
-    # 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
-    f_copen = dp.c_open_many_q(be, q, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net)
+    if one:
+        a_2c = dp.c_sumcheck_product_many_sq(be, sq, [(s_dev, T["V"])], 4 * M // l, pk.challenge_r1, pp, net)  # 2.c
+        a_copen = dp.c_open_many_sq(be, sq, q, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net)  # 2.d
+    else:
+        a_2c = lambda r=[dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net)]: r  # 2.c
+        # 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
+        a_copen = lambda f=dp.c_open_many_q(be, q, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net): f
     # 2.e (:322-340)
     hlen = 4 * M // npar
     num = be.fr_axpb(local_s_p, T["sid_p"], pk.alpha, pk.beta, hlen)
@@ -240,9 +254,9 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
             cur[k] = _at(cur[k], 32 * (clen // 2))
         clen //= 2
     # (local phases now; the exchange and the leader rounds -- host arithmetic -- in finalize(), beside the step's MSM pass)
-    f_dsp = dp.d_sumcheck_product_many_q(be, dsp_items, net)
+    f_dsp = dp.d_sumcheck_product_many_sq(be, sq, dsp_items, net) if one else dp.d_sumcheck_product_many_q(be, dsp_items, net)
     # the opens of local_s, of the five tables and of all layers are independent of each other
-    f_dopen = dp.d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net)
+    a_dopen = dp.d_open_many_sq(be, sq, q, dc, lay_tabs, lay_lens, lay_pts, net) if one else (lambda f=dp.d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net): f)
     f_top_commits, f_top_opens, top_proofs = [], None, []
     if top is not None:  # leader-only tail on the N_p-leaf top tree (:480-511)
         tt = np.asarray(top, dtype=np.uint64).reshape(-1, 4)
@@ -251,25 +265,33 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
         chs = pk.challenge_r2[:sbits]
         dv = [be.to_device(np.ascontiguousarray(v)) for v in (lvx0, lvx1, lv1x)]
         f_top_commits = [dp.commit_q(q, dc, d, len(v)) for d, v in zip(dv, (lvx0, lvx1, lv1x))]
-        f_top_opens = dp.open_many_q(be, q, dc, dv, [len(lvx0), len(lvx1), len(lv1x)], [chs] * 3)
+        f_top_opens = (dp.open_many_sq(be, sq, q, dc, dv, [len(lvx0), len(lvx1), len(lv1x)], [chs] * 3) if one
+                       else dp.open_many_q(be, q, dc, dv, [len(lvx0), len(lvx1), len(lv1x)], [chs] * 3))
         q.keep += dv
         d0, dd1, d1 = dv
-        top_proofs.append(dp.sumcheck_product(be, eq_top, d1, len(lv1x), chs))
-        top_proofs.append(dp.sumcheck_product(be, eq_top, d0, len(lvx0), chs))
-        top_proofs.append(dp.sumcheck_product(be, d0, dd1, len(lvx0), chs))
-    def finalize():
-        wiring_proofs.extend(f_dsp())                  # 2.e: after 2.c, before the leader-tree sumchecks (the reference's order)
-        wiring_opens.extend(f_copen())                 # 2.d
-        wiring_commits.extend(list(f_dcommit()))       # 2.b, then :363-380
-        wiring_opens.extend(f_dopen())
-        if top is not None:
-            for fc, fo in zip(f_top_commits, f_top_opens()):  # (commit, open) per table, in the reference's order
-                wiring_commits.append(fc())
-                wiring_opens.append(fo)
-            wiring_proofs.extend(top_proofs)
-        return wiring_proofs, wiring_commits, wiring_opens
+        for f_, g_, m_ in ((eq_top, d1, len(lv1x)), (eq_top, d0, len(lvx0)), (d0, dd1, len(lvx0))):
+            top_proofs.append(dp.sumcheck_product_sq(be, sq, f_, g_, m_, chs) if one else (lambda r=dp.sumcheck_product(be, f_, g_, m_, chs): r))
 
-    return q, finalize
+    def phase_b():
+        wiring_proofs.extend(a_2c())  # (one batch: pss2ss of 2.c)
+        f_copen = a_copen()           # (one batch: pss2ss of the two opens of V, their d_msm queued)
+        f_dopen = a_dopen()           # (one batch: the gather of the local open values, the leader's root opens)
+
+        def finalize():
+            wiring_proofs.extend(f_dsp())                  # 2.e: after 2.c, before the leader-tree sumchecks (the reference's order)
+            wiring_opens.extend(f_copen())                 # 2.d
+            wiring_commits.extend(list(f_dcommit()))       # 2.b, then :363-380
+            wiring_opens.extend(f_dopen())
+            if top is not None:
+                for fc, fo in zip(f_top_commits, f_top_opens()):  # (commit, open) per table, in the reference's order
+                    wiring_commits.append(fc())
+                    wiring_opens.append(fo)
+                wiring_proofs.extend(p() for p in top_proofs)
+            return wiring_proofs, wiring_commits, wiring_opens
+
+        return finalize
+
+    return q, phase_b
 
 
 def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be, net: Net, seed: int = 1, data_parallel: bool = False):
@@ -317,14 +339,44 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     Ml = M // l
     sum_ab = be.fr_add(T["a_evals"], T["b_evals"], Ml)  # :233-238
     sum_ci = be.fr_sub(T["I"], T["c_evals"], Ml)  # -c + I  :251-256
+    gate_pairs = [(T["eq"], T["S1"]), (T["S1"], sum_ab), (T["eq"], T["S2"]), (T["a_evals"], T["b_evals"]), (T["S2"], T["a_evals"]), (T["eq"], sum_ci)]
+    if ONE_BATCH and dp.PIPELINE_MSM:
+        # The sumcheck-family kernels of steps 2-4 as ONE batch (dp.ScQueue; zkhost/hyperplonk.hpp does the same): the six gate
+        # sumchecks, everything of the wiring step, the fold rounds of the Open step.  None needs another's result on the device; as
+        # ~10 blocking calls they were launch chains on a nearly empty chip.  Phase B of every primitive (the exchanges that need a
+        # kernel result) follows in the reference's order; then the two long MSM passes start.
+        sq = dp.ScQueue(be)
+        a_gate = dp.c_sumcheck_product_many_sq(be, sq, gate_pairs, Ml, pk.challenge, pp, net)
+        tm.end()
+        tm.start("Wire identity")
+        q_w, b_wiring = _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top, sq)
+        q_o = dp.MsmQueue(be)
+        a_co = dp.c_open_many_sq(be, sq, q_o, cc, [T[x] for x in names_c], [L[x] for x in names_c], [pk.challenge] * 3, pp, net)
+        a_do = dp.d_open_many_sq(be, sq, q_o, dc, [T[x] for x in names_d], [L[x] for x in names_d], [pk.challenge] * 3, net)
+        sq.run()
+        gate_proofs = a_gate()
+        finalize_wiring = b_wiring()
+        f_co, f_do = a_co(), a_do()
+        q_w.start()
+        q_o.start()
+        finish_commit()
+        tm.end()
+        tm.start("Open")
+        q_w.finish()
+        wiring_proofs, wiring_commits, wiring_opens = finalize_wiring()
+        q_o.finish()
+        gate_commitments = [(com[name], op) for name, op in zip(names_c + names_d, list(f_co()) + list(f_do()))]
+        tm.end()
+        tm.end()
+        return ((gate_proofs, gate_commitments), (wiring_proofs, wiring_commits, wiring_opens)), tm.t
     # the six sumchecks are independent: one batched phase 1, then the hand-offs in the reference's order
-    gate_proofs = dp.c_sumcheck_product_many(be, [(T["eq"], T["S1"]), (T["S1"], sum_ab), (T["eq"], T["S2"]), (T["a_evals"], T["b_evals"]),
-                                                  (T["S2"], T["a_evals"]), (T["eq"], sum_ci)], Ml, pk.challenge, pp, net)
+    gate_proofs = dp.c_sumcheck_product_many(be, gate_pairs, Ml, pk.challenge, pp, net)
     tm.end()
 
     # Step 2: wiring identity (shared with dpermcheck)
     tm.start("Wire identity")
-    q_w, finalize_wiring = _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top)
+    q_w, b_wiring = _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_l, eq_top)
+    finalize_wiring = b_wiring()
     # The kernel phase of the Open step (:517-553: fold rounds and quotients of a, b, c, I, S1, S2) depends on nothing the wiring step
     # produces, so it runs BEFORE the wiring pass is started: behind a running pass its ~0.5 ms of kernels would wait for the pass to
     # drain (they share the runtime's hardware queues), the Open pass could only be enqueued after that, and the GPU would idle between

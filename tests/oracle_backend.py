@@ -104,8 +104,11 @@ class OracleBackend:
     def product_tree(self, x, N):
         return NumpyBuf(co.product_tree(_arr(x)[:N]))
 
-    def open_rounds(self, tab, length, point):
+    def open_rounds(self, tab, length, point, q_out=None):
         q, v = co.open_quotients(_arr(tab)[:length], np.asarray(point).reshape(-1, 4))
+        if q_out is not None:  # (a caller-provided quotient buffer, like the library's q_out)
+            _arr(q_out)[: len(q)] = q
+            return q_out, v
         return NumpyBuf(q if len(q) else np.zeros((1, 4), np.uint64)), v
 
     # element-wise / table helpers used by the protocol driver

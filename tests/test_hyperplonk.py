@@ -210,6 +210,29 @@ def test_permchecks_structure_cpu():
     assert proofs[0].shape == (n + 2 + 1, 3, 4) and opens[0][1].shape == (n + 2, 18)
 
 
+@pytest.mark.parametrize("l,n,fn_name", [(1, 5, "dhyperplonk"), (2, 6, "dhyperplonk"), (1, 5, "dpermcheck")])
+def test_one_batch_schedule_equals_the_batch_per_call_form(l, n, fn_name, monkeypatch):
+    """ONE_BATCH (default): the sumcheck-family kernels of steps 2-4 are added to one dp.ScQueue, the exchanges that need a kernel
+    result follow in phase B; ONE_BATCH = False runs every primitive's kernels inside its own call.  Same transcript on every
+    party, same bytes on the wire"""
+    from zkhip import hyperplonk as hp
+
+    pp = PackedSharingParams(l)
+
+    def party(net):
+        be = OracleBackend()
+        pk = PackedProvingParameters.new(n, pp, be, seed=1200 + net.party_id, chal_seed=78)
+        res = getattr(hp, fn_name)(n, pk, pp, be, net, seed=1250 + net.party_id)[0]
+        return res, (net.upload, net.download)
+
+    got = LocalTestNet.simulate_network_round(pp.n, party)
+    monkeypatch.setattr(hp, "ONE_BATCH", False)
+    exp = LocalTestNet.simulate_network_round(pp.n, party)
+    for p in range(pp.n):
+        assert _digest(got[p][0]) == _digest(exp[p][0]), f"party {p}"
+        assert got[p][1] == exp[p][1], f"party {p}: bytes on the wire"
+
+
 @pytest.mark.parametrize("l,n", [(1, 5), (2, 6)])
 def test_cpermcheck_pipelined_equals_the_call_by_call_form(l, n, monkeypatch):
     """cpermcheck queues all commitments / quotient commitments into ONE MSM pass, batches the opens' fold rounds and the product
