@@ -163,6 +163,11 @@ def _halves(buf, length):
     return buf, _at(buf, 32 * (length // 2))
 
 
+def _done(value):
+    """a phase-B / finishing closure for work that has already run (the batch-per-call forms next to the *_sq ones)"""
+    return lambda: value
+
+
 def _at(buf, byte_off):
     return buf.at(byte_off) if hasattr(buf, "at") else buf + byte_off
 
@@ -219,9 +224,9 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
         a_2c = dp.c_sumcheck_product_many_sq(be, sq, [(s_dev, T["V"])], 4 * M // l, pk.challenge_r1, pp, net)  # 2.c
         a_copen = dp.c_open_many_sq(be, sq, q, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net)  # 2.d
     else:
-        a_2c = lambda r=[dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net)]: r  # 2.c
+        a_2c = _done([dp.c_sumcheck_product(be, s_dev, T["V"], 4 * M // l, pk.challenge_r1, pp, net)])  # 2.c
         # 2.d: the two opens of V are independent -> their q_i commitments share one d_msm
-        a_copen = lambda f=dp.c_open_many_q(be, q, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net): f
+        a_copen = _done(dp.c_open_many_q(be, q, cc, [T["V"], T["V"]], [4 * M // l] * 2, [pk.challenge_r1, pk.challenge_r2], pp, net))
     # 2.e (:322-340)
     hlen = 4 * M // npar
     num = be.fr_axpb(local_s_p, T["sid_p"], pk.alpha, pk.beta, hlen)
@@ -256,7 +261,7 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
     # (local phases now; the exchange and the leader rounds -- host arithmetic -- in finalize(), beside the step's MSM pass)
     f_dsp = dp.d_sumcheck_product_many_sq(be, sq, dsp_items, net) if one else dp.d_sumcheck_product_many_q(be, dsp_items, net)
     # the opens of local_s, of the five tables and of all layers are independent of each other
-    a_dopen = dp.d_open_many_sq(be, sq, q, dc, lay_tabs, lay_lens, lay_pts, net) if one else (lambda f=dp.d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net): f)
+    a_dopen = dp.d_open_many_sq(be, sq, q, dc, lay_tabs, lay_lens, lay_pts, net) if one else _done(dp.d_open_many_q(be, q, dc, lay_tabs, lay_lens, lay_pts, net))
     f_top_commits, f_top_opens, top_proofs = [], None, []
     if top is not None:  # leader-only tail on the N_p-leaf top tree (:480-511)
         tt = np.asarray(top, dtype=np.uint64).reshape(-1, 4)
@@ -270,7 +275,7 @@ def _wiring_enqueue(n, pk, pp, be, net, seed, data_parallel, local_s_p, local_s_
         q.keep += dv
         d0, dd1, d1 = dv
         for f_, g_, m_ in ((eq_top, d1, len(lv1x)), (eq_top, d0, len(lvx0)), (d0, dd1, len(lvx0))):
-            top_proofs.append(dp.sumcheck_product_sq(be, sq, f_, g_, m_, chs) if one else (lambda r=dp.sumcheck_product(be, f_, g_, m_, chs): r))
+            top_proofs.append(dp.sumcheck_product_sq(be, sq, f_, g_, m_, chs) if one else _done(dp.sumcheck_product(be, f_, g_, m_, chs)))
 
     def phase_b():
         wiring_proofs.extend(a_2c())  # (one batch: pss2ss of 2.c)
