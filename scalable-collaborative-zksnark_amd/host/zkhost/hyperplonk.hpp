@@ -362,23 +362,28 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     };
     std::vector<FrVec> pts3(3, pk.challenge);
     std::vector<Opening> ops;
-    static const bool late_commit = [] {  // EXPERIMENT: the commit pass is started together with the two long passes
+    // Where the commit pass is started.  2 (default, one-batch schedule): right after the kernel batch of steps 2-4 -- the product tree
+    // and the batch then run on an empty chip instead of queueing behind the pass, and the GPU works on the pass during the hand-offs
+    // (n = 18: 27.5 -> 24.5 ms, 64 parties at n = 20: 22.8 -> 20.5 ms, neutral at n = 12, 16, 20 .. 24: profiles/r05z_late_commit2_ab.txt);
+    // 0: at step 1, as the reference orders it; 1: together with the two long passes (ZKHOST_LATE_COMMIT)
+    static const int late_commit = [] {
         const char *e = std::getenv("ZKHOST_LATE_COMMIT");
-        return e && std::atoi(e) != 0;
+        return e ? std::atoi(e) : 2;
     }();
+    static const bool one_batch = [] {  // the sumcheck-family kernels of steps 2-4 as ONE batch (pipeline.hpp ScQueue); ZKHOST_ONE_BATCH=0: a batch per call
+        const char *e = std::getenv("ZKHOST_ONE_BATCH");
+        return !e || std::atoi(e) != 0;
+    }();
+    const bool commit_at_step_1 = late_commit == 0 || (late_commit == 2 && !one_batch);
     if (serial_steps) {
         q.run();
         collect_commit();
-    } else if (!late_commit) {
+    } else if (commit_at_step_1) {
         q.start();
     }
     tm.mark("commit pass started");
     tm.end();
 
-    static const bool one_batch = [] {  // the sumcheck-family kernels of steps 2-4 as ONE batch (pipeline.hpp ScQueue); ZKHOST_ONE_BATCH=0: a batch per call
-        const char *e = std::getenv("ZKHOST_ONE_BATCH");
-        return !e || std::atoi(e) != 0;
-    }();
     if (one_batch && !serial_steps) {
         ScQueue sq(be);
         MsmQueue q_w(be), q_o(be);
@@ -394,12 +399,13 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
         auto a_do = d_open_many_sq(be, sq, q_o, dc, td, ld, pts3, net);
         sq.run();
         tm.mark("the batch ran");
+        if (late_commit == 2) q.start();
         out.gate_proofs = a_gate();
         auto finalize_wiring = b_wiring();
         auto f_co = a_co();
         auto f_do = a_do();
         tm.mark("hand-offs done");
-        if (late_commit) q.start();
+        if (late_commit == 1) q.start();
         q_w.start();
         tm.mark("wiring pass started");
         q_o.start();
@@ -460,7 +466,7 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
         auto f_co = c_open_many_q(be, q_o, cc, tc, lc, pts3, pp, net);
         auto f_do = d_open_many_q(be, q_o, dc, td, ld, pts3, net);
         tm.mark("open-step kernels done");
-        if (late_commit) q.start();
+        if (!commit_at_step_1) q.start();
         q_w.start();
         tm.mark("wiring pass started");
         q_o.start();

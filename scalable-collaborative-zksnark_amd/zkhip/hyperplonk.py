@@ -20,6 +20,7 @@ from .net import Net
 from .pss import PackedSharingParams
 
 ONE_BATCH = os.environ.get("ZKHIP_ONE_BATCH", "1") != "0"  # the sumcheck-family kernels of a proof's steps 2-4 as ONE batch (dp.ScQueue); 0: a batch per call
+LATE_COMMIT = os.environ.get("ZKHIP_LATE_COMMIT", "1") != "0"  # one-batch schedule: the commit pass starts after the kernel batch (zkhost: ZKHOST_LATE_COMMIT=2)
 CPERM_SERIAL = os.environ.get("ZKHIP_CPERM_SERIAL", "0") == "1"  # cpermcheck call by call as the reference writes it (A/B switch: same transcript)
 
 
@@ -328,7 +329,11 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
     # The timer labels keep the reference's names; with the overlap "Commit" / "Wire identity" / "Open" no longer cover the reference's
     # steps ("Wire identity" = the kernel phases of steps 2 and 4 and the enqueue of their passes, "Open" = the collection of both),
     # only "Distributed HyperPlonk" is comparable.
-    q.start()
+    # (with the one-batch schedule the pass is started right after the kernel batch of steps 2-4: the product tree and the batch then
+    # run on an empty chip instead of queueing behind it, and the GPU works on the pass during the hand-offs; LATE_COMMIT = False: here)
+    late = LATE_COMMIT and ONE_BATCH and dp.PIPELINE_MSM
+    if not late:
+        q.start()
 
     def finish_commit():
         q.finish()
@@ -359,6 +364,8 @@ def dhyperplonk(n: int, pk: PackedProvingParameters, pp: PackedSharingParams, be
         a_co = dp.c_open_many_sq(be, sq, q_o, cc, [T[x] for x in names_c], [L[x] for x in names_c], [pk.challenge] * 3, pp, net)
         a_do = dp.d_open_many_sq(be, sq, q_o, dc, [T[x] for x in names_d], [L[x] for x in names_d], [pk.challenge] * 3, net)
         sq.run()
+        if late:
+            q.start()
         gate_proofs = a_gate()
         finalize_wiring = b_wiring()
         f_co, f_do = a_co(), a_do()
