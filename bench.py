@@ -275,6 +275,8 @@ def parse_args():
     ap.add_argument("--cpu-e2e-n", type=int, default=13, help="log2 constraints of the CPU end-to-end sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="time the MSM without the SRS window table (zk_srs_precompute)")
+    ap.add_argument("--table-rec", type=int, default=128, choices=(96, 128),
+                    help="bytes per record of the G1 window tables of the MSM legs (library option srs_table_rec: 128 = one record per 128-B line, +33 %% table memory; 96 = packed, the library default, what the proof legs run on)")
     ap.add_argument("--no-extra", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (counter-collection runs)")
     ap.add_argument("--no-e2e-n24", action="store_true", help="skip the n = 24 end-to-end leg (C++ host, ~25 s)")
@@ -454,6 +456,10 @@ def run_rank(args, grp, gpu: int, ctx, net):
             c0 = ctx.lib.zk_msm_window(n)
             default_path = {"scalar_muls_per_s": world * n / dt0, "ms_per_step": dt0 * 1e3, "steps": 10, "pippenger_window_bits": c0, "windows": (129 + c0 - 1) // c0,
                             "k_accum_tiles_ms": float(ph0[1]) / 10, "note": "no window table: endomorphism split, 2n entries per window, one bucket set per window"}
+        # the MSM legs of this file build their tables with one record per 128-B line (the library's option srs_table_rec, see
+        # config.srs_window_table); the protocol legs below are set back to the library default (packed 96-B records) -- their
+        # parameter sets hold tables for ~40 levels and the proofs of 8 parties on one GPU / the checked n = 24 proof need the memory
+        ctx.dbg_tune("srs_table_rec", args.table_rec)
         t0 = time.perf_counter()
         srs.precompute(0)
         ctx.sync()
@@ -540,7 +546,8 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 "pippenger_window_bits": c,
                 "windows": windows,
                 "entries_per_window": per_window,
-                "srs_window_table": ({"window_bits": tc, "copies": windows, "bytes": windows * ((n + 3) & ~3) * 96, "build_s": precompute_s,
+                "srs_window_table": ({"window_bits": tc, "copies": windows, "bytes": windows * ((n + 3) & ~3) * args.table_rec, "record_bytes": args.table_rec,
+                                      "record_note": "library option srs_table_rec: 128 = one G1 record per 128-B line (the MSM legs of this line), 96 = packed (library default; the e2e / cpermcheck legs)", "build_s": precompute_s,
                                       "built": "once per SRS level, outside the timed region (zk_srs_precompute)"} if tc else None),
             },
             "rccl_ranks": rccl_ranks,  # = zk_comm_size of the in-ctx communicator (0: no RCCL communicator in this run)
@@ -609,6 +616,14 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 extra["e2e_n24"] = {"skipped": f"{free_b >> 30} GiB of HBM free, the n = 24 parameter set with its window tables and pass arenas wants ~{need_b >> 30} GiB"}
             else:
                 r24 = cpp_host_e2e(24, reps=2, check=True, serial_rep=True, timeout=1500)
+                # the driver returns the child's ~200 GiB of HBM asynchronously after its exit: wait until this process sees them again
+                # (an allocation of the next leg right behind the child's exit was refused once the tables grew to 128-B records)
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < 60.0:
+                    if ctx.mem_info()[0] >= free_b - (8 << 30):
+                        break
+                    time.sleep(0.25)
+                r24["hbm_back_after_s"] = time.perf_counter() - t_w
                 ref24 = 398458791  # SURVEY.md 8(d), derived from dhyperplonk.rs:198-553
                 comp24 = ref24 - (1 << 25)  # the two opens of V share their first quotient's commitment (computed once)
                 t24 = (r24.get("timers_s") or {}).get("Distributed HyperPlonk")
@@ -759,6 +774,7 @@ def run_rank(args, grp, gpu: int, ctx, net):
         except Exception as ex:  # the contract line must survive a failure of these legs
             extra["legs_error"] = repr(ex)
 
+        ctx.dbg_tune("srs_table_rec", 96)  # (the protocol legs run on the library default)
         # ---- end to end: collaborative HyperPlonk l = 1, n = 20 (BASELINE configs[3]) ----
         if world in (1, 8) and not args.no_e2e:
             try:

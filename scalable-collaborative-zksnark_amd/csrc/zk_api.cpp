@@ -23,7 +23,7 @@ static const TuneKey kTuneKeys[] = {
     {"msm_table_dc", &Tuning::msm_table_dc}, {"msm_qstep", &Tuning::msm_qstep}, {"msm_tile", &Tuning::msm_tile}, {"msm_pair", &Tuning::msm_pair},
     {"msm_fixq", &Tuning::msm_fixq}, {"msm_quad", &Tuning::msm_quad}, {"msm_stage", &Tuning::msm_stage}, {"msm_split", &Tuning::msm_split},
     {"msm_np", &Tuning::msm_np}, {"msm_debug", &Tuning::msm_debug}, {"msm_serial", &Tuning::msm_serial}, {"msm_size_classes", &Tuning::msm_size_classes},
-    {"g1_map_by_column", &Tuning::g1_map_by_column}, {"msm_share", &Tuning::msm_share}, {"msm_size_class_min", &Tuning::msm_size_class_min}, {"msm_small_table_widths", &Tuning::msm_small_table_widths},
+    {"g1_map_by_column", &Tuning::g1_map_by_column}, {"msm_share", &Tuning::msm_share}, {"srs_table_rec", &Tuning::srs_table_rec}, {"msm_size_class_min", &Tuning::msm_size_class_min}, {"msm_small_table_widths", &Tuning::msm_small_table_widths},
 };
 static Tuning g_tuning;
 int tune_set(const char* key, long value) {

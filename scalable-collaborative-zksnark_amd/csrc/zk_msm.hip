@@ -60,6 +60,12 @@ struct CvG1 {
     static constexpr bool kEndo = true;  // scalars split with the endomorphism, SRS holds phi(P_i) after P_i
     static constexpr bool kQuad = true;  // quad-lane fix-up / reduction kernels exist
     __device__ static __forceinline__ Aff aff_load(const void* b, size_t i) { return aff30_load(b, i); }
+    __device__ static __forceinline__ Aff aff_load_rec(const void* b, size_t i, u32 rec) {
+        Aff p;
+        p.x = f30_load(b, i * rec);
+        p.y = f30_load(b, i * rec + 48);
+        return p;
+    }
     __device__ static __forceinline__ Xyzz load(const void* b, size_t i) { return xyzz30_load(b, i); }
     __device__ static __forceinline__ void store(void* b, size_t i, const Xyzz& p) { xyzz30_store(b, i, p); }
     __device__ static __forceinline__ void set_inf(Xyzz& p) { xyzz30_set_inf(p); }
@@ -78,7 +84,7 @@ struct CvG1 {
     __device__ static __forceinline__ void add_quad(const void* in, size_t ia, size_t ib, void* out, size_t io, int role) { xyzz30_add_quad(in, ia, ib, out, io, role); }
     __device__ static __forceinline__ Xyzz acc_quad(const Xyzz& acc, const void* in, size_t ib, int role) { return xyzz30_acc_quad(acc, in, ib, role); }
     // the affine image of acc as one record of the window table (canonical coordinates, like every SRS coordinate)
-    __device__ static __forceinline__ void table_store(const Xyzz& acc, void* table, size_t idx) {
+    __device__ static __forceinline__ void table_store(const Xyzz& acc, void* table, size_t idx, u32 rec) {
         Aff30 a;
         if (xyzz30_is_inf(acc)) {
             a.x = f30_zero();
@@ -89,8 +95,8 @@ struct CvG1 {
             a.x = f30_canon8(f30_mul(acc.x, f30_sqr(iz)));  // X/Z^2
             a.y = f30_canon8(f30_mul(acc.y, i3));           // Y/Z^3
         }
-        f30_store(table, idx * 96, a.x);
-        f30_store(table, idx * 96 + 48, a.y);
+        f30_store(table, idx * rec, a.x);
+        f30_store(table, idx * rec + 48, a.y);
     }
     // (X*ZZ, Y*ZZZ, ZZ) is a Jacobian representative; written in the REFERENCE Montgomery form
     __device__ static __forceinline__ void finish(const Xyzz& acc, void* out, size_t t) {
@@ -113,6 +119,7 @@ struct CvG2 {
     static constexpr bool kEndo = false;
     static constexpr bool kQuad = true;
     __device__ static __forceinline__ Aff aff_load(const void* b, size_t i) { return aff2_load(b, i); }
+    __device__ static __forceinline__ Aff aff_load_rec(const void* b, size_t i, u32 /*rec*/) { return aff_load(b, i); }
     __device__ static __forceinline__ Xyzz load(const void* b, size_t i) { return xyzz2_load(b, i); }
     __device__ static __forceinline__ void store(void* b, size_t i, const Xyzz& p) { xyzz2_store(b, i, p); }
     __device__ static __forceinline__ void set_inf(Xyzz& p) { xyzz2_set_inf(p); }
@@ -129,7 +136,7 @@ struct CvG2 {
     }
     __device__ static __forceinline__ void add_quad(const void* in, size_t ia, size_t ib, void* out, size_t io, int role) { xyzz2_add_quad(in, ia, ib, out, io, role); }
     __device__ static __forceinline__ Xyzz acc_quad(const Xyzz& acc, const void* in, size_t ib, int role) { return xyzz2_acc_quad(acc, in, ib, role); }
-    __device__ static __forceinline__ void table_store(const Xyzz& acc, void* table, size_t idx) {
+    __device__ static __forceinline__ void table_store(const Xyzz& acc, void* table, size_t idx, u32 /*rec: always kAffBytes*/) {
         Fq2x x = f2_zero(), y = f2_zero();
         if (!xyzz2_is_inf(acc)) {
             // 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2)
@@ -223,6 +230,7 @@ struct ItemDesc {
     u32 n;
     u32 pstride;  // a row holds several copies of the point range: entry v -> bases[(v / ns) * pstride + v % ns]
                   // (copy 1 = the endomorphism images phi(P_i); precomputed table: copy w = 2^{offset(w)} P_i)
+    u32 rec;      // bytes between two records of `bases` (kAffBytes; a G1 window table may hold 128-B aligned records: zk_srs::table_rec)
 };
 
 // GLV split for BLS12-381 G1: lambda = z^2 - 1 (z the curve parameter) satisfies lambda^2 + lambda + 1 = 0
@@ -676,7 +684,7 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
     typename Cv::Xyzz acc;
     Cv::set_inf(acc);
     u32 v = run[e0];
-    typename Cv::Aff p = Cv::aff_load(bases, pidx(v));
+    typename Cv::Aff p = Cv::aff_load_rec(bases, pidx(v), it.rec);
     for (u32 e = e0; e < e1; e++) {
         if (e == bend) {  // run finished: flush and move to the next non-empty bucket
             if (ps == bstart) Cv::store(buckets, w * nb + b, acc);  // whole bucket
@@ -694,7 +702,7 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
         typename Cv::Aff cur = p;
         if (e + 1 < e1) {  // prefetch the next point while this one is being added
             v = run[e + 1];
-            p = Cv::aff_load(bases, pidx(v));
+            p = Cv::aff_load_rec(bases, pidx(v), it.rec);
         }
         Cv::madd(acc, cur, neg);
     }
@@ -901,7 +909,7 @@ static __global__ void __launch_bounds__(64) k_finish(const void* __restrict__ i
 // With it every window's digit can use the SAME bucket set (the factor 2^{c w} is in the base).
 template <class Cv>
 static __global__ void __launch_bounds__(Cv::kEndo ? kBlk : 64) k_precompute(const void* __restrict__ bases, size_t n, size_t nsr, WinLayout L,
-                                                                       void* __restrict__ table) {
+                                                                       void* __restrict__ table, u32 rec) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const typename Cv::Aff p = Cv::aff_load(bases, i);
@@ -911,7 +919,7 @@ static __global__ void __launch_bounds__(Cv::kEndo ? kBlk : 64) k_precompute(con
     for (int w = 0; w < L.W; w++) {
         if (w > 0)
             for (int k = 0; k < L.width(w - 1); k++) acc = Cv::dbl(acc);
-        Cv::table_store(acc, table, (size_t)w * nsr + i);
+        Cv::table_store(acc, table, (size_t)w * nsr + i, rec);
     }
 }
 
@@ -1496,7 +1504,8 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         for (size_t j = 0; j < nitems; j++) {
             const MsmItem& it = items[cl.idx[j]];
             h_items[j].scalars = it.d_scalars;
-            h_items[j].bases = (const char*)(cl.shared ? it.srs->d_table : it.srs->d_bases) + it.offset * Cv::kAffBytes;
+            h_items[j].rec = cl.shared ? (u32)it.srs->table_rec : (u32)Cv::kAffBytes;
+            h_items[j].bases = (const char*)(cl.shared ? it.srs->d_table : it.srs->d_bases) + it.offset * (size_t)h_items[j].rec;
             h_items[j].n = (u32)it.n;
             h_items[j].pstride = cl.shared ? (u32)it.srs->table_stride : (Cv::kEndo ? (u32)it.srs->n : 0u);  // phi(P_i) sits n points after P_i
         }
@@ -1682,7 +1691,7 @@ int msm_g2_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
 // the G2 half of srs_precompute: table[w][i] = 2^{bit_offset(w)} P_i for a G2 level
 int srs_precompute_table_g2(zk_ctx* ctx, const zk_srs* srs, int c, size_t nsr, void* d_table) {
     const WinLayout L = msm_layout(c, kFullBits);
-    hipLaunchKernelGGL((k_precompute<CvG2>), dim3((unsigned)((srs->n + 63) / 64)), dim3(64), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr, L, d_table);
+    hipLaunchKernelGGL((k_precompute<CvG2>), dim3((unsigned)((srs->n + 63) / 64)), dim3(64), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr, L, d_table, (u32)CvG2::kAffBytes);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
@@ -1887,7 +1896,12 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     if (srs->n == 0) return ZK_OK;
     const WinLayout L = msm_layout(c, kFullBits);
     const size_t nsr = (srs->n + 3) & ~(size_t)3;
-    const size_t rec = srs->g2 ? CvG2::kAffBytes : CvG1::kAffBytes;
+    // A G1 point is 96 B.  Packed (the default), two records of three straddle a 128-B line and a gather of the accumulation moves 1.67
+    // lines on average; with the tuning knob srs_table_rec = 128 the table holds one record per 128-B line (+33 % table memory).
+    // Measured (profiles/r05zb_table_rec_ab.txt): k_accum_tiles at 2^20 2.04-2.14 -> 1.90-1.91 ms, the 2^20 MSM 3.57-3.70e8 -> 3.82-3.84e8
+    // scalar-muls/s, 2^24 4.69 -> 4.80e8, n = 24 proof 0.815 -> 0.793 s.  It is an OPTION because the memory is not free everywhere: with it
+    // the 8-party n = 20 proof on ONE GPU and the n = 24 proof with --check run the device out of resources (bench.py's MSM legs switch it on).
+    const size_t rec = srs->g2 ? CvG2::kAffBytes : (tuning().srs_table_rec == 128 ? (size_t)128 : CvG1::kAffBytes);
     ZK_HIP(ctx, device_alloc(ctx, &srs->d_table, (size_t)L.W * nsr * rec));
     ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * rec, ctx->stream));
     if (srs->g2) {
@@ -1895,12 +1909,13 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
         if (rc) return rc;
     } else {
         hipLaunchKernelGGL((k_precompute<CvG1>), dim3((unsigned)((srs->n + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr,
-                           L, srs->d_table);
+                           L, srs->d_table, (u32)rec);
     }
     ZK_HIP(ctx, hipGetLastError());
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     srs->table_c = c;
     srs->table_stride = nsr;
+    srs->table_rec = rec;
     return ZK_OK;
 }
 
