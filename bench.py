@@ -276,7 +276,7 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="time the MSM without the SRS window table (zk_srs_precompute)")
     ap.add_argument("--table-rec", type=int, default=128, choices=(96, 128),
-                    help="bytes per record of the G1 window tables of the MSM legs (library option srs_table_rec: 128 = one record per 128-B line, +33 %% table memory; 96 = packed, the library default, what the proof legs run on)")
+                    help="bytes per record of the G1 window tables of the MSM legs (zk_srs_precompute_layout: 128 = one record per 128-B line, +33 %% table memory; 96 = packed, the library default, what the proof legs run on)")
     ap.add_argument("--no-extra", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (counter-collection runs)")
     ap.add_argument("--no-e2e-n24", action="store_true", help="skip the n = 24 end-to-end leg (C++ host, ~25 s)")
@@ -456,12 +456,11 @@ def run_rank(args, grp, gpu: int, ctx, net):
             c0 = ctx.lib.zk_msm_window(n)
             default_path = {"scalar_muls_per_s": world * n / dt0, "ms_per_step": dt0 * 1e3, "steps": 10, "pippenger_window_bits": c0, "windows": (129 + c0 - 1) // c0,
                             "k_accum_tiles_ms": float(ph0[1]) / 10, "note": "no window table: endomorphism split, 2n entries per window, one bucket set per window"}
-        # the MSM legs of this file build their tables with one record per 128-B line (the library's option srs_table_rec, see
-        # config.srs_window_table); the protocol legs below are set back to the library default (packed 96-B records) -- their
-        # parameter sets hold tables for ~40 levels and the proofs of 8 parties on one GPU / the checked n = 24 proof need the memory
-        ctx.dbg_tune("srs_table_rec", args.table_rec)
+        # the MSM legs of this file build their tables with one record per 128-B line (zk_srs_precompute_layout, see
+        # config.srs_window_table); the protocol legs below run on the library default (packed 96-B records) -- their parameter
+        # sets hold tables for ~40 levels and the proofs of 8 parties on one GPU / the checked n = 24 proof need the memory
         t0 = time.perf_counter()
-        srs.precompute(0)
+        srs.precompute(0, record_bytes=args.table_rec)
         ctx.sync()
         precompute_s = time.perf_counter() - t0
     for _ in range(args.warmup):
@@ -547,7 +546,7 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 "windows": windows,
                 "entries_per_window": per_window,
                 "srs_window_table": ({"window_bits": tc, "copies": windows, "bytes": windows * ((n + 3) & ~3) * args.table_rec, "record_bytes": args.table_rec,
-                                      "record_note": "library option srs_table_rec: 128 = one G1 record per 128-B line (the MSM legs of this line), 96 = packed (library default; the e2e / cpermcheck legs)", "build_s": precompute_s,
+                                      "record_note": "zk_srs_precompute_layout: 128 = one G1 record per 128-B line (the MSM legs of this line), 96 = packed (what zk_srs_precompute builds; the e2e / cpermcheck legs)", "build_s": precompute_s,
                                       "built": "once per SRS level, outside the timed region (zk_srs_precompute)"} if tc else None),
             },
             "rccl_ranks": rccl_ranks,  # = zk_comm_size of the in-ctx communicator (0: no RCCL communicator in this run)
@@ -644,7 +643,7 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 per = (1 << lg) // world
                 s_srs = ctx.srs_generate(0xABCDE, 0x13579, 1 << lg) if world == 1 else ctx.srs_generate(0xABCDE + per * rank * 0x13579, 0x13579, per)
                 if not args.no_precompute:
-                    s_srs.precompute(0)  # (setup, like the headline's)
+                    s_srs.precompute(0, record_bytes=args.table_rec)  # (setup, like the headline's)
                 s_sc = device_table(ctx, max(lg - (world.bit_length() - 1), 0), 77 + rank)
                 fn = (lambda: ctx.msm_g1(s_srs, s_sc, per)) if world == 1 else (lambda: sh.sharded_msm(ctx, s_srs, s_sc, per, net))
                 fn()
@@ -774,7 +773,6 @@ def run_rank(args, grp, gpu: int, ctx, net):
         except Exception as ex:  # the contract line must survive a failure of these legs
             extra["legs_error"] = repr(ex)
 
-        ctx.dbg_tune("srs_table_rec", 96)  # (the protocol legs run on the library default)
         # ---- end to end: collaborative HyperPlonk l = 1, n = 20 (BASELINE configs[3]) ----
         if world in (1, 8) and not args.no_e2e:
             try:

@@ -188,10 +188,16 @@ int zk_g1_apply_matrix(zk_ctx *ctx, const uint64_t *h_matrix, size_t rows, size_
 /* Optional, once per SRS level (setup, like uploading it): build the table 2^{o_w} * P_i for every
  * window offset o_w of a `window_bits`-wide signed-digit decomposition (0 = pick for the level's
  * length).  MSMs on this SRS then use ONE bucket set for all windows: 1/W of the bucket-reduction
- * and fix-up work and no cross-window doubling chain.  Costs W x the level's memory (W ~ 14-22 copies).  Option (tuning key
- * "srs_table_rec" = 128 before the call): G1 records padded from 96 to 128 bytes, one per cache line -- the accumulation's
- * gathers then move one line each (2^20 MSM +4-7 %) for 4/3 of the table memory. */
+ * and fix-up work and no cross-window doubling chain.  Costs W x the level's memory (W ~ 14-22 copies).  See
+ * zk_srs_precompute_layout for G1 records padded from 96 to 128 bytes, one per cache line: the accumulation's gathers then
+ * move one line each (2^20 MSM +4-7 %) for 4/3 of the table memory. */
 int zk_srs_precompute(zk_ctx *ctx, zk_srs *srs, int window_bits);
+/* The same with the record layout of a G1 table chosen by the caller: record_bytes = 96 (packed: what zk_srs_precompute builds),
+ * 128 (one record per 128-byte cache line) or 0 (the default).  Same MSM results; 128 wants 4/3 of the table memory.  G2 levels
+ * ignore it (192-byte records).  ZK_ERR_INVALID for any other value. */
+int zk_srs_precompute_layout(zk_ctx *ctx, zk_srs *srs, int window_bits, int record_bytes);
+/* bytes per record of the level's table (0: none built) */
+int zk_srs_table_record(const zk_srs *srs);
 /* window bits of the level's table (0: none built) -- the MSMs on it insert ceil(256 / bits) digits per scalar */
 int zk_srs_table_window(const zk_srs *srs);
 int zk_srs_free(zk_ctx *ctx, zk_srs *srs);

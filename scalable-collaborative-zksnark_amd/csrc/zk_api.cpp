@@ -403,8 +403,14 @@ int zk_g1_apply_matrix(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows, size_
 }
 int zk_srs_precompute(zk_ctx* ctx, zk_srs* srs, int window_bits) {
     NEED(ctx, srs);
-    return srs_precompute(ctx, srs, window_bits);
+    return srs_precompute(ctx, srs, window_bits, 0);
 }
+int zk_srs_precompute_layout(zk_ctx* ctx, zk_srs* srs, int window_bits, int record_bytes) {
+    NEED(ctx, srs);
+    if (record_bytes != 0 && record_bytes != 96 && record_bytes != 128) return fail(ctx, ZK_ERR_INVALID, "zk_srs_precompute_layout: record_bytes must be 0 (default), 96 or 128");
+    return srs_precompute(ctx, srs, window_bits, record_bytes);
+}
+int zk_srs_table_record(const zk_srs* srs) { return (srs && srs->d_table) ? (int)srs->table_rec : 0; }
 int zk_srs_free(zk_ctx* ctx, zk_srs* srs) {
     if (!srs) return ZK_OK;
     if (srs->d_table) {

@@ -167,7 +167,7 @@ int msm_g2_batch(zk_ctx* ctx, const MsmItem* items, size_t count, uint64_t* h_ou
 int srs_pack_g2(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
 int msm_g1(zk_ctx* ctx, const zk_srs* srs, size_t offset, const void* d_scalars, size_t n, uint64_t* h_out);
 int srs_pack(zk_ctx* ctx, const void* h_bases, size_t stride, size_t n, zk_srs** out);
-int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c);
+int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c, int record_bytes);  // record_bytes 0: the default (tuning knob srs_table_rec)
 void msm_host_pool_destroy(zk_ctx* ctx);
 int srs_from_device(zk_ctx* ctx, const void* d_bases96, size_t n, zk_srs** out);
 int srs_download(zk_ctx* ctx, const zk_srs* srs, void* h_out96);

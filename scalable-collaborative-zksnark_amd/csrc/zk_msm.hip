@@ -1883,7 +1883,7 @@ static int msm_pick_window_full_g2(size_t n) {
 }
 
 int srs_precompute_table_g2(zk_ctx* ctx, const zk_srs* srs, int c, size_t nsr, void* d_table);  // zk_msm.hip built with -DZK_MSM_TU_G2
-int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
+int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c, int record_bytes) {
     if (!srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
     if (c == 0) c = srs->g2 ? msm_pick_window_full_g2(srs->n ? srs->n : 1) : msm_pick_window_full(srs->n ? srs->n : 1);
     if (c < 2 || c > 20) return fail(ctx, ZK_ERR_INVALID, "window bits out of range");
@@ -1897,11 +1897,12 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c) {
     const WinLayout L = msm_layout(c, kFullBits);
     const size_t nsr = (srs->n + 3) & ~(size_t)3;
     // A G1 point is 96 B.  Packed (the default), two records of three straddle a 128-B line and a gather of the accumulation moves 1.67
-    // lines on average; with the tuning knob srs_table_rec = 128 the table holds one record per 128-B line (+33 % table memory).
+    // lines on average; zk_srs_precompute_layout(.., 128) -- or the process-wide knob srs_table_rec -- builds one record per 128-B line (+33 % table memory).
     // Measured (profiles/r05zb_table_rec_ab.txt): k_accum_tiles at 2^20 2.04-2.14 -> 1.90-1.91 ms, the 2^20 MSM 3.57-3.70e8 -> 3.82-3.84e8
     // scalar-muls/s, 2^24 4.69 -> 4.80e8, n = 24 proof 0.815 -> 0.793 s.  It is an OPTION because the memory is not free everywhere: with it
     // the 8-party n = 20 proof on ONE GPU and the n = 24 proof with --check run the device out of resources (bench.py's MSM legs switch it on).
-    const size_t rec = srs->g2 ? CvG2::kAffBytes : (tuning().srs_table_rec == 128 ? (size_t)128 : CvG1::kAffBytes);
+    const long want_rec = record_bytes ? (long)record_bytes : tuning().srs_table_rec;  // (zk_srs_precompute_layout, or the process-wide default)
+    const size_t rec = srs->g2 ? CvG2::kAffBytes : (want_rec == 128 ? (size_t)128 : CvG1::kAffBytes);
     ZK_HIP(ctx, device_alloc(ctx, &srs->d_table, (size_t)L.W * nsr * rec));
     ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * rec, ctx->stream));
     if (srs->g2) {

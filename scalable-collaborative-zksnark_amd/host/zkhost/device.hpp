@@ -274,7 +274,9 @@ class Ctx {
         check(zk_srs_to_packed(h_, level.handle(), row_canonical[0].v, l, &s));
         return std::make_shared<Srs>(ref_, s);
     }
-    void srs_precompute(Srs &s, int window_bits = 0) { check(zk_srs_precompute(h_, s.handle(), window_bits)); }
+    void srs_precompute(Srs &s, int window_bits = 0, int record_bytes = 0) {  // record_bytes: 0 / 96 packed (default), 128 = one G1 record per cache line
+        check(record_bytes ? zk_srs_precompute_layout(h_, s.handle(), window_bits, record_bytes) : zk_srs_precompute(h_, s.handle(), window_bits));
+    }
 
     // ---- MSM ----
     G1 msm_g1(const Srs &srs, const DevPtr &scalars, size_t n, size_t offset = 0) {

@@ -52,7 +52,9 @@ SYMBOLS = [
     ("zk_srs_to_packed", _i, [_vp, _vp, _vp, _sz, _pp]),
     ("zk_g1_apply_matrix", _i, [_vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _sz]),
     ("zk_srs_precompute", _i, [_vp, _vp, _i]),
+    ("zk_srs_precompute_layout", _i, [_vp, _vp, _i, _i]),
     ("zk_srs_table_window", _i, [_vp]),
+    ("zk_srs_table_record", _i, [_vp]),
     ("zk_srs_free", _i, [_vp, _vp]),
     ("zk_srs_len", _sz, [_vp]),
     ("zk_srs_device_ptr", _vp, [_vp]),

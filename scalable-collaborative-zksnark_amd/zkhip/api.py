@@ -126,10 +126,19 @@ class Srs:
     def device_ptr(self) -> int:
         return self.ctx.lib.zk_srs_device_ptr(self.h) or 0
 
-    def precompute(self, window_bits: int = 0):
-        """build the per-window tables (setup): MSMs on this SRS then share one bucket set"""
-        self.ctx._check(self.ctx.lib.zk_srs_precompute(self.ctx.h, self.h, window_bits))
+    def precompute(self, window_bits: int = 0, record_bytes: int = 0):
+        """build the per-window tables (setup): MSMs on this SRS then share one bucket set.  record_bytes (G1): 96 packed (the default),
+        128 = one record per 128-byte line (faster gathers, 4/3 of the table memory)"""
+        if record_bytes:
+            self.ctx._check(self.ctx.lib.zk_srs_precompute_layout(self.ctx.h, self.h, window_bits, record_bytes))
+        else:
+            self.ctx._check(self.ctx.lib.zk_srs_precompute(self.ctx.h, self.h, window_bits))
         return self
+
+    @property
+    def table_record(self) -> int:
+        """bytes per record of the precomputed table, 0 if none"""
+        return self.ctx.lib.zk_srs_table_record(self.h)
 
     @property
     def table_window(self) -> int:

@@ -181,6 +181,30 @@ def test_msm_batch_matches_individual(ctx, co):
     assert (jac_norm_to_affine(got[1]) == co.msm_g1(bases[1024:1536], sc[1024:1536])).all()
 
 
+def test_window_table_record_layouts_give_the_same_points(ctx):
+    """zk_srs_precompute_layout: packed 96-byte records (what zk_srs_precompute builds) and one record per 128-byte line -- same MSM
+    results with and without the table, also for a sub-range of the level and in a batch that mixes both layouts; bad values are refused"""
+    import zkhip
+
+    n = 1 << 13
+    srs_a, srs_b = ctx.srs_generate(321, 654, n), ctx.srs_generate(321, 654, n)
+    sc = ctx.to_device(rand_fr(n, 77))
+    ref = ctx.msm_g1(srs_a, sc, n)
+    ref_sub = ctx.msm_g1(srs_a, sc, 1000, offset=123)
+    srs_a.precompute(0, record_bytes=96)
+    srs_b.precompute(0, record_bytes=128)
+    assert srs_a.table_record == 96 and srs_b.table_record == 128 and srs_a.table_window == srs_b.table_window > 0
+    for srs in (srs_a, srs_b):
+        assert (ctx.msm_g1(srs, sc, n) == ref).all()
+        assert (ctx.msm_g1(srs, sc, 1000, offset=123) == ref_sub).all()
+    got = ctx.msm_g1_batch([srs_a, srs_b, srs_b], [sc, sc, sc], [n, n, 1000])
+    assert (got[0] == ref).all() and (got[1] == ref).all() and (got[2] == ctx.msm_g1(srs_a, sc, 1000)).all()
+    with pytest.raises(zkhip.ZkError):
+        srs_a.precompute(0, record_bytes=100)
+    srs_b.precompute(0)  # (rebuilt in the default layout)
+    assert srs_b.table_record == 96 and (ctx.msm_g1(srs_b, sc, n) == ref).all()
+
+
 def test_msm_batch_of_window_table_items_of_many_sizes(ctx, co):
     """
     the short items of a proof's passes (dpoly_comm.rs:401-464: an open commits quotients of 2^k, 2^(k-1), .. points): levels of
