@@ -209,8 +209,9 @@ int main(int argc, char **argv) {
         else if (k == "--share-gpus") a.share_gpus = true;  // --mode rccl with fewer GPUs than parties: only the test double of librccl accepts it
         else if (k == "--tamper") a.check = a.tamper = true;
         else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
+        else if (k == "--table-rec") setenv("ZKHOST_TABLE_REC", val(), 1);  // 128: one G1 table record per cache line (4/3 of the table memory)
         else {
-            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--digest] [--check] [--tamper] [--serial-rep]\n");
+            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--table-rec 96|128] [--digest] [--check] [--tamper] [--serial-rep]\n");
             return 64;
         }
     }

@@ -119,15 +119,21 @@ struct PackedProvingParameters {
         std::vector<SrsPtr> all = c_commitment;
         all.insert(all.end(), d_commitment.begin(), d_commitment.end());
         std::stable_sort(all.begin(), all.end(), [](const SrsPtr &a, const SrsPtr &b) { return a->len() < b->len(); });
+        // ZKHOST_TABLE_REC=128: G1 table records of 128 bytes, one per cache line (zk_srs_precompute_layout): n = 20 / 24 proofs -1.3 / -2.7 %
+        // for 4/3 of the table memory -- an opt-in: a GPU shared by several parties, or the n = 24 proof with its self-check, do not have it
+        static const int table_rec = [] {
+            const char *e = std::getenv("ZKHOST_TABLE_REC");
+            return e ? std::atoi(e) : 0;
+        }();
         for (auto &lv : all) {  // largest levels last: the ones without a table simply use the table-less path
             size_t len = lv->len();
             if (len < 64 || len > (size_t(1) << table_max_log2)) continue;
             if (len > (size_t(1) << 22)) {
                 size_t fr = 0, tot = 0;
                 be.check(zk_mem_info(be.handle(), &fr, &tot));
-                if ((double)fr - 16.0 * 96.0 * (double)len < 0.4 * (double)tot) break;
+                if ((double)fr - 16.0 * (table_rec == 128 ? 128.0 : 96.0) * (double)len < 0.4 * (double)tot) break;
             }
-            int rc = zk_srs_precompute(be.handle(), lv->handle(), window_bits ? window_bits(len) : 0);
+            int rc = zk_srs_precompute_layout(be.handle(), lv->handle(), window_bits ? window_bits(len) : 0, table_rec == 128 ? 128 : 0);
             if (rc == ZK_ERR_OOM) break;
             be.check(rc);
         }

@@ -21,6 +21,7 @@ from .pss import PackedSharingParams
 
 ONE_BATCH = os.environ.get("ZKHIP_ONE_BATCH", "1") != "0"  # the sumcheck-family kernels of a proof's steps 2-4 as ONE batch (dp.ScQueue); 0: a batch per call
 LATE_COMMIT = os.environ.get("ZKHIP_LATE_COMMIT", "1") != "0"  # one-batch schedule: the commit pass starts after the kernel batch (zkhost: ZKHOST_LATE_COMMIT=2)
+TABLE_REC = int(os.environ.get("ZKHIP_TABLE_REC", "0"))  # 128: G1 window-table records of 128 bytes, one per cache line (zk_srs_precompute_layout; 4/3 of the table memory)
 CPERM_SERIAL = os.environ.get("ZKHIP_CPERM_SERIAL", "0") == "1"  # cpermcheck call by call as the reference writes it (A/B switch: same transcript)
 
 
@@ -139,10 +140,10 @@ class PackedProvingParameters:
                 if hasattr(lv, "precompute") and 64 <= len(lv) <= (1 << table_max_log2):
                     if hasattr(be, "mem_info") and len(lv) > (1 << 22):
                         free, total = be.mem_info()
-                        if free - 16 * 96 * len(lv) < 0.4 * total:
+                        if free - 16 * (TABLE_REC or 96) * len(lv) < 0.4 * total:
                             break
                     try:
-                        lv.precompute(0)
+                        lv.precompute(0, record_bytes=TABLE_REC)
                     except Exception as e:
                         if getattr(e, "code", None) != -6:  # ZK_ERR_OOM: keep going without the remaining tables
                             raise
