@@ -302,3 +302,33 @@ def test_l2_sixteen_parties_gpu_matches_oracle_backed_run(fn_name):
     got = _run_l2(lambda: zkhip.Ctx(0), n, fn_name)
     for p in (0, 1, 15):
         assert _digest(got[p]) == _digest(exp[p]), f"{fn_name}: party {p}"
+
+
+def test_sc_queue_two_phase_forms_cpu():
+    """dp.ScQueue (the mirror of zkhost/pipeline.hpp): a result cannot be read before the batch ran; the two-phase open equals the
+    one-call form; the same table at the same point twice is ONE request whose MSM items the queue computes once"""
+    from zkhip import dist_primitive as dp
+    from zkhip.field import random_fr
+    from zkhip.net import LeaderEchoNet
+
+    be = OracleBackend()
+    pp = PackedSharingParams(1)
+    net = LeaderEchoNet(pp.n)
+    n = 4
+    length = 1 << n
+    pc = dp.PolynomialCommitmentCub.new_single(be, n + 1, pp, seed=5)
+    tab, other = be.to_device(random_fr(length, 31)), be.to_device(random_fr(length, 32))
+    pt = random_fr(n + 3, 33)
+    sq, q = dp.ScQueue(be), dp.MsmQueue(be)
+    phase_b = dp.c_open_many_sq(be, sq, q, pc.powers_of_g, [tab, other, tab], [length] * 3, [pt, pt, pt], pp, net)
+    assert len(sq.reqs) == 2  # (tab, pt) twice -> one request
+    with pytest.raises(RuntimeError):
+        sq.at(0)
+    sq.run()
+    fin = phase_b()
+    assert len(q.lens) == 2 * n  # the repeated open's items are the first one's
+    q.run()
+    got = fin()
+    exp = dp.c_open_many(be, pc.powers_of_g, [tab, other], [length] * 2, [pt, pt], pp, net)
+    for g, e in zip(got, [exp[0], exp[1], exp[0]]):
+        assert (g[0] == e[0]).all() and (g[1] == e[1]).all()
