@@ -484,6 +484,39 @@ class Radix2Domain:
 
 
 _G1_OPS = dict(zero=None, add=g1_add, scale=g1_mul)
+_G1_MSM = [g1_msm]  # the MSM the protocol-level restatements call (see g1_backend)
+
+
+def _msm(bases, scalars) -> Point:
+    return _G1_MSM[0](bases, scalars)
+
+
+class g1_backend:
+    """
+    `with g1_backend(msm=..., add=..., mul=...):` -- run the protocol-level restatements below with another implementation of
+    the three group operations (same signatures as g1_msm / g1_add / g1_mul on affine int points).  The tests pass the plain-C
+    port (oracle/zk_oracle.c, itself checked against this file in tests/test_oracle_c.py) so that a whole 8- or 16-party proof
+    finishes in seconds; every output is a canonical affine point, so the choice cannot change a result.
+    """
+
+    def __init__(self, msm=None, add=None, mul=None):
+        self.new = (msm or g1_msm, add or g1_add, mul or g1_mul)
+
+    def __enter__(self):
+        self.old = (_G1_MSM[0], _G1_OPS["add"], _G1_OPS["scale"])
+        _G1_MSM[0], _G1_OPS["add"], _G1_OPS["scale"] = self.new
+        return self
+
+    def __exit__(self, *exc):
+        _G1_MSM[0], _G1_OPS["add"], _G1_OPS["scale"] = self.old
+        return False
+
+
+def _g1_sum(points: Sequence[Point]) -> Point:
+    acc = None
+    for P in points:
+        acc = _G1_OPS["add"](acc, P)
+    return acc
 
 
 class PackedSharingParams:
@@ -558,11 +591,11 @@ def d_msm_all(bases: Sequence[Sequence[Sequence[Point]]], scalars, pp: PackedSha
     dmsm.rs:9-43.  bases[p][k] / scalars[p][k] = party p's k-th batch item.
     Returns result[p][k] = party p's share of MSM k.
     """
-    c_shares = [[g1_msm(b, s) for b, s in zip(bases[p], scalars[p])] for p in range(pp.n)]
+    c_shares = [[_msm(b, s) for b, s in zip(bases[p], scalars[p])] for p in range(pp.n)]
     per_item = transpose(c_shares)  # dmsm.rs:30
     results = []
     for s in per_item:
-        output = g1_sum(pp.unpack2_g1(s))  # :34-35
+        output = _g1_sum(pp.unpack2_g1(s))  # :34-35
         results.append(pp.pack_from_public_g1([output] * pp.l))  # :36-37
     return transpose(results)  # :39
 
@@ -707,7 +740,7 @@ def commit(powers_of_g, peval) -> Point:
     """dpoly_comm.rs:237-243 (= d_local_commit :269-275)"""
     level = len(peval).bit_length() - 1
     assert level < len(powers_of_g) and len(peval) == 1 << level
-    return g1_msm(powers_of_g[level], peval)
+    return _msm(powers_of_g[level], peval)
 
 
 def open_(powers_of_g, peval, point):
@@ -723,19 +756,28 @@ def open_(powers_of_g, peval, point):
     return cur[0], result
 
 
+class PerParty(list):
+    """marks an SRS argument of the *_all forms as one SRS PER PARTY (the parties of a test run may hold different synthetic
+    parameter sets); a plain list of levels is one SRS shared by all parties"""
+
+
+def _srs(powers_of_g, p: int):
+    return powers_of_g[p] if isinstance(powers_of_g, PerParty) else powers_of_g
+
+
 def d_commit_all(powers_of_g, pevals) -> Point:
     """dpoly_comm.rs:276-297: every party ends with the sum of local commitments"""
-    return g1_sum([commit(powers_of_g, p) for p in pevals])
+    return _g1_sum([commit(_srs(powers_of_g, p), pv) for p, pv in enumerate(pevals)])
 
 
 def d_open_all(powers_of_g, pevals, point):
     """dpoly_comm.rs:355-398: leader's (value, proofs); root proofs first"""
     np_ = len(pevals)
     plog = np_.bit_length() - 1
-    local = [open_(powers_of_g, p, point[plog:]) for p in pevals]
+    local = [open_(_srs(powers_of_g, p), pv, point[plog:]) for p, pv in enumerate(pevals)]
     local_z = [lo[0] for lo in local]
-    pi = [g1_sum([local[p][1][i] for p in range(np_)]) for i in range(len(local[0][1]))]
-    root = open_(powers_of_g, local_z, point[:plog])
+    pi = [_g1_sum([local[p][1][i] for p in range(np_)]) for i in range(len(local[0][1]))]
+    root = open_(_srs(powers_of_g, 0), local_z, point[:plog])  # the leader's own SRS (:372-378)
     return root[0], list(root[1]) + pi
 
 
@@ -754,7 +796,7 @@ def c_open_all(powers_of_g, pevals, point, pp: PackedSharingParams):
         qs.append(res)
         lasts.append(cur[0])
     # c_commit (:244-267): bases level = log2(len * l)
-    bases = [[powers_of_g[(len(q) * pp.l).bit_length() - 1] for q in qs[p]] for p in range(pp.n)]
+    bases = [[_srs(powers_of_g, p)[(len(q) * pp.l).bit_length() - 1] for q in qs[p]] for p in range(pp.n)]
     res = d_msm_all(bases, qs, pp)
     ss = pss2ss_all(lasts, pp)
     out = []
@@ -765,7 +807,7 @@ def c_open_all(powers_of_g, pevals, point, pp: PackedSharingParams):
             h = len(cur) // 2
             q = [(cur[j + h] - cur[j]) % R_MOD for j in range(h)]
             level = (len(q) * pp.l).bit_length() - 1
-            proofs.append(g1_msm(powers_of_g[level], q))
+            proofs.append(_msm(_srs(powers_of_g, p)[level], q))
             cur = fold(cur, point[i])
         out.append((cur[0], proofs))
     return out
@@ -997,3 +1039,289 @@ def g2_from_mont_limbs(a) -> Point2:
         return None
     c = [fq_from_mont_limbs(a[6 * i : 6 * i + 6]) for i in range(4)]
     return ((c[0], c[1]), (c[2], c[3]))
+
+
+# --------------------------------------------------------------------------
+# The protocol drivers (hyperplonk/src/dhyperplonk.rs), all parties in-process, STRAIGHT-LINE: one sequential call per reference
+# line, built only from the *_all primitives above -- no queue, no batching, no de-duplication, no overlap.  They exist to pin
+# the product's drivers (zkhip/hyperplonk.py, host/zkhost/hyperplonk.hpp), which run the same calls re-scheduled, to an
+# independent statement of the call sequence: which table, which challenge slice, which SRS, which output position.
+#
+# pks[p]  : party p's PackedProvingParameters as a dict of python ints / lists of ints, keys = the reference's field names
+#           (dhyperplonk.rs:22-62); "c_commitment" / "d_commitment" = powers_of_g levels (lists of affine points).
+# runs[p] : party p's per-run random data ("Jump from sky", :187-190 / :601-604 / :985-987): "local_s_p", "local_s", "eq",
+#           and "s" for the data-parallel form.
+# comm    : True = the `comm` feature (real exchanges); False = the no-`comm` fake (serializing_net.rs:144-264), which is
+#           what `leader` mode runs: only party 0 exists, every gather hands it N copies of its own message and every
+#           scatter hands back slot 0 of what it would have sent -- for the star exchanges of these drivers that equals a run
+#           of N parties that all hold party 0's data, read at party 0 (c_acc_product_and_share has its own echo form below).
+# Returned per party, positions as in the reference's return tuples; a worker's d_sumcheck_product is [] (dsumcheck.rs:507-509),
+# its d_open (0, []) (dpoly_comm.rs:386), and only the leader runs the top-tree tail (dhyperplonk.rs:480).
+# --------------------------------------------------------------------------
+def _c_commit_all(pks, pevals, pp: PackedSharingParams):
+    """dpoly_comm.rs:244-267 for all parties; pevals[p] = party p's batch (a list of vectors) -> result[p][k]"""
+    bases = [[pks[p]["c_commitment"][(len(v) * pp.l).bit_length() - 1] for v in pevals[p]] for p in range(pp.n)]
+    return d_msm_all(bases, pevals, pp)
+
+
+def _lead(value, worker, np_: int):
+    """a leader_compute / gather whose workers get `worker`"""
+    return [value] + [worker] * (np_ - 1)
+
+
+def _wiring_identity_all(n: int, pks, pp: PackedSharingParams, runs, s_tables):
+    """dhyperplonk.rs:296-514 == :1021-1237 (dpermcheck) for all parties; s_tables[p] = party p's `s` of step 2.a"""
+    N = pp.n
+    P = range(N)
+    cc = PerParty(pk["c_commitment"] for pk in pks)
+    dc = PerParty(pk["d_commitment"] for pk in pks)
+    gate_count = 1 << n
+    proofs = [[] for _ in P]
+    commits = [[] for _ in P]
+    opens = [[] for _ in P]
+
+    def d_commit(tabs):  # dpoly_comm.rs:276-297: the leader hands the sum to everyone
+        c = d_commit_all(dc, tabs)
+        for p in P:
+            commits[p].append(c)
+
+    def d_open(tabs, point):  # dpoly_comm.rs:355-398
+        o = d_open_all(dc, tabs, point)
+        for p, v in enumerate(_lead(o, (0, []), N)):
+            opens[p].append(v)
+
+    def d_sumcheck_product(fs, gs, challenge):  # dsumcheck.rs:359-512
+        r = d_sumcheck_product_all(fs, gs, challenge)
+        for p, v in enumerate(_lead(r, [], N)):
+            proofs[p].append(v)
+
+    local_s_p = [runs[p]["local_s_p"] for p in P]
+    # 2.b (:296-302)
+    d_commit(local_s_p)
+    # 2.c (:304)
+    r = c_sumcheck_product_all(s_tables, [pk["V"] for pk in pks], pks[0]["challenge_r1"], pp)
+    for p in P:
+        proofs[p].append(r[p])
+    # 2.d (:306-320)
+    for point in (pks[0]["challenge_r1"], pks[0]["challenge_r2"]):
+        o = c_open_all(cc, [pk["V"] for pk in pks], point, pp)
+        for p in P:
+            opens[p].append(o[p])
+    r2 = pks[0]["challenge_r2"]
+    d_open(local_s_p, r2)
+    # 2.e (:324-340)
+    h_length = gate_count * 4 // N
+    num = [[(local_s_p[p][i] + pks[p]["alpha"] * pks[p]["sid_p"][i] + pks[p]["beta"]) % R_MOD for i in range(h_length)] for p in P]
+    den = [[(pks[p]["eq_r1_p"][i] + pks[p]["alpha"] * pks[p]["ssigma_p"][i] + pks[p]["beta"]) % R_MOD for i in range(h_length)] for p in P]
+    h_p = [[a * pow(b, -1, R_MOD) % R_MOD for a, b in zip(num[p], den[p])] for p in P]
+    subtrees, top = d_acc_product_all(h_p)  # :342
+    v1x = [t[len(t) // 2 :] for t in subtrees]  # :344-348
+    vx0 = [t[0::2] for t in subtrees]  # :349-353
+    vx1 = [t[1::2] for t in subtrees]  # :354-359
+    # :363-380
+    d_commit([pk["ssigma_p"] for pk in pks])
+    d_commit([pk["sid_p"] for pk in pks])
+    for tabs in (h_p, num, den, v1x, vx0, vx1):
+        d_commit(tabs)
+    # :383-407
+    d_open([pk["ssigma_p"] for pk in pks], r2)
+    d_open([pk["sid_p"] for pk in pks], r2)
+    for tabs in (h_p, num, den):
+        d_open(tabs, r2)
+    # 2.e.1 (:411-413)
+    eq_r2_p = [pk["eq_r2_p"] for pk in pks]
+    d_sumcheck_product(den, eq_r2_p, r2)
+    d_sumcheck_product(h_p, den, r2)
+    d_sumcheck_product(num, eq_r2_p, r2)
+    # 2.e.2 (:418-478)
+    s = N.bit_length() - 1
+    cur_v1x = [t[: len(t) // 2] for t in v1x]
+    cur_vx0 = [t[: len(t) // 2] for t in vx0]
+    cur_vx1 = [t[: len(t) // 2] for t in vx1]
+    cur_eq = [t[: len(t) // 2] for t in eq_r2_p]
+    for i in range(1, n - s + 1):
+        ch = r2[i:]
+        d_sumcheck_product(cur_eq, cur_v1x, ch)
+        d_sumcheck_product(cur_eq, cur_vx0, ch)
+        d_sumcheck_product(cur_vx0, cur_vx1, ch)
+        d_open(cur_v1x, ch)
+        d_open(cur_vx0, ch)
+        d_open(cur_vx1, ch)
+        cur_v1x = [t[len(t) // 2 :] for t in cur_v1x]
+        cur_vx0 = [t[len(t) // 2 :] for t in cur_vx0]
+        cur_vx1 = [t[len(t) // 2 :] for t in cur_vx1]
+        cur_eq = [t[len(t) // 2 :] for t in cur_eq]
+    # :480-511, the leader alone, on its own SRS and its own `eq`
+    lt = top
+    lv1x, lvx0, lvx1 = lt[len(lt) // 2 :], lt[0::2], lt[1::2]
+    d0 = pks[0]["d_commitment"]
+    for tab in (lvx0, lvx1, lv1x):
+        commits[0].append(commit(d0, tab))
+        opens[0].append(open_(d0, tab, r2[:s]))
+    eq = runs[0]["eq"]
+    for f, g in ((eq, lv1x), (eq, lvx0), (lvx0, lvx1)):
+        proofs[0].append(sumcheck_product(f, g, r2[:s]))
+    return [(proofs[p], commits[p], opens[p]) for p in P]
+
+
+def _echo(pks, runs, pp):
+    """the no-`comm` fake seen from party 0: N parties that all hold party 0's data"""
+    return [pks[0]] * pp.n, [runs[0]] * pp.n
+
+
+def _s_tables(pks, runs, pp, data_parallel: bool):
+    """step 2.a (:268-294; data-parallel :603: local random data, no exchange)"""
+    if data_parallel:
+        return [runs[p]["s"] for p in range(pp.n)]
+    s = []
+    for i in range(pp.n):  # party i sends local_s to everyone; in order of sender
+        s.extend(runs[i]["local_s"])
+    return [list(s) for _ in range(pp.n)]
+
+
+def dpermcheck_all(n: int, pks, pp: PackedSharingParams, runs, comm: bool = True):
+    """dhyperplonk.rs:962-1247 -> per party (wiring_proofs, wiring_commits, wiring_opens)"""
+    if not comm:
+        pks, runs = _echo(pks, runs, pp)
+    out = _wiring_identity_all(n, pks, pp, runs, _s_tables(pks, runs, pp, False))
+    return out if comm else out[:1]
+
+
+def dhyperplonk_all(n: int, pks, pp: PackedSharingParams, runs, data_parallel: bool = False, comm: bool = True):
+    """
+    dhyperplonk.rs:159-571 (data_parallel: dhyperplonk_data_parallel :573-960) ->
+    per party ((gate_identity_proofs, gate_identity_commitments), (wiring_proofs, wiring_commits, wiring_opens))
+    """
+    if not comm:
+        pks, runs = _echo(pks, runs, pp)
+    N = pp.n
+    P = range(N)
+    cc = PerParty(pk["c_commitment"] for pk in pks)
+    dc = PerParty(pk["d_commitment"] for pk in pks)
+    ch = pks[0]["challenge"]
+    # Step 1 (:198-215)
+    com_a = _c_commit_all(pks, [[pk["a_evals"]] for pk in pks], pp)
+    com_b = _c_commit_all(pks, [[pk["b_evals"]] for pk in pks], pp)
+    com_c = _c_commit_all(pks, [[pk["c_evals"]] for pk in pks], pp)
+    com_I = d_commit_all(dc, [pk["I_p"] for pk in pks])
+    com_S1 = d_commit_all(dc, [pk["S1_p"] for pk in pks])
+    com_S2 = d_commit_all(dc, [pk["S2_p"] for pk in pks])
+    # Step 3 (:223-260)
+    col = lambda name: [pk[name] for pk in pks]
+    sum_ab = [[(a + b) % R_MOD for a, b in zip(pk["a_evals"], pk["b_evals"])] for pk in pks]  # :233-238
+    sum_ci = [[(-a + b) % R_MOD for a, b in zip(pk["c_evals"], pk["I"])] for pk in pks]  # :251-256
+    gate = [
+        c_sumcheck_product_all(col("eq"), col("S1"), ch, pp),  # :229-230
+        c_sumcheck_product_all(col("S1"), sum_ab, ch, pp),  # :240-241
+        c_sumcheck_product_all(col("eq"), col("S2"), ch, pp),  # :243-244
+        c_sumcheck_product_all(col("a_evals"), col("b_evals"), ch, pp),  # :245-246
+        c_sumcheck_product_all(col("S2"), col("a_evals"), ch, pp),  # :247-248
+        c_sumcheck_product_all(col("eq"), sum_ci, ch, pp),  # :258-259
+    ]
+    # Step 2 (:262-514)
+    wiring = _wiring_identity_all(n, pks, pp, runs, _s_tables(pks, runs, pp, data_parallel))
+    # Open (:517-553)
+    open_a = c_open_all(cc, col("a_evals"), ch, pp)
+    open_b = c_open_all(cc, col("b_evals"), ch, pp)
+    open_c = c_open_all(cc, col("c_evals"), ch, pp)
+    open_I = _lead(d_open_all(dc, col("I_p"), ch), (0, []), N)
+    open_S1 = _lead(d_open_all(dc, col("S1_p"), ch), (0, []), N)
+    open_S2 = _lead(d_open_all(dc, col("S2_p"), ch), (0, []), N)
+    out = []
+    for p in P:
+        gate_proofs = [g[p] for g in gate]
+        gate_commitments = [
+            (com_a[p][0], open_a[p]), (com_b[p][0], open_b[p]), (com_c[p][0], open_c[p]),
+            (com_I, open_I[p]), (com_S1, open_S1[p]), (com_S2, open_S2[p]),
+        ]
+        out.append(((gate_proofs, gate_commitments), wiring[p]))
+    return out if comm else out[:1]
+
+
+def c_acc_product_and_share_echo(shares, masks, unmask0, unmask1, unmask2, pp: PackedSharingParams):
+    """
+    dacc_product.rs:66-292 as the no-`comm` build runs it on party 0 (the only party of `leader` mode):
+      * d_unpack2_many (:94-104, unpack.rs:57-70): only the gather whose receiver is party 0 returns data -- N copies of the
+        party's own block 0 (serializing_net.rs:159-162); the other N - 1 return empty vectors,
+      * c_acc_product (:296-363): the leader receives N copies of its own last elements,
+      * the looped scatters (:155-203) are replaced by the party's OWN share rows, `results.push(subtree_share[i])` (:194-202),
+      * the leader-tree scatter (:253-261) returns slot 0 of what the leader would have sent (serializing_net.rs:204-207).
+    """
+    N = pp.n
+    S = len(shares)
+    assert S > N
+    bs = S // N
+    masked = [x * m % R_MOD for x, m in zip(shares, masks)]
+    masked_x = []
+    for k in range(bs):
+        masked_x.extend(pp.unpack2([masked[k]] * N))
+    subtrees, leader_tree = c_acc_product_all([masked_x] * N, pp)
+    st = subtrees[0]
+
+    def pack_chunks(vals):
+        return transpose([pp.pack_from_public(vals[i : i + pp.l]) for i in range(0, len(vals), pp.l)]) if vals else [[] for _ in range(N)]
+
+    num_to_send = min(N, len(st))
+    to_share = st[: len(st) - num_to_send]
+    out = []
+    for rows, lt, um in (
+        (pack_chunks(to_share[0::2]), pack_chunks(leader_tree[0::2]), unmask0),
+        (pack_chunks(to_share[1::2]), pack_chunks(leader_tree[1::2]), unmask1),
+        (pack_chunks(to_share[len(st) // 2 :]), pack_chunks(leader_tree), unmask2),
+    ):
+        sh = merge(rows) + lt[0]
+        out.append([v * um[i] % R_MOD for i, v in enumerate(sh)])
+    return tuple(out)
+
+
+def cpermcheck_all(n: int, pks, pp: PackedSharingParams, comm: bool = True):
+    """dhyperplonk.rs:1249-1385 -> per party (wiring_proofs, wiring_commits, wiring_opens)"""
+    if not comm:
+        pks = [pks[0]] * pp.n
+    N = pp.n
+    P = range(N)
+    cc = PerParty(pk["c_commitment"] for pk in pks)
+    gate_count = (1 << n) // pp.l  # :1270
+    r1 = pks[0]["challenge_r1"]
+    col = lambda name: [pk[name] for pk in pks]
+    num = [[(pk["V"][i] + pk["alpha"] * pk["sid"][i] + pk["beta"]) % R_MOD for i in range(gate_count * 4)] for pk in pks]  # :1277-1279
+    den = [[(pk["eq_r1"][i] + pk["alpha"] * pk["ssigma"][i] + pk["beta"]) % R_MOD for i in range(gate_count * 4)] for pk in pks]  # :1280-1282
+    proofs = [[] for _ in P]
+    commits = [[] for _ in P]
+    opens = [[] for _ in P]
+
+    def c_commit(tabs):
+        r = _c_commit_all(pks, [[t] for t in tabs], pp)
+        for p in P:
+            commits[p].append(r[p][0])
+
+    def c_open(tabs):
+        r = c_open_all(cc, tabs, r1, pp)
+        for p in P:
+            opens[p].append(r[p])
+
+    def c_sumcheck_product(fs, gs):
+        r = c_sumcheck_product_all(fs, gs, r1, pp)
+        for p in P:
+            proofs[p].append(r[p])
+
+    c_commit(col("ssigma"))  # :1289-1293
+    c_open(col("ssigma"))  # :1294-1298
+    c_commit(col("sid"))  # :1299-1303
+    c_open(col("sid"))  # :1304-1308
+    for evaluations in (num, den):  # :1309
+        if comm:
+            sh = c_acc_product_and_share_all(evaluations, col("mask"), col("unmask0"), col("unmask1"), col("unmask2"), pp)  # :1311-1322
+        else:
+            pk = pks[0]
+            sh = [c_acc_product_and_share_echo(evaluations[0], pk["mask"], pk["unmask0"], pk["unmask1"], pk["unmask2"], pp)] * N
+        vx0, vx1, v1x = [s[0] for s in sh], [s[1] for s in sh], [s[2] for s in sh]
+        for tabs in (evaluations, vx0, vx1, v1x):  # :1324-1363
+            c_commit(tabs)
+            c_open(tabs)
+        c_sumcheck_product(col("eq_r1"), v1x)  # :1365-1366
+        c_sumcheck_product(col("eq_r1"), vx0)  # :1367-1368
+        c_sumcheck_product(vx0, vx1)  # :1369
+        c_open(evaluations)  # :1371-1375
+    out = [(proofs[p], commits[p], opens[p]) for p in P]
+    return out if comm else out[:1]

@@ -3,7 +3,7 @@
 // run the collaborative proof on the GPU(s), print the reference's timer labels and its `Comm: (up, down)` line (:564).
 //
 //   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2]
-//              [--digest] [--check] [--tamper] [--serial-rep]
+//              [--digest] [--dump PREFIX] [--check] [--tamper] [--serial-rep]
 //     leader   party 0 on the no-`comm` echo net (the reference's `-F leader` build: one party's full work; default)
 //     threads  all 8 l parties as threads of this process, one ctx each, exchanges through host memory (LocalTestNet); the
 //              parties share the visible GPUs round-robin
@@ -16,6 +16,9 @@
 //              forms, the repetitions and the traced run must agree bit for bit, and a copy of the transcript with one limb
 //              flipped must be rejected under exactly its label.  Prints one `check: ...` line per party; exit code 3 when any
 //              party fails.  --tamper flips that limb in the transcript under test instead (the run must then FAIL: exit 3).
+//     --dump PREFIX  EVERY party writes the transcript of its last repetition to PREFIX.party<p>.bin (raw limbs behind u64 counts, in
+//              the reference's order): tests/test_protocol_oracle.py compares it position by position with the oracle's straight-line
+//              statement of the call sequence (oracle/pyoracle.py dhyperplonk_all / dpermcheck_all / cpermcheck_all)
 //     --serial-rep  after the timed repetitions, one more proof with every MSM pass run to completion inside the step that owns
 //              it (`End(serial):` lines): the per-step timers of the timed repetitions are OVERLAPPED sections
 #include <algorithm>
@@ -33,7 +36,7 @@ using namespace zkhost;
 
 struct Args {
     size_t l = 1, n = 12, reps = 3, table_max = 24;
-    std::string mode = "leader", which = "dhyperplonk";
+    std::string mode = "leader", which = "dhyperplonk", dump;
     bool tables = true, digest = false, check = false, tamper = false, serial_rep = false, marks = false, share_gpus = false;
 };
 
@@ -55,6 +58,31 @@ static std::string transcript_digest(const Transcript &t) {
     h.update(t.wiring_commits.data(), 144 * t.wiring_commits.size());
     for (auto &o : t.wiring_opens) h.update(o.value.v, 32), h.update(o.proofs.data(), 144 * o.proofs.size());
     return h.hex();
+}
+
+// --dump: u64 counts + raw limbs, lists in the reference's order (the reader is tests/test_protocol_oracle.py::_read_dump)
+static void dump_transcript(const Transcript &t, const std::string &path) {
+    std::FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("--dump: cannot open " + path);
+    auto u64 = [f](uint64_t v) { std::fwrite(&v, 8, 1, f); };
+    auto proofs = [&](const std::vector<std::vector<Triple>> &ps) {
+        u64(ps.size());
+        for (auto &p : ps) u64(p.size()), std::fwrite(p.data(), 96, p.size(), f);
+    };
+    auto opening = [&](const Opening &o) {
+        std::fwrite(o.value.v, 32, 1, f);
+        u64(o.proofs.size());
+        std::fwrite(o.proofs.data(), 144, o.proofs.size(), f);
+    };
+    proofs(t.gate_proofs);
+    u64(t.gate_commitments.size());
+    for (auto &c : t.gate_commitments) std::fwrite(c.first.data(), 144, 1, f), opening(c.second);
+    proofs(t.wiring_proofs);
+    u64(t.wiring_commits.size());
+    std::fwrite(t.wiring_commits.data(), 144, t.wiring_commits.size(), f);
+    u64(t.wiring_opens.size());
+    for (auto &o : t.wiring_opens) opening(o);
+    std::fclose(f);
 }
 
 // flip one limb of one t2 in the middle of a transcript every party holds (gate[3], or the first wiring transcript of the
@@ -149,6 +177,7 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
         uint64_t up0 = net.upload, down0 = net.download;
         Transcript t = run_once(a, pk, pp, be, net, tm);
         if (a.check) digests.push_back(transcript_digest(t));
+        if (!a.dump.empty() && r + 1 == a.reps) dump_transcript(t, a.dump + ".party" + std::to_string(p) + ".bin");
         for (auto &kv : tm.t)
             if (kv.first.rfind("Distributed", 0) == 0 || kv.first.rfind("Collaborative", 0) == 0) totals.push_back(kv.second);
         if (net.is_leader()) {
@@ -203,6 +232,7 @@ int main(int argc, char **argv) {
         else if (k == "--which") a.which = val();
         else if (k == "--no-tables") a.tables = false;
         else if (k == "--digest") a.digest = true;
+        else if (k == "--dump") a.dump = val();
         else if (k == "--check") a.check = true;
         else if (k == "--serial-rep") a.serial_rep = true;
         else if (k == "--marks") a.marks = true;  // diagnostics: host time stamps of the calls inside a proof
@@ -211,7 +241,7 @@ int main(int argc, char **argv) {
         else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
         else if (k == "--table-rec") setenv("ZKHOST_TABLE_REC", val(), 1);  // 128: one G1 table record per cache line (4/3 of the table memory)
         else {
-            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--table-rec 96|128] [--digest] [--check] [--tamper] [--serial-rep]\n");
+            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--table-rec 96|128] [--digest] [--dump PREFIX] [--check] [--tamper] [--serial-rep]\n");
             return 64;
         }
     }
