@@ -1224,8 +1224,11 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
     std::vector<MsmClass>& classes = run.classes;
     const Tuning& tn = tuning();
     if (tn.msm_share > 0 && tn.msm_share < 100) {  // experiment knob: a grid of persistent workgroups that leaves the other slots free
-        static int occ = 0;          // resident workgroups of k_accum_tiles<Cv> per CU (one static per instantiation)
-        if (!occ && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_accum_tiles<Cv>, kBlk, 0) != hipSuccess) occ = 2;
+        // resident workgroups of k_accum_tiles<Cv> per CU (one static per instantiation; party threads may enqueue concurrently)
+        static const int occ = [] {
+            int o = 0;
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)k_accum_tiles<Cv>, kBlk, 0) == hipSuccess && o > 0 ? o : 2;
+        }();
         run.accum_wg_cap = std::max<size_t>(1, (size_t)ctx->cu_count * (size_t)std::max(occ, 1) * (size_t)tn.msm_share / 100);
     }
     const u32 T_env = (u32)tn.msm_tile;

@@ -257,7 +257,9 @@ int g1_apply_matrix_internal(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows,
             }
     const size_t total = rows * k;
     // few outputs of many terms each: one lane per term (see k_g1_scale_cols); otherwise one lane per output
-    const bool by_column = cols >= 8 && total < 16384 && total * cols <= ((size_t)1 << 22) && tuning().g1_map_by_column != 0;
+    // (capped at 2^18 terms = 48 + 24 MiB of transient scratch: the motivating case is the leader's maps of 3 x 16 outputs of 128 terms; a GPU
+    // shared by several parties must not be asked for hundreds of MiB per call.  If even that is refused, the row form -- total * 192 B -- runs.)
+    bool by_column = cols >= 8 && total < 16384 && total * cols <= ((size_t)1 << 18) && tuning().g1_map_by_column != 0;
     void *d_m = nullptr, *d_x = nullptr, *d_a = nullptr, *d_t = nullptr;
     auto cleanup = [&] {
         if (d_m) hipFree(d_m);
@@ -266,8 +268,18 @@ int g1_apply_matrix_internal(zk_ctx* ctx, const uint64_t* h_matrix, size_t rows,
         if (d_t) hipFree(d_t);
     };
     hipError_t e = device_alloc(ctx, &d_m, std::max<size_t>(rows * cols * 32, 32));
-    if (e == hipSuccess) e = device_alloc(ctx, &d_x, ((total * (by_column ? (cols + 1) / 2 : 1) + 63) & ~(size_t)63) * 192);
-    if (e == hipSuccess && by_column) e = device_alloc(ctx, &d_t, ((total * cols + 63) & ~(size_t)63) * 192);
+    if (e == hipSuccess && by_column) {
+        hipError_t ec = device_alloc(ctx, &d_x, ((total * ((cols + 1) / 2) + 63) & ~(size_t)63) * 192);
+        if (ec == hipSuccess) ec = device_alloc(ctx, &d_t, ((total * cols + 63) & ~(size_t)63) * 192);
+        if (ec != hipSuccess) {  // out of memory for the per-term scratch: fall back to one lane per output
+            (void)hipGetLastError();
+            if (d_x) hipFree(d_x);
+            if (d_t) hipFree(d_t);
+            d_x = d_t = nullptr;
+            by_column = false;
+        }
+    }
+    if (e == hipSuccess && !by_column) e = device_alloc(ctx, &d_x, ((total + 63) & ~(size_t)63) * 192);
     if (e == hipSuccess) e = device_alloc(ctx, &d_a, total * 96);
     if (e == hipSuccess) e = hipMemcpyAsync(d_m, h_matrix, rows * cols * 32, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // h_matrix is caller memory

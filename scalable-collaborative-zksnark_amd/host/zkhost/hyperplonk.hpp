@@ -374,7 +374,8 @@ inline Transcript dhyperplonk(size_t n, const PackedProvingParameters &pk, const
     // 0: at step 1, as the reference orders it; 1: together with the two long passes (ZKHOST_LATE_COMMIT)
     static const int late_commit = [] {
         const char *e = std::getenv("ZKHOST_LATE_COMMIT");
-        return e ? std::atoi(e) : 2;
+        const int v = e ? std::atoi(e) : 2;
+        return (v == 0 || v == 1) ? v : 2;  // anything else is the default (an unknown value must not leave the commit pass unstarted)
     }();
     static const bool one_batch = [] {  // the sumcheck-family kernels of steps 2-4 as ONE batch (pipeline.hpp ScQueue); ZKHOST_ONE_BATCH=0: a batch per call
         const char *e = std::getenv("ZKHOST_ONE_BATCH");

@@ -90,6 +90,7 @@ struct AnchorValues {
 // (sum_j f_j g_j, f(r), g(r)) through kernels the product sumcheck does not share
 inline AnchorValues product_anchor(Ctx &be, const ScTrace &t) {
     size_t n = Ctx::log2_exact(t.len);
+    if (t.challenge.size() < n) throw std::invalid_argument("product_anchor: a traced sumcheck of 2^" + std::to_string(n) + " elements carries " + std::to_string(t.challenge.size()) + " challenges");
     FrVec ch(t.challenge.begin(), t.challenge.begin() + n);
     AnchorValues a;
     a.kind = t.kind, a.rounds = n, a.challenge = t.challenge;
@@ -169,7 +170,9 @@ inline void check_product_transcripts(const ProductAnchors &A, const Transcript 
         bool good = true;
         if (a.kind == 'c') {
             Fr fin = a.f_r * a.g_r;
-            good = pr.size() == a.rounds + logl + 1 && sumcheck_product_chain(pr, a.challenge, a.rounds, &a.claimed, &fin);
+            // (the traced challenge holds the rounds of phase 1; phase 2 re-reads its first log2(l) entries: a table shorter than l -- small n,
+            // large l -- has fewer, which is a labelled failure of the check, not an exception out of it)
+            good = pr.size() == a.rounds + logl + 1 && a.challenge.size() >= std::max(a.rounds, logl) && sumcheck_product_chain(pr, a.challenge, a.rounds, &a.claimed, &fin);
             if (good) {
                 FrVec vf = A.tail_f[e], vg = A.tail_g[e];
                 for (size_t i = 0; i < logl && good; ++i) {
