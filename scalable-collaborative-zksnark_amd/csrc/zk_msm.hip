@@ -643,6 +643,418 @@ static __global__ void __launch_bounds__(kSortThreads) k_part_sort(const u32* __
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Round 6: the sort of long WINDOW-TABLE rows without the digits array, and a level 2 that stores runs.
+//
+// Measured on the round-5 code at 2^24 points (13 windows of 20 bits: a row of 218 M entries; profiles/r06b_trace_2p24.txt):
+// k_digits 0.26 + k_part_hist 0.26 + k_part_scan 0.13 + k_part_scatter_staged 1.07 + k_part_sort 2.91 = 4.63 ms, 9 GB of counter
+// traffic against 1.4 GB compulsory (32 B per scalar in, 4 B per entry out).  Two causes:
+//   * the digits took a round trip through HBM (52 B written per scalar, read twice) although a scalar is the most compact
+//     form of its own digits: k_tab_hist / k_tab_scatter below recompute them from the 32-byte scalar (read twice, kept in
+//     registers between the counting and the placing phase of the scatter);
+//   * level 2 placed every entry with its own 4-byte store at a random position of its partition's 0.85 MB output range: 64
+//     cache lines per wave store, two thirds of the phase.  the tiled level 2 (k_l2_*) sorts 16 Ki entries at a time by bucket in LDS and
+//     writes every bucket's run (32+ entries) with consecutive lanes.
+// The fused level 1 applies to classes that share one bucket set over all windows of a window table (`cl.shared`: the row is
+// [W][ns], entry v = w * ns + i); other classes keep k_digits and the digit-reading kernels.
+// ---------------------------------------------------------------------------------------
+static constexpr int kTabW = 22;  // most windows of a fused class (12-bit tables: 22 windows)
+
+// all digits of one canonical scalar over the W windows of the layout (W <= kTabW), in registers:
+// d[w] = kSkip, or sign bit | (|digit| - 1) -- the same values k_digits stores.
+// C > 0: the 256-bit layout of a C-bit window table (msm_layout(C, kFullBits)) as compile-time constants -- every digit is a
+// bit-field at a known position of two known limbs (2-3 instructions instead of shifting the whole scalar: k_tab_hist at 2^24
+// was bound by its ~700 instructions per scalar, not by the 32 bytes it reads).  C = 0: any layout, at run time.
+// one window of the compile-time layout (recursion over w: every limb index and shift is a constant expression)
+template <int C, int w>
+__device__ __forceinline__ void recode_fixed(const u32 (&s)[8], u32 carry, u32 (&d)[kTabW]) {
+    constexpr int W = (kFullBits + C - 1) / C, base = kFullBits / W, rem = kFullBits % W;
+    static_assert(W <= kTabW && base + 1 <= 31, "layout");
+    if constexpr (w < W) {
+        constexpr int cw = base + (w < rem ? 1 : 0), off = w * base + (w < rem ? w : rem);
+        constexpr int limb = off >> 5, sh = off & 31;
+        constexpr u32 mask = (1u << cw) - 1u, half = 1u << (cw - 1);
+        u32 v;
+        if constexpr (sh + cw <= 32) v = (s[limb] >> sh) & mask;
+        else v = ((s[limb] >> sh) | (s[limb + 1] << (32 - sh))) & mask;  // (off + cw <= 256: limb + 1 <= 7)
+        v += carry;
+        u32 sg = 0;
+        if (v > half) {
+            v = (1u << cw) - v;
+            carry = 1;
+            sg = 0x80000000u;
+        } else {
+            carry = 0;
+        }
+        d[w] = (v == 0) ? kSkip : (sg | (v - 1));
+        recode_fixed<C, w + 1>(s, carry, d);
+    } else if constexpr (w < kTabW) {
+        d[w] = kSkip;
+        recode_fixed<C, w + 1>(s, carry, d);
+    }
+}
+template <int C>
+__device__ __forceinline__ void recode_all(u32 (&s)[8], const WinLayout& L, u32 (&d)[kTabW]) {
+    if constexpr (C > 0) {
+        recode_fixed<C, 0>(s, 0u, d);
+    } else {
+        u32 carry = 0;
+#pragma unroll
+        for (int w = 0; w < kTabW; w++) {
+            if (w < L.W) {
+                const int cw = L.width(w);
+                const u32 mask = (1u << cw) - 1u, half = 1u << (cw - 1);
+                u32 v = (s[0] & mask) + carry;
+#pragma unroll
+                for (int k = 0; k < 7; k++) s[k] = (s[k] >> cw) | (s[k + 1] << (32 - cw));
+                s[7] >>= cw;
+                u32 sg = 0;
+                if (v > half) {
+                    v = (1u << cw) - v;
+                    carry = 1;
+                    sg = 0x80000000u;
+                } else {
+                    carry = 0;
+                }
+                d[w] = (v == 0) ? kSkip : (sg | (v - 1));
+            } else {
+                d[w] = kSkip;
+            }
+        }
+    }
+}
+
+// 64-lane inclusive scan without LDS
+__device__ __forceinline__ u32 wave_inclusive_scan(u32 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+// exclusive scan over the block (blockDim a multiple of 64, <= 1024) in three barriers; sh: >= 160 words
+__device__ __forceinline__ u32 block_exclusive_scan_fast(u32 v, u32* sh, u32* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const u32 incl = wave_inclusive_scan(v);
+    if (lane == 63) sh[wid] = incl;
+    __syncthreads();
+    if (wid == 0) {
+        const u32 t = lane < nw ? sh[lane] : 0u;
+        const u32 ti = wave_inclusive_scan(t);
+        sh[64 + lane] = ti - t;
+        if (lane == 63) sh[128] = ti;
+    }
+    __syncthreads();
+    const u32 res = incl - v + sh[64 + wid];
+    if (total) *total = sh[128];
+    __syncthreads();
+    return res;
+}
+
+// Workgroup b of a launch runs on XCD b mod 8, and every XCD has its own L2.  The scatters below write runs that CONTINUE the
+// run of the previous chunk / tile (chunk c + 1's entries of partition p land right behind chunk c's): with consecutive chunks on
+// different XCDs every 128-byte line at a seam is written partially from two L2s.  This map gives XCD x the x-th contiguous
+// eighth of the chunks, in increasing order: seams close inside one L2.  `per` = ceil(count / 8); the launch has 8 * per
+// workgroups per row, the ones that fall off the end exit.
+__device__ __forceinline__ u32 xcd_contiguous(u32 b, u32 per) { return (b & 7u) * per + (b >> 3); }
+
+// level 1, histogram: block (chunk, row) reads `chunk_sc` scalars of item `row` and counts their W digits per partition
+template <int C>
+static __global__ void __launch_bounds__(kSortThreads) k_tab_hist(const ItemDesc* __restrict__ items, WinLayout L, u32 chunk_sc, u32 nchunks, u32 np,
+                                                         int low_bits, u32* __restrict__ hist) {
+    __shared__ u32 cnt[kMaxParts];
+    const u32 chunk = blockIdx.x % nchunks, row = blockIdx.x / nchunks;
+    const ItemDesc it = items[row];
+    for (u32 i = threadIdx.x; i < np; i += kSortThreads) cnt[i] = 0u;
+    __syncthreads();
+    const u32 i0 = chunk * chunk_sc;
+    Fr sc[2];  // chunk_sc <= 2 * kSortThreads: both loads go out before the arithmetic
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const u32 i = i0 + q * kSortThreads + threadIdx.x;
+        if ((u32)q * kSortThreads + threadIdx.x < chunk_sc && i < it.n) sc[q] = fr_load(it.scalars, i);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const u32 i = i0 + q * kSortThreads + threadIdx.x;
+        if ((u32)q * kSortThreads + threadIdx.x >= chunk_sc || i >= it.n) break;
+        Fr s = fp_from_mont<FrCfg>(sc[q]);
+        u32 d[kTabW];
+        recode_all<C>(s.l, L, d);
+#pragma unroll
+        for (int w = 0; w < kTabW; w++)
+            if (d[w] != kSkip) atomicAdd(&cnt[(d[w] & 0x7fffffffu) >> low_bits], 1u);
+    }
+    __syncthreads();
+    for (u32 p = threadIdx.x; p < np; p += kSortThreads) hist[((size_t)row * np + p) * nchunks + chunk] = cnt[p];
+}
+
+// level 1, scatter: the same chunk again.  How many of its entries fall into partition p is already in the scanned histogram
+// (hist[p][chunk + 1] - hist[p][chunk]): no second counting pass over LDS atomics -- those, not the bytes, bound these kernels
+// (~2 lane-atomics per clock and CU measured: 218 M entries cost ~0.2 ms per pass at 2^24).  The chunk's entries are grouped by
+// partition in LDS (one word each: sign | window | scalar-in-chunk | bucket-in-partition) and every partition's run leaves with
+// consecutive lanes (a half wave per run).  SPT = scalars per thread.
+template <int SPT, int C>
+static __global__ void __launch_bounds__(kSortThreads) k_tab_scatter(const ItemDesc* __restrict__ items, u32 ns, WinLayout L, u32 nchunks, u32 np,
+                                                            int low_bits, const u32* __restrict__ hist, const u32* __restrict__ ptotal,
+                                                            const u32* __restrict__ base, int idx_bits, size_t row_len, u32* __restrict__ part_idx,
+                                                            unsigned short* __restrict__ part_low) {
+    extern __shared__ u32 sm[];
+    u32* cnt = sm;                    // [kMaxParts] fill cursors
+    u32* loc = cnt + kMaxParts;       // [kMaxParts + 1] start of the partition's run inside the stage
+    u32* gcur = loc + kMaxParts + 1;  // [kMaxParts] destination of that run in the row
+    u32* sh = gcur + kMaxParts;       // [160] scan scratch
+    u32* stage = sh + 160;            // [SPT * kSortThreads * W]
+    const u32 per8 = (nchunks + 7) / 8, row = blockIdx.x / (8 * per8);
+    const u32 chunk = xcd_contiguous(blockIdx.x % (8 * per8), per8);
+    if (chunk >= nchunks) return;
+    const ItemDesc it = items[row];
+    const u32 i0 = chunk * (SPT * kSortThreads);
+    if (i0 >= it.n) return;  // (a shorter item of the class: nothing in this chunk)
+    // the scalars' loads go out first
+    Fr sc[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const u32 i = i0 + k * kSortThreads + threadIdx.x;
+        if (i < it.n) sc[k] = fr_load(it.scalars, i);
+    }
+    {
+        u32 v = 0, h0 = 0;  // kSortThreads == kMaxParts: one partition per thread
+        if (threadIdx.x < np) {
+            const u32* h = hist + ((size_t)row * np + threadIdx.x) * nchunks;
+            h0 = h[chunk];
+            v = ((chunk + 1 < nchunks) ? h[chunk + 1] : ptotal[(size_t)row * np + threadIdx.x]) - h0;
+            gcur[threadIdx.x] = base[(size_t)row * np + threadIdx.x] + h0;
+        }
+        u32 total;
+        const u32 ex = block_exclusive_scan_fast(v, sh, &total);
+        loc[threadIdx.x] = ex;
+        cnt[threadIdx.x] = ex;
+        if (threadIdx.x == 0) loc[kMaxParts] = total;
+    }
+    __syncthreads();
+    const u32 low_mask = (1u << low_bits) - 1u;
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const u32 i = i0 + k * kSortThreads + threadIdx.x;
+        if (i >= it.n) continue;
+        Fr s = fp_from_mont<FrCfg>(sc[k]);
+        u32 d[kTabW];
+        recode_all<C>(s.l, L, d);
+#pragma unroll
+        for (int w = 0; w < kTabW; w++) {
+            const u32 dd = d[w];
+            if (dd != kSkip) {
+                const u32 b = dd & 0x7fffffffu;
+                const u32 pos = atomicAdd(&cnt[b >> low_bits], 1u);
+                stage[pos] = (dd & 0x80000000u) | ((u32)w << 26) | ((u32)(k * kSortThreads + threadIdx.x) << 15) | (b & low_mask);  // low_bits <= 11 < 15, SPT * 1024 <= 2^11
+            }
+        }
+    }
+    __syncthreads();
+    u32* oi = part_idx + (size_t)row * row_len;
+    unsigned short* ol = part_low + (size_t)row * row_len;
+    const u32 hw = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+    for (u32 p = hw; p < np; p += kSortThreads / 32) {
+        const u32 a = loc[p], n = loc[p + 1] - a, g = gcur[p];
+        for (u32 k = l32; k < n; k += 32) {
+            const u32 wd = stage[a + k];
+            const u32 v = ((wd >> 26) & 31u) * ns + i0 + ((wd >> 15) & 2047u);
+            const u32 low = wd & 0x7fffu;
+            if (idx_bits) {
+                oi[g + k] = v | (low << idx_bits) | (wd & 0x80000000u);
+            } else {
+                oi[g + k] = v | (wd & 0x80000000u);
+                ol[g + k] = (unsigned short)low;
+            }
+        }
+    }
+}
+
+// level 2 for long partitions, three launches with a workgroup per TILE of kL2Tile entries (a first form with one workgroup per
+// partition walking its tiles in sequence took 1.48 ms at 2^24: 1 024 workgroups, each a chain of 13 tiles, four rounds on the
+// chip).  A partition of m entries is ceil(m / kL2Tile) tiles; tile j of the row belongs to partition p with tstart[p] <= j.
+//   k_l2_tiles    block (row): tstart[row][0 .. np] = exclusive scan of the partitions' tile counts
+//   k_l2_hist     block (tile, row): bucket histogram of the tile -> h2[row][tile][nlow]
+//   k_l2_scan     block (p, row): per bucket the exclusive scan over the partition's tiles (h2 in place), the bucket counts,
+//                 their scan -> (offset, count) records, first bucket of every accumulation tile (as k_part_sort)
+//   k_l2_scatter  block (tile, row): entries in registers, grouped by bucket in LDS, every bucket's run stored by a half wave at
+//                 oc[bucket].offset + h2[tile][bucket]
+// Same outputs as k_part_sort (the order inside a bucket differs; the additions are exact).
+static constexpr u32 kL2Per = 16, kL2Tile = kL2Per * kSortThreads;
+static __global__ void __launch_bounds__(kScanThreads) k_l2_tiles(const u32* __restrict__ base, const u32* __restrict__ rowtot, u32 np, u32* __restrict__ tstart) {
+    __shared__ u32 sh[kScanThreads];
+    const u32 row = blockIdx.x, p = threadIdx.x;
+    u32 v = 0;
+    if (p < np) {
+        const u32 s = base[(size_t)row * np + p], e = (p + 1 < np) ? base[(size_t)row * np + p + 1] : rowtot[row];
+        v = (e - s + kL2Tile - 1) / kL2Tile;
+    }
+    u32 all;
+    const u32 ex = block_exclusive_scan(v, sh, &all);
+    if (p < np) tstart[(size_t)row * (np + 1) + p] = ex;
+    if (p == 0) tstart[(size_t)row * (np + 1) + np] = all;
+}
+// tile j of `row` -> its partition and entry range; false: no such tile
+__device__ __forceinline__ bool l2_tile_range(const u32* __restrict__ tstart, const u32* __restrict__ base, const u32* __restrict__ rowtot, u32 np, u32 row, u32 j,
+                                              u32& p, u32& e0, u32& e1) {
+    const u32* ts = tstart + (size_t)row * (np + 1);
+    if (j >= ts[np]) return false;
+    u32 lo = 0, hi = np;  // largest p with ts[p] <= j (partitions without tiles share their successor's start)
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (ts[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    p = lo;
+    const u32 s = base[(size_t)row * np + p], e = (p + 1 < np) ? base[(size_t)row * np + p + 1] : rowtot[row];
+    e0 = s + (j - ts[p]) * kL2Tile;
+    e1 = (e0 + kL2Tile < e) ? e0 + kL2Tile : e;
+    return true;
+}
+static __global__ void __launch_bounds__(kSortThreads) k_l2_hist(const u32* __restrict__ part_idx, const unsigned short* __restrict__ part_low, size_t row_len, u32 np,
+                                                        int low_bits, int idx_bits, const u32* __restrict__ base, const u32* __restrict__ rowtot,
+                                                        const u32* __restrict__ tstart, u32 ub, u32* __restrict__ h2) {
+    __shared__ u32 cnt[kMaxLow];
+    const u32 j = blockIdx.x % ub, row = blockIdx.x / ub;
+    u32 p, e0, e1;
+    if (!l2_tile_range(tstart, base, rowtot, np, row, j, p, e0, e1)) return;
+    const u32 nlow = 1u << low_bits, low_mask = nlow - 1u;
+    for (u32 i = threadIdx.x; i < nlow; i += kSortThreads) cnt[i] = 0u;
+    __syncthreads();
+    const u32* pi = part_idx + (size_t)row * row_len;
+    const unsigned short* pl = part_low + (size_t)row * row_len;
+    for (u32 i = e0 + threadIdx.x; i < e1; i += kSortThreads) atomicAdd(&cnt[idx_bits ? ((pi[i] >> idx_bits) & low_mask) : (u32)pl[i]], 1u);
+    __syncthreads();
+    u32* h = h2 + ((size_t)row * ub + j) * nlow;
+    for (u32 i = threadIdx.x; i < nlow; i += kSortThreads) h[i] = cnt[i];
+}
+static __global__ void __launch_bounds__(kSortThreads) k_l2_scan(u32 np, int low_bits, size_t nb, const u32* __restrict__ base, const u32* __restrict__ tstart, u32 ub,
+                                                        u32* __restrict__ h2, uint2* __restrict__ oc, u32 T, size_t tiles_per_w, u32* __restrict__ tile_b) {
+    __shared__ u32 sh[160];
+    const u32 p = blockIdx.x % np, row = blockIdx.x / np;
+    const u32 nlow = 1u << low_bits;
+    const u32* ts = tstart + (size_t)row * (np + 1);
+    const u32 j0 = ts[p], j1 = ts[p + 1];
+    const u32 per = (nlow + kSortThreads - 1) / kSortThreads;  // 1 or 2 (nlow <= kMaxLow)
+    const u32 lo = threadIdx.x * per < nlow ? threadIdx.x * per : nlow, hi = (lo + per < nlow) ? lo + per : nlow;
+    u32 c[2] = {0u, 0u};
+    for (u32 j = j0; j < j1; j++) {
+        u32* h = h2 + ((size_t)row * ub + j) * nlow;
+        for (u32 i = lo; i < hi; i++) {
+            const u32 v = h[i];
+            h[i] = c[i - lo];
+            c[i - lo] += v;
+        }
+    }
+    u32 run = base[(size_t)row * np + p] + block_exclusive_scan_fast(c[0] + c[1], sh, nullptr);
+    uint2* oc_out = oc + (size_t)row * nb + (size_t)p * nlow;
+    u32* tile_out = tile_b + (size_t)row * tiles_per_w;
+    for (u32 i = lo; i < hi; i++) {
+        const u32 v = c[i - lo];
+        oc_out[i] = make_uint2(run, v);
+        if (v)
+            for (u32 t = (run + T - 1) / T; t <= (run + v - 1) / T; t++) tile_out[t] = p * nlow + i;
+        run += v;
+    }
+}
+static __global__ void __launch_bounds__(kSortThreads) k_l2_scatter(const u32* __restrict__ part_idx, const unsigned short* __restrict__ part_low, size_t row_len, u32 np,
+                                                           int low_bits, int idx_bits, size_t nb, const u32* __restrict__ base, const u32* __restrict__ rowtot,
+                                                           const u32* __restrict__ tstart, u32 ub, const u32* __restrict__ h2, const uint2* __restrict__ oc,
+                                                           u32* __restrict__ sorted) {
+    extern __shared__ u32 sm[];
+    const u32 nlow = 1u << low_bits, low_mask = nlow - 1u;
+    u32* lc = sm;              // [nlow] count, then cursor
+    u32* loc = lc + nlow;      // [nlow + 1] start of the bucket's run in the stage
+    u32* sh = loc + nlow + 1;  // [160]
+    u32* stage = sh + 160;     // [kL2Tile]
+    const u32 per8 = (ub + 7) / 8, row = blockIdx.x / (8 * per8);
+    const u32 j = xcd_contiguous(blockIdx.x % (8 * per8), per8);
+    u32 p, e0, e1;
+    if (j >= ub || !l2_tile_range(tstart, base, rowtot, np, row, j, p, e0, e1)) return;
+    const u32 keep = idx_bits ? (((1u << idx_bits) - 1u) | 0x80000000u) : 0xffffffffu;
+    const u32* pi = part_idx + (size_t)row * row_len;
+    const unsigned short* pl = part_low + (size_t)row * row_len;
+    const u32* h = h2 + ((size_t)row * ub + j) * nlow;
+    const uint2* ocp = oc + (size_t)row * nb + (size_t)p * nlow;
+    u32 ev[kL2Per], el[kL2Per];
+#pragma unroll
+    for (u32 k = 0; k < kL2Per; k++) {  // (the loads go out first)
+        const u32 i = e0 + k * kSortThreads + threadIdx.x;
+        el[k] = 0xffffffffu;
+        if (i < e1) {
+            ev[k] = pi[i];
+            el[k] = idx_bits ? ((ev[k] >> idx_bits) & low_mask) : (u32)pl[i];
+        }
+    }
+    {
+        // the tile's bucket counts are the differences of the scanned tile histograms (k_l2_scan) -- no counting pass
+        const bool last = tstart[(size_t)row * (np + 1) + p + 1] == j + 1;
+        const u32 per = (nlow + kSortThreads - 1) / kSortThreads;
+        const u32 lo = threadIdx.x * per < nlow ? threadIdx.x * per : nlow, hi = (lo + per < nlow) ? lo + per : nlow;
+        u32 c[2] = {0u, 0u};
+        for (u32 i = lo; i < hi; i++) c[i - lo] = (last ? ocp[i].y : h[nlow + i]) - h[i];
+        u32 total;
+        u32 run = block_exclusive_scan_fast(c[0] + c[1], sh, &total);
+        for (u32 i = lo; i < hi; i++) {
+            loc[i] = run;
+            lc[i] = run;
+            run += c[i - lo];
+        }
+        if (threadIdx.x == 0) loc[nlow] = total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < kL2Per; k++)
+        if (el[k] != 0xffffffffu) stage[atomicAdd(&lc[el[k]], 1u)] = ev[k] & keep;
+    __syncthreads();
+    u32* out = sorted + (size_t)row * row_len;
+    const u32 hw = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+    for (u32 b = hw; b < nlow; b += kSortThreads / 32) {
+        const u32 a = loc[b], n = loc[b + 1] - a;
+        if (n == 0) continue;
+        const u32 g = ocp[b].x + h[b];
+        for (u32 k = l32; k < n; k += 32) out[g + k] = stage[a + k];
+    }
+}
+
+// host dispatch of the fused level 1 over the table widths that occur on long rows (any other width: the run-time layout, C = 0)
+#define ZK_TAB_WIDTHS(X) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+static int tab_width_known(int c) {
+#define X(Cc) if (c == Cc) return Cc;
+    ZK_TAB_WIDTHS(X)
+#undef X
+    return 0;
+}
+static void tab_launch_hist(int c, dim3 grid, hipStream_t st, const ItemDesc* items, WinLayout L, u32 chunk_sc, u32 nchunks, u32 np, int low_bits, u32* hist) {
+    switch (c) {
+#define X(Cc) case Cc: hipLaunchKernelGGL(k_tab_hist<Cc>, grid, dim3(kSortThreads), 0, st, items, L, chunk_sc, nchunks, np, low_bits, hist); break;
+        ZK_TAB_WIDTHS(X)
+#undef X
+        default: hipLaunchKernelGGL(k_tab_hist<0>, grid, dim3(kSortThreads), 0, st, items, L, chunk_sc, nchunks, np, low_bits, hist);
+    }
+}
+template <int SPT, int C>
+static void tab_launch_scatter_one(dim3 grid, size_t lds, hipStream_t st, const ItemDesc* items, u32 ns, WinLayout L, u32 nchunks, u32 np, int low_bits, const u32* hist,
+                                   const u32* ptotal, const u32* base, int idx_bits, size_t row_len, u32* part_idx, unsigned short* part_low) {
+    hipFuncSetAttribute((const void*)k_tab_scatter<SPT, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((k_tab_scatter<SPT, C>), grid, dim3(kSortThreads), lds, st, items, ns, L, nchunks, np, low_bits, hist, ptotal, base, idx_bits, row_len, part_idx, part_low);
+}
+static void tab_launch_scatter(int c, int spt, dim3 grid, size_t lds, hipStream_t st, const ItemDesc* items, u32 ns, WinLayout L, u32 nchunks, u32 np, int low_bits,
+                               const u32* hist, const u32* ptotal, const u32* base, int idx_bits, size_t row_len, u32* part_idx, unsigned short* part_low) {
+#define ZK_ARGS grid, lds, st, items, ns, L, nchunks, np, low_bits, hist, ptotal, base, idx_bits, row_len, part_idx, part_low
+    switch (c) {
+#define X(Cc) case Cc: if (spt == 2) tab_launch_scatter_one<2, Cc>(ZK_ARGS); else tab_launch_scatter_one<1, Cc>(ZK_ARGS); break;
+        ZK_TAB_WIDTHS(X)
+#undef X
+        default: if (spt == 2) tab_launch_scatter_one<2, 0>(ZK_ARGS); else tab_launch_scatter_one<1, 0>(ZK_ARGS);
+    }
+#undef ZK_ARGS
+}
+
 // ---------------------------------------------------------------------------------------
 // 4. bucket accumulation over fixed-size TILES of the sorted array: every lane performs exactly
 // T mixed additions regardless of how the scalars distribute over buckets (no lock-step waiting
@@ -1145,6 +1557,11 @@ struct MsmClass {
     int low_bits = 0;                 // log2(buckets per partition)
     int idx_bits = 0;                 // > 0: level-1 entries carry the bucket-in-partition above the index bits
     bool staged_scatter = false;      // level-1 scatter through an LDS-sorted chunk (long rows)
+    bool fused_tab = false;           // level 1 straight from the scalars (k_tab_hist / k_tab_scatter): long window-table rows
+    bool tiled_l2 = false;            // level 2 with LDS-staged runs (k_l2_*): long partitions
+    u32 tab_spt = 2;                  // fused level 1: scalars per thread (chunk = tab_spt * 1024 scalars)
+    int tab_c = 0;                    // fused level 1: the table width when a compile-time layout exists for it (else 0)
+    u32 l2_ub = 0;                    // tiled level 2: upper bound of the tiles of a row (row_len / kL2Tile + np)
     size_t pinned_off = 0;  // byte offset of this class's results in the pinned staging area
     size_t off[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets of this class inside the scratch arenas
 };
@@ -1368,7 +1785,28 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         if (cl.rows * (size_t)cl.np * (cl.row_len / kStageChunk + 1) > ((size_t)64 << 20)) cl.staged_scatter = false;  // histogram arena <= 256 MiB
         cl.chunk_len = cl.staged_scatter ? kStageChunk : (std::max<size_t>(16384, (cl.row_len + 511) / 512) + 3) & ~(size_t)3;
         cl.nchunks = (u32)((cl.row_len + cl.chunk_len - 1) / cl.chunk_len);
+        // round 6 (see k_tab_hist): long window-table rows are partitioned straight from the scalars, long partitions are sorted in tiles
+        cl.fused_tab = cl.shared && cl.w0 == 0 && cl.wc == cl.L.W && cl.L.W <= kTabW && cl.np == kMaxParts && cl.row_len >= ((size_t)1 << (tn.msm_fused_min > 0 ? tn.msm_fused_min : 23)) &&
+                       tn.msm_fused_min >= 0;
+        if (cl.fused_tab) {
+            cl.tab_spt = cl.L.W <= 16 ? 2 : 1;  // the stage holds tab_spt * 1024 * W words of LDS
+            if (tn.msm_tab_spt == 1) cl.tab_spt = 1;  // (A/B: 66 KB of LDS, two workgroups per CU, runs half as long)
+            cl.tab_c = tab_width_known(cl.key_c);
+            if (cl.tab_c) {  // (the compile-time layout must be the class's)
+                const WinLayout chk = msm_layout(cl.tab_c, kFullBits);
+                if (chk.W != cl.L.W || chk.base != cl.L.base || chk.rem != cl.L.rem) cl.tab_c = 0;
+            }
+            const size_t chunk_sc = (size_t)cl.tab_spt * kSortThreads;
+            const size_t nch = (cl.ns + chunk_sc - 1) / chunk_sc;
+            if (cl.rows * (size_t)cl.np * nch > ((size_t)64 << 20)) cl.fused_tab = false;  // histogram arena <= 256 MiB
+            else cl.nchunks = (u32)nch;
+        }
+        // (below ~2^23 entries per row the four extra launches cost what the run stores save: measured 2^16 .. 2^20 points, profiles/r06d_sort_ab.txt)
+        cl.tiled_l2 = tn.msm_l2_tiled >= 0 && cl.row_len / cl.np >= (size_t)(tn.msm_l2_tiled > 0 ? tn.msm_l2_tiled : 8192) && (tn.msm_l2_tiled > 0 || cl.row_len >= ((size_t)1 << 23));
+        cl.l2_ub = (u32)(cl.row_len / kL2Tile + cl.np);
+        if (cl.tiled_l2 && cl.rows * (size_t)cl.l2_ub * ((size_t)1 << cl.low_bits) > ((size_t)64 << 20)) cl.tiled_l2 = false;  // tile histograms <= 256 MiB
         cl.cc_elems = cl.rows * (size_t)cl.np * cl.nchunks + 2 * cl.rows * (size_t)cl.np + cl.rows;  // hist, total, base, rowtot
+        if (cl.tiled_l2) cl.cc_elems += cl.rows * (size_t)(cl.np + 1) + cl.rows * (size_t)cl.l2_ub * ((size_t)1 << cl.low_bits);  // tstart, h2
         // classes run concurrently on separate streams: each gets its own region of every arena
         const size_t total64 = (cl.total + 63) & ~(size_t)63, tiles64 = (cl.total_tiles + 63) & ~(size_t)63;  // XYZZ arrays: blocks of 64
         const size_t want_b[10] = {cl.rows * cl.row_len * 4, cl.rows * cl.row_len * 4, 2 * cl.total * 4 + cl.total_tiles * 4, total64 * Cv::kXyzzBytes, total64 * Cv::kXyzzBytes,
@@ -1515,8 +1953,9 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         if (t_first) hipEventRecord(ctx->ev[0], st);
         ZK_HIP_INFLIGHT(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
         ZK_HIP_INFLIGHT(ctx, hipMemsetAsync(longs, 0, 4, st));
-        hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
-                           (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, (cl.shared || !Cv::kEndo) ? 0 : 1, digits);
+        if (!cl.fused_tab)
+            hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
+                               (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, (cl.shared || !Cv::kEndo) ? 0 : 1, digits);
         {
             u32* hist = cc;
             u32* ptotal = hist + cl.rows * (size_t)cl.np * cl.nchunks;
@@ -1524,11 +1963,18 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
             u32* rowtot = pbase + cl.rows * (size_t)cl.np;
             const dim3 g_chunks((unsigned)(cl.nchunks * cl.rows)), g_parts((unsigned)(cl.np * cl.rows));
             const RowReal rr{(const ItemDesc*)d_items, (u32)cl.rpi, (u32)ns};
-            hipLaunchKernelGGL(k_part_hist, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, cl.np,
-                               cl.low_bits, hist, rr);
-            hipLaunchKernelGGL(k_part_scan, dim3((unsigned)(cl.rows * cl.np)), dim3(128), 0, st, hist, cl.nchunks, ptotal);  // <= 512 chunks per row
+            if (cl.fused_tab)
+                tab_launch_hist(cl.tab_c, g_chunks, st, (const ItemDesc*)d_items, cl.L, cl.tab_spt * (u32)kSortThreads, cl.nchunks, cl.np, cl.low_bits, hist);
+            else
+                hipLaunchKernelGGL(k_part_hist, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks, cl.np,
+                                   cl.low_bits, hist, rr);
+            hipLaunchKernelGGL(k_part_scan, dim3((unsigned)(cl.rows * cl.np)), dim3(cl.nchunks >= 2048 ? 1024 : 128), 0, st, hist, cl.nchunks, ptotal);
             hipLaunchKernelGGL(k_part_bases, dim3((unsigned)cl.rows), dim3(cl.np <= 256 ? 256 : kScanThreads), 0, st, (const u32*)ptotal, cl.np, pbase, rowtot);
-            if (cl.staged_scatter) {
+            if (cl.fused_tab) {
+                const size_t lds = (3 * (size_t)kMaxParts + 1 + 160 + (size_t)cl.tab_spt * kSortThreads * cl.L.W) * 4;
+                tab_launch_scatter(cl.tab_c, (int)cl.tab_spt, dim3((unsigned)(8 * ((cl.nchunks + 7) / 8) * cl.rows)), lds, st, (const ItemDesc*)d_items, (u32)ns, cl.L, cl.nchunks, cl.np, cl.low_bits, (const u32*)hist,
+                                   (const u32*)ptotal, (const u32*)pbase, cl.idx_bits, cl.row_len, part_idx, part_low);
+            } else if (cl.staged_scatter) {
                 const size_t lds = (3 * (size_t)kMaxParts + kSortThreads + 2 * (size_t)kStageChunk) * 4;
                 hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL(k_part_scatter_staged, g_chunks, dim3(kSortThreads), lds, st, (const u32*)digits, cl.row_len, cl.chunk_len,
@@ -1537,6 +1983,20 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
                 hipLaunchKernelGGL(k_part_scatter, g_chunks, dim3(kSortThreads), 0, st, (const u32*)digits, cl.row_len, cl.chunk_len, cl.nchunks,
                                    cl.np, cl.low_bits, (const u32*)hist, (const u32*)pbase, cl.idx_bits, part_idx, part_low, rr);
             }
+            if (cl.tiled_l2) {
+                u32* tstart = rowtot + cl.rows;
+                u32* h2 = tstart + cl.rows * (size_t)(cl.np + 1);
+                const u32 ub = cl.l2_ub;
+                const dim3 g_tiles((unsigned)(ub * cl.rows));
+                const size_t lds = (2 * ((size_t)1 << cl.low_bits) + 1 + 160 + kL2Tile) * 4;
+                hipLaunchKernelGGL(k_l2_tiles, dim3((unsigned)cl.rows), dim3(kScanThreads), 0, st, (const u32*)pbase, (const u32*)rowtot, cl.np, tstart);
+                hipLaunchKernelGGL(k_l2_hist, g_tiles, dim3(kSortThreads), 0, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len, cl.np, cl.low_bits, cl.idx_bits,
+                                   (const u32*)pbase, (const u32*)rowtot, (const u32*)tstart, ub, h2);
+                hipLaunchKernelGGL(k_l2_scan, g_parts, dim3(kSortThreads), 0, st, cl.np, cl.low_bits, nb, (const u32*)pbase, (const u32*)tstart, ub, h2, oc, cl.T, cl.tiles_per_w, tile_b);
+                hipFuncSetAttribute((const void*)k_l2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL(k_l2_scatter, dim3((unsigned)(8 * ((ub + 7) / 8) * cl.rows)), dim3(kSortThreads), lds, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len, cl.np, cl.low_bits,
+                                   cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, (const u32*)tstart, ub, (const u32*)h2, (const uint2*)oc, sorted);
+            } else
             hipLaunchKernelGGL(k_part_sort, g_parts, dim3(cl.row_len / cl.np >= 4096 ? kSortThreads : 256), 0, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len,
                                cl.np, cl.low_bits, cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, oc, cl.T, cl.tiles_per_w, tile_b, sorted);
         }

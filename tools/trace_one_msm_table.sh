@@ -9,7 +9,7 @@ import csv,glob
 f=glob.glob('/tmp/prof_trt/**/*kernel_trace.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'k_digits' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'k_digits' in r['Kernel_Name'] or 'k_tab_hist' in r['Kernel_Name']]
 rows=rows[idx[-1]:]
 t0=int(rows[0]['Start_Timestamp'])
 for r in rows:
