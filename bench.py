@@ -275,8 +275,9 @@ def parse_args():
     ap.add_argument("--cpu-e2e-n", type=int, default=13, help="log2 constraints of the CPU end-to-end sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="time the MSM without the SRS window table (zk_srs_precompute)")
-    ap.add_argument("--table-rec", type=int, default=128, choices=(96, 128),
-                    help="bytes per record of the G1 window tables of the MSM legs (zk_srs_precompute_layout: 128 = one record per 128-B line, +33 %% table memory; 96 = packed, the library default, what the proof legs run on)")
+    ap.add_argument("--table-rec", type=int, default=0, choices=(0, 96, 128),
+                    help="bytes per record of the G1 window tables of the MSM legs: 0 = the library's own choice (zk_srs_precompute: 128-B records -- one per cache line -- while the table leaves >= 60 %% of the device free, "
+                         "packed 96-B records otherwise; the hosts' parameter sets apply the same rule per level), 96 / 128 = forced (A/B)")
     ap.add_argument("--no-extra", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (counter-collection runs)")
     ap.add_argument("--no-e2e-n24", action="store_true", help="skip the n = 24 end-to-end leg (C++ host, ~25 s)")
@@ -456,9 +457,9 @@ def run_rank(args, grp, gpu: int, ctx, net):
             c0 = ctx.lib.zk_msm_window(n)
             default_path = {"scalar_muls_per_s": world * n / dt0, "ms_per_step": dt0 * 1e3, "steps": 10, "pippenger_window_bits": c0, "windows": (129 + c0 - 1) // c0,
                             "k_accum_tiles_ms": float(ph0[1]) / 10, "note": "no window table: endomorphism split, 2n entries per window, one bucket set per window"}
-        # the MSM legs of this file build their tables with one record per 128-B line (zk_srs_precompute_layout, see
-        # config.srs_window_table); the protocol legs below run on the library default (packed 96-B records) -- their parameter
-        # sets hold tables for ~40 levels and the proofs of 8 parties on one GPU / the checked n = 24 proof need the memory
+        # the table layout is the library's own choice (zk_srs_precompute: 128-B records while the device has the room, packed otherwise) --
+        # the rule the hosts' parameter sets apply per level, so the MSM legs and the proof legs of this line run the same layout policy;
+        # config.srs_window_table.record_bytes says what was built
         t0 = time.perf_counter()
         srs.precompute(0, record_bytes=args.table_rec)
         ctx.sync()
@@ -545,8 +546,8 @@ def run_rank(args, grp, gpu: int, ctx, net):
                 "pippenger_window_bits": c,
                 "windows": windows,
                 "entries_per_window": per_window,
-                "srs_window_table": ({"window_bits": tc, "copies": windows, "bytes": windows * ((n + 3) & ~3) * args.table_rec, "record_bytes": args.table_rec,
-                                      "record_note": "zk_srs_precompute_layout: 128 = one G1 record per 128-B line (the MSM legs of this line), 96 = packed (what zk_srs_precompute builds; the e2e / cpermcheck legs)", "build_s": precompute_s,
+                "srs_window_table": ({"window_bits": tc, "copies": windows, "bytes": windows * ((n + 3) & ~3) * srs.table_record, "record_bytes": srs.table_record, "record_policy": ("library default: by free memory" if not args.table_rec else "forced by --table-rec"),
+                                      "record_note": "128 = one G1 record per 128-B line, 96 = packed; zk_srs_precompute and the hosts' parameter sets (per level) choose 128 while the table leaves >= 60 % of the device free", "build_s": precompute_s,
                                       "built": "once per SRS level, outside the timed region (zk_srs_precompute)"} if tc else None),
             },
             "rccl_ranks": rccl_ranks,  # = zk_comm_size of the in-ctx communicator (0: no RCCL communicator in this run)

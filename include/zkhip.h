@@ -188,13 +188,14 @@ int zk_g1_apply_matrix(zk_ctx *ctx, const uint64_t *h_matrix, size_t rows, size_
 /* Optional, once per SRS level (setup, like uploading it): build the table 2^{o_w} * P_i for every
  * window offset o_w of a `window_bits`-wide signed-digit decomposition (0 = pick for the level's
  * length).  MSMs on this SRS then use ONE bucket set for all windows: 1/W of the bucket-reduction
- * and fix-up work and no cross-window doubling chain.  Costs W x the level's memory (W ~ 14-22 copies).  See
- * zk_srs_precompute_layout for G1 records padded from 96 to 128 bytes, one per cache line: the accumulation's gathers then
- * move one line each (2^20 MSM +4-7 %) for 4/3 of the table memory. */
+ * and fix-up work and no cross-window doubling chain.  Costs W x the level's memory (W ~ 13-22 copies).  A G1 table's
+ * records are padded from 96 to 128 bytes -- one per cache line: the accumulation's gathers then move one line each, 2^20 MSM
+ * +4-7 %, 4/3 of the table memory -- when that leaves at least 60 % of the device free at the moment of the call, and packed
+ * (96 bytes) otherwise; zk_srs_precompute_layout forces one form.  window_bits <= 22. */
 int zk_srs_precompute(zk_ctx *ctx, zk_srs *srs, int window_bits);
-/* The same with the record layout of a G1 table chosen by the caller: record_bytes = 96 (packed: what zk_srs_precompute builds),
- * 128 (one record per 128-byte cache line) or 0 (the default).  Same MSM results; 128 wants 4/3 of the table memory.  G2 levels
- * ignore it (192-byte records).  ZK_ERR_INVALID for any other value. */
+/* The same with the record layout of a G1 table chosen by the caller: record_bytes = 96 (packed), 128 (one record per 128-byte
+ * cache line) or 0 (zk_srs_precompute's own choice, by free memory).  Same MSM results.  G2 levels ignore it (192-byte
+ * records).  ZK_ERR_INVALID for any other value. */
 int zk_srs_precompute_layout(zk_ctx *ctx, zk_srs *srs, int window_bits, int record_bytes);
 /* bytes per record of the level's table (0: none built) */
 int zk_srs_table_record(const zk_srs *srs);

@@ -170,6 +170,7 @@ struct CvG2 {
 // the buckets to reduce and half the host doubling chain, for the same number of bucket additions.
 static constexpr int kEndoBits = 129;  // 128 bits + room for the carry of the signed recoding
 static constexpr int kFullBits = 256;  // 255-bit scalar + carry (precomputed-table mode)
+static constexpr int kMaxTableBits = 22;  // widest window of a table: 2^21 buckets = kMaxParts partitions x kMaxLow buckets of the sort
 
 // window bits for an n-point MSM (2n entries per window after the split).  Up to 2^21 points the
 // measured optimum follows log2(n) - 3, log2(n) - 2 below 2^16 (sweeps in tools/sweep_msm.py); from 2^22 on 19 bits (7 windows
@@ -199,7 +200,7 @@ static int msm_pick_window_full(size_t n) {
     if (tuning().msm_small_table_widths != 0 && lg <= 14) c = lg <= 10 ? 12 : 14;
     c += (int)tuning().msm_table_dc;  // (sweeps)
     if (c < 4) c = 4;
-    if (c > 20) c = 20;
+    if (c > 20) c = 20;  // (the automatic pick; zk_srs_precompute accepts up to kMaxTableBits -- see the sweep in profiles/r06h_table_width_sweep.txt)
     return c;
 }
 
@@ -324,7 +325,7 @@ __device__ __forceinline__ void recode_windows(u32 (&s)[NL], const WinLayout& L,
                                                size_t row_len, size_t pos) {
     u32 carry = 0;
     for (int w = 0; w < w0 + wc; w++) {
-        const int cw = L.width(w);  // <= 20
+        const int cw = L.width(w);  // <= kMaxTableBits
         const u32 mask = (1u << cw) - 1u, half = 1u << (cw - 1);
         u32 v = (s[0] & mask) + carry;
         // s >>= cw
@@ -2349,7 +2350,7 @@ int srs_precompute_table_g2(zk_ctx* ctx, const zk_srs* srs, int c, size_t nsr, v
 int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c, int record_bytes) {
     if (!srs) return fail(ctx, ZK_ERR_INVALID, "null srs");
     if (c == 0) c = srs->g2 ? msm_pick_window_full_g2(srs->n ? srs->n : 1) : msm_pick_window_full(srs->n ? srs->n : 1);
-    if (c < 2 || c > 20) return fail(ctx, ZK_ERR_INVALID, "window bits out of range");
+    if (c < 2 || c > kMaxTableBits) return fail(ctx, ZK_ERR_INVALID, "window bits out of range");
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     if (srs->d_table) {
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2359,12 +2360,18 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c, int record_bytes) {
     if (srs->n == 0) return ZK_OK;
     const WinLayout L = msm_layout(c, kFullBits);
     const size_t nsr = (srs->n + 3) & ~(size_t)3;
-    // A G1 point is 96 B.  Packed (the default), two records of three straddle a 128-B line and a gather of the accumulation moves 1.67
-    // lines on average; zk_srs_precompute_layout(.., 128) -- or the process-wide knob srs_table_rec -- builds one record per 128-B line (+33 % table memory).
-    // Measured (profiles/r05zb_table_rec_ab.txt): k_accum_tiles at 2^20 2.04-2.14 -> 1.90-1.91 ms, the 2^20 MSM 3.57-3.70e8 -> 3.82-3.84e8
-    // scalar-muls/s, 2^24 4.69 -> 4.80e8, n = 24 proof 0.815 -> 0.793 s.  It is an OPTION because the memory is not free everywhere: with it
-    // the 8-party n = 20 proof on ONE GPU and the n = 24 proof with --check run the device out of resources (bench.py's MSM legs switch it on).
-    const long want_rec = record_bytes ? (long)record_bytes : tuning().srs_table_rec;  // (zk_srs_precompute_layout, or the process-wide default)
+    // A G1 point is 96 B.  Packed, two records of three straddle a 128-B line and a gather of the accumulation moves 1.67 lines on average; one
+    // record per 128-B line costs +33 % table memory.  Measured (profiles/r05zb_table_rec_ab.txt): k_accum_tiles at 2^20 2.04-2.14 -> 1.90-1.91 ms, the
+    // 2^20 MSM 3.57-3.70e8 -> 3.82-3.84e8 scalar-muls/s, 2^24 4.69 -> 4.80e8, n = 24 proof 0.815 -> 0.793 s.
+    // Round 6: the DEFAULT (record_bytes = 0 and the knob srs_table_rec = 0) decides per table by what the device can spare right now -- 128-B
+    // records when the table then leaves >= 60 % of the device free, packed 96-B records otherwise: a prover's ~40 levels, or several parties
+    // sharing one GPU, fall back to the packed form by themselves as the memory fills (the hosts' parameter sets add their own floor below which
+    // a level gets no table at all: zkhost/hyperplonk.hpp finish_setup).  zk_srs_precompute_layout(.., 96 | 128) forces one form.
+    long want_rec = record_bytes ? (long)record_bytes : tuning().srs_table_rec;
+    if (want_rec == 0 && !srs->g2) {
+        size_t fr = 0, tot = 0;
+        want_rec = (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)fr - (double)L.W * (double)nsr * 128.0 >= 0.6 * (double)tot) ? 128 : 96;
+    }
     const size_t rec = srs->g2 ? CvG2::kAffBytes : (want_rec == 128 ? (size_t)128 : CvG1::kAffBytes);
     ZK_HIP(ctx, device_alloc(ctx, &srs->d_table, (size_t)L.W * nsr * rec));
     ZK_HIP(ctx, hipMemsetAsync(srs->d_table, 0, (size_t)L.W * nsr * rec, ctx->stream));

@@ -35,7 +35,7 @@
 using namespace zkhost;
 
 struct Args {
-    size_t l = 1, n = 12, reps = 3, table_max = 24;
+    size_t l = 1, n = 12, reps = 3, table_max = 25;
     std::string mode = "leader", which = "dhyperplonk", dump;
     bool tables = true, digest = false, check = false, tamper = false, serial_rep = false, marks = false, share_gpus = false;
 };

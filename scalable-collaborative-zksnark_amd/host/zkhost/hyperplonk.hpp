@@ -102,9 +102,9 @@ struct PackedProvingParameters {
     }
     // the folds of V and the synthetic SRS (random points in the reference as well); window_tables: build the MSM window
     // table of every level up to 2^table_max_log2 points (setup work like generating the level; results are bit-identical
-    // with and without); a level is skipped when its table would leave less than 40 % of the device free
+    // with and without); a level is skipped when its table would leave less than 40 % of the device free (the rule is below)
     // window_bits(len): width of a level's table (0 = the library's pick for a single MSM of that length)
-    void finish_setup(Ctx &be, const PackedSharingParams &pp, uint64_t seed, bool window_tables = true, size_t table_max_log2 = 24,
+    void finish_setup(Ctx &be, const PackedSharingParams &pp, uint64_t seed, bool window_tables = true, size_t table_max_log2 = 25,
                       const std::function<int(size_t)> &window_bits = nullptr) {
         size_t M = size_t(1) << n, l = pp.l;
         Fr zero = Fr::zero(), one = Fr::one();
@@ -119,8 +119,13 @@ struct PackedProvingParameters {
         std::vector<SrsPtr> all = c_commitment;
         all.insert(all.end(), d_commitment.begin(), d_commitment.end());
         std::stable_sort(all.begin(), all.end(), [](const SrsPtr &a, const SrsPtr &b) { return a->len() < b->len(); });
-        // ZKHOST_TABLE_REC=128: G1 table records of 128 bytes, one per cache line (zk_srs_precompute_layout): n = 20 / 24 proofs -1.3 / -2.7 %
-        // for 4/3 of the table memory -- an opt-in: a GPU shared by several parties, or the n = 24 proof with its self-check, do not have it
+        // Record layout per level (round 6; the Python host applies the same rule, zkhip/hyperplonk.py `_synthetic_srs`).  A G1 table record is
+        // 96 B packed or 128 B -- one per cache line: the accumulation's gathers move 1 line instead of 1.67, k_accum_tiles -7 .. -10 %
+        // (profiles/r05zb_table_rec_ab.txt) for 4/3 of the table memory.  The levels are built smallest first and each takes what the device
+        // can spare at that moment: 128-B records while that leaves >= 60 % of the device free, packed records while that leaves >= 40 %
+        // (the MSM arenas of an n = 24 proof want ~80 GB), no table -- the table-less path -- below that.  A GPU shared by several parties
+        // (threads mode) fills up as the parties build their sets, and the later / larger levels fall back by themselves.
+        // ZKHOST_TABLE_REC=96 / 128 forces one layout for every level (A/B runs).
         static const int table_rec = [] {
             const char *e = std::getenv("ZKHOST_TABLE_REC");
             return e ? std::atoi(e) : 0;
@@ -128,19 +133,27 @@ struct PackedProvingParameters {
         for (auto &lv : all) {  // largest levels last: the ones without a table simply use the table-less path
             size_t len = lv->len();
             if (len < 64 || len > (size_t(1) << table_max_log2)) continue;
-            if (len > (size_t(1) << 22)) {
-                size_t fr = 0, tot = 0;
-                be.check(zk_mem_info(be.handle(), &fr, &tot));
-                if ((double)fr - 16.0 * (table_rec == 128 ? 128.0 : 96.0) * (double)len < 0.4 * (double)tot) break;
+            size_t fr = 0, tot = 0;
+            be.check(zk_mem_info(be.handle(), &fr, &tot));
+            const double copies = 16.0;  // (an upper bound of the table's window count at every width the library picks)
+            auto left_after = [&](double rec_bytes) { return ((double)fr - copies * rec_bytes * (double)len) / (double)tot; };
+            int rec = 96;
+            if (table_rec == 96 || table_rec == 128) {
+                rec = table_rec;
+                if (left_after(rec) < 0.4) break;
+            } else if (left_after(128.0) >= 0.6) {
+                rec = 128;
+            } else if (left_after(96.0) < 0.4) {
+                break;
             }
-            int rc = zk_srs_precompute_layout(be.handle(), lv->handle(), window_bits ? window_bits(len) : 0, table_rec == 128 ? 128 : 0);
+            int rc = zk_srs_precompute_layout(be.handle(), lv->handle(), window_bits ? window_bits(len) : 0, rec);
             if (rc == ZK_ERR_OOM) break;
             be.check(rc);
         }
     }
     // dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy(): tables from SplitMix64(seed ...)
     static PackedProvingParameters make(Ctx &be, size_t n, const PackedSharingParams &pp, uint64_t seed, uint64_t chal_seed = 0, bool window_tables = true,
-                                        const std::function<int(size_t)> &window_bits = nullptr, size_t table_max_log2 = 24) {
+                                        const std::function<int(size_t)> &window_bits = nullptr, size_t table_max_log2 = 25) {
         PackedProvingParameters pk;
         pk.n = n;
         uint64_t sd = 0x5CA1AB1Eull + 1000 * seed;

@@ -21,7 +21,7 @@ from .pss import PackedSharingParams
 
 ONE_BATCH = os.environ.get("ZKHIP_ONE_BATCH", "1") != "0"  # the sumcheck-family kernels of a proof's steps 2-4 as ONE batch (dp.ScQueue); 0: a batch per call
 LATE_COMMIT = os.environ.get("ZKHIP_LATE_COMMIT", "1") != "0"  # one-batch schedule: the commit pass starts after the kernel batch (zkhost: ZKHOST_LATE_COMMIT=2)
-TABLE_REC = int(os.environ.get("ZKHIP_TABLE_REC", "0"))  # 128: G1 window-table records of 128 bytes, one per cache line (zk_srs_precompute_layout; 4/3 of the table memory)
+TABLE_REC = int(os.environ.get("ZKHIP_TABLE_REC", "0"))  # 0: per level by free memory (see _synthetic_srs); 96 / 128: one G1 window-table record layout for every level (A/B)
 CPERM_SERIAL = os.environ.get("ZKHIP_CPERM_SERIAL", "0") == "1"  # cpermcheck call by call as the reference writes it (A/B switch: same transcript)
 
 
@@ -56,7 +56,7 @@ class PackedProvingParameters:
     d_commitment: List = None  # levels 0..n-1          (new_random, dpoly_comm.rs:220-233)
 
     @staticmethod
-    def new(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = None, window_tables: bool = True, table_max_log2: int = 24) -> "PackedProvingParameters":
+    def new(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = None, window_tables: bool = True, table_max_log2: int = 25) -> "PackedProvingParameters":
         """
         dhyperplonk.rs:65-156 with a documented seed instead of StdRng::from_entropy().  chal_seed: the
         challenges are public values every party shares (the reference's local mode clones ONE parameter set
@@ -102,7 +102,7 @@ class PackedProvingParameters:
                        "eq_r2", "eq_r2_p", "local_s_p", "local_s_l", "eq_top", "s_data_parallel")
 
     @staticmethod
-    def new_splitmix(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = 0, window_tables: bool = True, table_max_log2: int = 24) -> "PackedProvingParameters":
+    def new_splitmix(n: int, pp: PackedSharingParams, be, seed: int, chal_seed: int = 0, window_tables: bool = True, table_max_log2: int = 25) -> "PackedProvingParameters":
         """
         The parameter set the C++ host builds (host/zkhost/hyperplonk.hpp `PackedProvingParameters::make`): every table from
         SplitMix64(0x5CA1AB1E + 1000 seed + k) (SURVEY.md 8(d) "Synthetic inputs"), the same challenges and SRS seeds -- so that a
@@ -135,15 +135,27 @@ class PackedProvingParameters:
         pk.c_commitment = [be.srs_generate(seed * 7919 + 2 * i + 1, seed * 104729 + 2 * i + 3, max(1, (1 << i) // l)) for i in range(n + 3)]
         pk.d_commitment = [be.srs_generate(seed * 6007 + 2 * i + 5, seed * 15485863 + 2 * i + 7, 1 << i) for i in range(n - (npar.bit_length() - 1) + 3)]
         if window_tables:
-            # largest levels last: if the device runs out of memory the levels without a table simply use the table-less path
+            # Largest levels last; each takes what the device can spare at that moment (the rule of zkhost/hyperplonk.hpp finish_setup): 128-B
+            # records -- one per cache line, k_accum_tiles -7 .. -10 % for 4/3 of the memory -- while that leaves >= 60 % of the device free,
+            # packed 96-B records while that leaves >= 40 % (the MSM arenas of an n = 24 proof want ~80 GB), no table below that: the level
+            # then runs the table-less path.  A GPU shared by several parties fills up and the later / larger levels fall back by themselves.
             for lv in sorted(pk.c_commitment + pk.d_commitment, key=len):
                 if hasattr(lv, "precompute") and 64 <= len(lv) <= (1 << table_max_log2):
-                    if hasattr(be, "mem_info") and len(lv) > (1 << 22):
+                    rec = TABLE_REC
+                    if hasattr(be, "mem_info"):
                         free, total = be.mem_info()
-                        if free - 16 * (TABLE_REC or 96) * len(lv) < 0.4 * total:
+                        left_after = lambda rec_bytes: (free - 16 * rec_bytes * len(lv)) / total
+                        if TABLE_REC in (96, 128):
+                            if left_after(TABLE_REC) < 0.4:
+                                break
+                        elif left_after(128) >= 0.6:
+                            rec = 128
+                        elif left_after(96) < 0.4:
                             break
+                        else:
+                            rec = 96
                     try:
-                        lv.precompute(0, record_bytes=TABLE_REC)
+                        lv.precompute(0, record_bytes=rec)
                     except Exception as e:
                         if getattr(e, "code", None) != -6:  # ZK_ERR_OOM: keep going without the remaining tables
                             raise

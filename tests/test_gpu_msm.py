@@ -182,7 +182,7 @@ def test_msm_batch_matches_individual(ctx, co):
 
 
 def test_window_table_record_layouts_give_the_same_points(ctx):
-    """zk_srs_precompute_layout: packed 96-byte records (what zk_srs_precompute builds) and one record per 128-byte line -- same MSM
+    """zk_srs_precompute_layout: packed 96-byte records and one record per 128-byte line -- same MSM
     results with and without the table, also for a sub-range of the level and in a batch that mixes both layouts; bad values are refused"""
     import zkhip
 
@@ -201,8 +201,15 @@ def test_window_table_record_layouts_give_the_same_points(ctx):
     assert (got[0] == ref).all() and (got[1] == ref).all() and (got[2] == ctx.msm_g1(srs_a, sc, 1000)).all()
     with pytest.raises(zkhip.ZkError):
         srs_a.precompute(0, record_bytes=100)
-    srs_b.precompute(0)  # (rebuilt in the default layout)
-    assert srs_b.table_record == 96 and (ctx.msm_g1(srs_b, sc, n) == ref).all()
+    srs_b.precompute(0)  # (rebuilt in the default layout: by free memory -- 128-byte records while the table leaves >= 60 % of the device free)
+    free, total = ctx.mem_info()
+    assert srs_b.table_record == (128 if free >= 0.65 * total else srs_b.table_record) and srs_b.table_record in (96, 128)
+    assert (ctx.msm_g1(srs_b, sc, n) == ref).all()
+    # a table wider than 20 bits (the automatic pick stops there; 22 = the sort's 1 024 partitions x 2 048 buckets) -- same points
+    srs_b.precompute(22)
+    assert srs_b.table_window == 22 and (ctx.msm_g1(srs_b, sc, n) == ref).all()
+    with pytest.raises(zkhip.ZkError):
+        srs_b.precompute(23)
 
 
 def test_msm_batch_of_window_table_items_of_many_sizes(ctx, co):
