@@ -974,10 +974,13 @@ def run_rank(args, grp, gpu: int, ctx, net):
         cpu_dt = time.perf_counter() - t
         got = ctx.msm_g1(srs, ctx.to_device(sc_h), m)
         assert (got[:12] == ref).all(), "GPU MSM differs from the CPU oracle on the baseline sample"
-        f_h, g_h = random_fr(1 << 18, 1), random_fr(1 << 18, 2)
+        # BASELINE configs[2] on its own size: the 20-variate product sumcheck (two tables of 2^20 Fr), checked against the GPU transcript
+        f_h, g_h = random_fr(1 << 20, 1), random_fr(1 << 20, 2)
         t = time.perf_counter()
-        co.sumcheck_product(f_h, g_h, chal[:18])
+        sc_ref = co.sumcheck_product(f_h, g_h, chal[:20])
         cpu_sc = time.perf_counter() - t
+        sc_got = ctx.sumcheck_product(ctx.to_device(f_h), ctx.to_device(g_h), 1 << 20, chal[:20])[0]
+        assert (np.asarray(sc_got) == sc_ref[:20]).all(), "GPU product sumcheck differs from the CPU oracle on the baseline sample"
         # generous baseline: the same port on many host cores (the reference itself is single-threaded per
         # party: no `parallel` feature, Cargo.lock:120-134) -- contiguous chunks of the MSM on a thread
         # pool (ctypes releases the GIL), partial results added with the oracle's group law
@@ -1012,8 +1015,8 @@ def run_rank(args, grp, gpu: int, ctx, net):
             "cores": 1,
             "kind": "port",
             "sample": f"one MSM of 2^{args.cpu_log2n} of the same bases/scalars (ark-ec window rule c={co.msm_window(m)}), {cpu_dt:.1f} s; result bit-identical to the GPU",
-            "sumcheck_fr_field_ops_per_s": 18.0 * (1 << 18) / cpu_sc,
-            "sumcheck_sample": f"sumcheck_product on 2^18 random Fr, {cpu_sc:.2f} s",
+            "sumcheck_fr_field_ops_per_s": 18.0 * (1 << 20) / cpu_sc,
+            "sumcheck_sample": f"sumcheck_product on 2^20 random Fr (the size of BASELINE configs[2]), {cpu_sc:.2f} s; transcript bit-identical to the GPU's",
             "all_cores": {"value": m / cpu_mt, "unit": "G1 scalar-muls/s", "cores": cores, "sample": f"same MSM in {cores} chunks on {cores} threads, {cpu_mt:.2f} s"},
             "host": os.uname().nodename,
             "cpu_model": next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "unknown") if os.path.exists("/proc/cpuinfo") else "unknown",

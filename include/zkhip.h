@@ -264,7 +264,7 @@ int zk_msm_set_window(zk_ctx *ctx, int c_override);
 int zk_msm_last_timing(zk_ctx *ctx, float h_ms[6]);
 
 /* device time of the last zk_sumcheck / zk_sumcheck_product / zk_open_rounds call on this ctx, HIP events on the ctx stream,
- * recorded only while the knob "sc_ts" is 3 (zk_dbg_tune): [0] the first stage (the first HBM pass of a large table:
+ * recorded only while the knob "sc_ts" is 3 (ZKHIP_TUNE=sc_ts=3, or zk_dbg_tune of include/zkhip_test.h): [0] the first stage (the first HBM pass of a large table:
  * k_pass<2,1> for the product sumcheck), [1] all launches of the call */
 int zk_sumcheck_last_timing(zk_ctx *ctx, float h_ms[2]);
 
@@ -318,25 +318,7 @@ int zk_scatter(zk_ctx *ctx, const void *d_send, size_t bytes, int root, void *d_
 int zk_d_msm(zk_ctx *ctx, size_t count, const zk_srs *const *srs, const size_t *offsets, const void *const *d_scalars,
              const size_t *n, const uint64_t *h_lambda, const uint64_t *h_coeffs, uint64_t *h_out);
 
-/* ---- TEST HOOKS, NOT ABI: zk_dbg_* exist for tests/ and tools/ only.  They are not part of the drop-in surface, a
- * reference-side binding must not bind them, and they may change or disappear between versions. --- */
-/* Process-wide experiment / diagnostics knobs (csrc/zk_ctx.hpp `struct Tuning` lists them; the same keys are read once
- * from ZKHIP_TUNE="key=value,..."): e.g. "sc_t1_device" = 1 makes the product sumcheck compute t1 = sum f_hi g_hi of
- * EVERY round on the device instead of deriving it from the previous round polynomial (the cross-check of
- * tests/test_gpu_bigsizes.py).  Returns ZK_ERR_INVALID for an unknown key. */
-int zk_dbg_tune(const char *key, long value);
-int zk_dbg_fq_mul(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
-int zk_dbg_fq_add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
-int zk_dbg_fq_sub(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
-/* a*b + b*b through the fused two-product multiplication (one Montgomery reduction) */
-int zk_dbg_fq_mul2add(zk_ctx *ctx, const void *d_a, const void *d_b, void *d_out, size_t n);
-/* device XYZZ formulas on pairs of packed affine points; h_out[i] = 18 u64 normalised Jacobian.
- * mode 0: p+q (mixed add)  1: (p+q)+p (full add)  2: (p+q)+(p+q) (doubling path)  3: p-q */
-int zk_dbg_g1_op(zk_ctx *ctx, int mode, const void *d_p96, const void *d_q96, void *h_out, size_t n);
-
-/* the G2 formulas on pairs of affine points (192 B, reference form); h_out[i] = 36 u64 normalised Jacobian.
- * mode 0: p+q  1: (p+q)+p  2: (p+q)+(p+q) (full-addition doubling path)  3: p-q  4: 2(p+q) (doubling)  5: (p+q)-(p+q) */
-int zk_dbg_g2_op(zk_ctx *ctx, int mode, const void *d_p192, const void *d_q192, void *h_out, size_t n);
+/* (the zk_dbg_* test hooks of the library are declared in include/zkhip_test.h: they are not part of this surface) */
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/zkhip.h"
+#include "../../include/zkhip_test.h"  // (the zk_dbg_* hooks are defined in this library too)
 
 struct zk_msm_job;  // zk_msm.hip
 

@@ -1773,6 +1773,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
             const size_t np_env = (size_t)tn.msm_np;
             while (want < kMaxParts && cl.row_len / want > 16384) want <<= 1;
             if (np_env) want = np_env;
+            while (want < kMaxParts && cl.nb / want > kMaxLow) want <<= 1;  // (tables wider than 20 bits: a partition holds at most kMaxLow buckets)
             cl.np = (u32)std::min<size_t>(cl.nb, want);
         }
         cl.low_bits = 0;

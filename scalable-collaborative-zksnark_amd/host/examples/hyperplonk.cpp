@@ -18,7 +18,7 @@
 //              party fails.  --tamper flips that limb in the transcript under test instead (the run must then FAIL: exit 3).
 //     --dump PREFIX  EVERY party writes the transcript of its last repetition to PREFIX.party<p>.bin (raw limbs behind u64 counts, in
 //              the reference's order): tests/test_protocol_oracle.py compares it position by position with the oracle's straight-line
-//              statement of the call sequence (oracle/pyoracle.py dhyperplonk_all / dpermcheck_all / cpermcheck_all)
+//              statement of the reference's call sequence
 //     --serial-rep  after the timed repetitions, one more proof with every MSM pass run to completion inside the step that owns
 //              it (`End(serial):` lines): the per-step timers of the timed repetitions are OVERLAPPED sections
 #include <algorithm>
@@ -188,6 +188,12 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
             if (a.digest) std::printf("transcript sha256 %s\n", transcript_digest(t).c_str());
             for (auto &m : tm.marks) std::printf("  mark %9.3f ms  %s\n", m.second * 1e3, m.first.c_str());
         }
+    }
+    if (net.is_leader()) {
+        // (the MSM / sumcheck arenas stay with the ctx between proofs: free memory now = the device minus this run's whole footprint;
+        // with one party per GPU -- `--mode rccl` on an 8-GPU node -- that footprint is the per-GPU figure of the configuration)
+        size_t fr = 0, tot = 0;
+        if (a.reps && !zk_mem_info(be.handle(), &fr, &tot)) std::printf("HBM after the proofs: %.1f GiB free of %.1f GiB (tables, parameter set and arenas resident: %.1f GiB in use on this device)\n", fr / 1073741824.0, tot / 1073741824.0, (tot - fr) / 1073741824.0);
     }
     if (net.is_leader() && totals.size() >= 3) {
         // (the first proof of a process also sizes the library's arenas: left out)

@@ -84,6 +84,10 @@ SYMBOLS = [
     ("zk_gather", _i, [_vp, _vp, _sz, _i, _vp]),
     ("zk_scatter", _i, [_vp, _vp, _sz, _i, _vp]),
     ("zk_d_msm", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+]
+
+# include/zkhip_test.h: the zk_dbg_* test hooks -- not part of the ABI, resolved only when a test / tool asks (test_hooks())
+TEST_SYMBOLS = [
     ("zk_dbg_tune", _i, [ctypes.c_char_p, ctypes.c_long]),
     ("zk_dbg_fq_mul", _i, [_vp, _vp, _vp, _vp, _sz]),
     ("zk_dbg_fq_add", _i, [_vp, _vp, _vp, _vp, _sz]),
@@ -129,3 +133,19 @@ def lib() -> ctypes.CDLL:
             f.argtypes = args
         _lib = l
     return _lib
+
+
+_hooks = False
+
+
+def test_hooks() -> ctypes.CDLL:
+    """the library with the zk_dbg_* test hooks of include/zkhip_test.h resolved as well (tests/, tools/, bench.py's timing knobs)"""
+    global _hooks
+    l = lib()
+    if not _hooks:
+        for name, res, args in TEST_SYMBOLS:
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _hooks = True
+    return l

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import ZK_ERR_DIV_ZERO, ZK_ERR_LENGTH
+from ._lib import ZK_ERR_DIV_ZERO, ZK_ERR_LENGTH, test_hooks
 
 
 _TRACE_MSM = bool(os.environ.get("ZKHIP_TRACE_MSM"))
@@ -672,25 +672,26 @@ class Ctx:
         self._check(self.lib.zk_msm_last_timing(self.h, _h(t)))
         return t
 
-    # ---- test hooks ----
+    # ---- test hooks (include/zkhip_test.h: not part of the ABI; resolved on first use) ----
     def dbg_tune(self, key: str, value: int):
         """process-wide experiment / diagnostics knob (zk_dbg_tune; csrc/zk_ctx.hpp `struct Tuning`)"""
-        rc = self.lib.zk_dbg_tune(key.encode(), int(value))
+        rc = test_hooks().zk_dbg_tune(key.encode(), int(value))
         if rc != 0:
             raise ZkError(rc, f"zk_dbg_tune: unknown key {key!r}")
 
     def dbg_fq(self, op: str, a, b, n, out=None):
-        fn = {"add": self.lib.zk_dbg_fq_add, "sub": self.lib.zk_dbg_fq_sub, "mul": self.lib.zk_dbg_fq_mul, "mul2add": self.lib.zk_dbg_fq_mul2add}[op]
+        h = test_hooks()
+        fn = {"add": h.zk_dbg_fq_add, "sub": h.zk_dbg_fq_sub, "mul": h.zk_dbg_fq_mul, "mul2add": h.zk_dbg_fq_mul2add}[op]
         out = out or self.alloc(max(48 * n, 1))
         self._check(fn(self.h, _ptr(a), _ptr(b), _ptr(out), n))
         return out
 
     def dbg_g2_op(self, mode: int, p, q, n) -> np.ndarray:
         out = np.zeros((n, 36), dtype=np.uint64)
-        self._check(self.lib.zk_dbg_g2_op(self.h, mode, _ptr(p), _ptr(q), _h(out), n))
+        self._check(test_hooks().zk_dbg_g2_op(self.h, mode, _ptr(p), _ptr(q), _h(out), n))
         return out
 
     def dbg_g1_op(self, mode: int, p, q, n) -> np.ndarray:
         out = np.zeros((n, 18), dtype=np.uint64)
-        self._check(self.lib.zk_dbg_g1_op(self.h, mode, _ptr(p), _ptr(q), _h(out), n))
+        self._check(test_hooks().zk_dbg_g1_op(self.h, mode, _ptr(p), _ptr(q), _h(out), n))
         return out

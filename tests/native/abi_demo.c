@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "zkhip.h"
+#include "zkhip_test.h" /* (one test hook below: zk_dbg_tune) */
 
 #define CHECK(call)                                                                                   \
     do {                                                                                              \

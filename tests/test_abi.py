@@ -8,8 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "zkhip.h")).read()
+def _header_symbols(name="zkhip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", src)))
 
@@ -24,6 +24,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/zkhip.h but not exported"
     bound = {s[0] for s in zkhip._lib.SYMBOLS}
     assert bound == set(declared), (bound ^ set(declared))
+    # the test hooks live in a header of their own: exported, bound only on request, absent from the ABI header and the Rust binding
+    hooks = _header_symbols("zkhip_test.h")
+    assert hooks and all(h.startswith("zk_dbg_") for h in hooks) and not any(d.startswith("zk_dbg_") for d in declared)
+    for name in hooks:
+        assert hasattr(lib, name), f"{name} declared in include/zkhip_test.h but not exported"
+    assert {s[0] for s in zkhip._lib.TEST_SYMBOLS} == set(hooks)
+    assert "zk_dbg_" not in open(os.path.join(ROOT, "rust", "zkhip_sys.rs")).read()
 
 
 def test_no_silent_fallback_without_gpu():
