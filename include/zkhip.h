@@ -64,6 +64,15 @@ int zk_device_count(void);
 
 /* free / total bytes of the ctx's GPU (hipMemGetInfo; parked zk_free blocks count as used) */
 int zk_mem_info(zk_ctx *ctx, size_t *h_free, size_t *h_total);
+/* The ARENA PLAN of a ctx: the sizes its scratch arenas (MSM passes, asynchronous MSM lanes, sumcheck family, pinned staging) have
+ * grown to.  The arenas are sized on demand, so the FIRST proof of a process pays their allocation (n = 24: ~110 GB, seconds).  A
+ * prover issues the same passes proof after proof: export the plan after one proof of a parameter-set shape (a few hundred bytes,
+ * ZK_ARENA_PLAN_WORDS u64 -- keep it beside the proving key), import it right after zk_ctx_create in later processes, and the first
+ * proof allocates nothing.  Import only grows arenas; ZK_ERR_INVALID for a buffer that is not a plan, ZK_ERR_OOM when the device
+ * cannot hold it (what was allocated stays).  No reference counterpart: the reference allocates per call (Vec per round). */
+#define ZK_ARENA_PLAN_WORDS 48
+int zk_arena_plan_export(zk_ctx *ctx, uint64_t *h_plan /* [ZK_ARENA_PLAN_WORDS] */);
+int zk_arena_plan_import(zk_ctx *ctx, const uint64_t *h_plan /* [ZK_ARENA_PLAN_WORDS] */);
 /* ---- device memory helpers for non-HIP callers.  zk_free parks the block in the ctx (no device
  * synchronisation) and zk_malloc of the same size reuses it; everything is released with the ctx. -- */
 int zk_malloc(zk_ctx *ctx, size_t bytes, void **d_out);

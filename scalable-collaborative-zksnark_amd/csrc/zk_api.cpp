@@ -94,12 +94,24 @@ size_t pool_trim(zk_ctx* ctx) {
 }
 // the ONE hipMalloc site of the library: on out-of-memory the parked blocks are dropped and the
 // allocation retried once (the park is invisible to hipMalloc, torch and RCCL otherwise)
+// Large requests leave kRuntimeReserve of the device to the runtime: a kernel dispatch needs memory of its own (the private segments of
+// the big accumulation kernels, signals, kernarg pools), and a device filled to the last GiB by arenas does not fail a hipMalloc -- it
+// fails the NEXT DISPATCH with HSA_STATUS_ERROR_OUT_OF_RESOURCES and a queue dump, which kills the process (seen with 8 parties' arenas on
+// one GPU).  Refusing the allocation instead is ZK_ERR_OOM: an error the caller can act on.
+static constexpr size_t kRuntimeReserve = (size_t)2 << 30;
+static bool leaves_reserve(size_t bytes) {
+    if (bytes < ((size_t)64 << 20)) return true;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return true;
+    return fr >= bytes && fr - bytes >= kRuntimeReserve;
+}
 hipError_t device_alloc(zk_ctx* ctx, void** out, size_t bytes, bool pool_locked) {
-    hipError_t e = hipMalloc(out, bytes);
+    hipError_t e = leaves_reserve(bytes) ? hipMalloc(out, bytes) : hipErrorOutOfMemory;
     if (e != hipErrorOutOfMemory) return e;
     (void)hipGetLastError();
     if (pool_locked) pool_flush_locked(ctx);
     else pool_trim(ctx);
+    if (!leaves_reserve(bytes)) return hipErrorOutOfMemory;
     return hipMalloc(out, bytes);
 }
 void* scratch(zk_ctx* ctx, int slot, size_t bytes) {
@@ -144,6 +156,38 @@ using namespace zk;
 extern "C" {
 
 const char* zk_version(void) { return "zkhip 0.1 (gfx950)"; }
+
+// ---- the arena plan (include/zkhip.h): [magic, lanes, 12 scratch caps, pinned cap, 3 x (10 lane caps, lane pinned cap)] ----
+static constexpr uint64_t kPlanMagic = 0x31304e414c504b5aull;  // "ZKPLAN01"
+int zk_arena_plan_export(zk_ctx* ctx, uint64_t* h_plan) {
+    if (!ctx || !h_plan) return ZK_ERR_INVALID;
+    static_assert(2 + 12 + 1 + (zk_ctx::kLanes - 1) * 11 == ZK_ARENA_PLAN_WORDS, "plan layout");
+    size_t k = 0;
+    h_plan[k++] = kPlanMagic;
+    h_plan[k++] = zk_ctx::kLanes;
+    for (int i = 0; i < 12; i++) h_plan[k++] = ctx->scratch[i].p ? ctx->scratch[i].cap : 0;
+    h_plan[k++] = ctx->h_pinned ? ctx->h_pinned_cap : 0;
+    for (int l = 1; l < zk_ctx::kLanes; l++) {
+        for (int i = 0; i < 10; i++) h_plan[k++] = ctx->lanes[l].mem[i].p ? ctx->lanes[l].mem[i].cap : 0;
+        h_plan[k++] = ctx->lanes[l].pinned ? ctx->lanes[l].pinned_cap : 0;
+    }
+    return ZK_OK;
+}
+int zk_arena_plan_import(zk_ctx* ctx, const uint64_t* h_plan) {
+    if (!ctx || !h_plan) return ZK_ERR_INVALID;
+    if (h_plan[0] != kPlanMagic || h_plan[1] != (uint64_t)zk_ctx::kLanes) return fail(ctx, ZK_ERR_INVALID, "zk_arena_plan_import: not an arena plan of this library version");
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    size_t k = 2;
+    for (int i = 0; i < 12; i++, k++)
+        if (h_plan[k] && !scratch(ctx, i, (size_t)h_plan[k])) return ZK_ERR_OOM;
+    if (h_plan[k] && !pinned(ctx, (size_t)h_plan[k])) return ZK_ERR_OOM;
+    k++;
+    for (int l = 1; l < zk_ctx::kLanes; l++, k += 11) {
+        const int rc = msm_lanes_reserve(ctx, l, h_plan + k, h_plan[k + 10]);
+        if (rc) return rc;
+    }
+    return ZK_OK;
+}
 
 int zk_device_count(void) {
     int count = 0;

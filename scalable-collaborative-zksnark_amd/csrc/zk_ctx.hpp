@@ -131,6 +131,7 @@ void* pinned(zk_ctx* ctx, size_t bytes);
 // hipMalloc that drops the ctx's parked zk_free blocks and retries once on out-of-memory
 hipError_t device_alloc(zk_ctx* ctx, void** out, size_t bytes, bool pool_locked = false);
 size_t pool_trim(zk_ctx* ctx);
+int msm_lanes_reserve(zk_ctx* ctx, int lane, const uint64_t* caps10, uint64_t pinned_cap);  // zk_msm.hip: grow an asynchronous lane's arenas
 
 #define ZK_HIP(ctx, call)                                            \
     do {                                                             \

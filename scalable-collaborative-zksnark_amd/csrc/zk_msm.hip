@@ -1609,6 +1609,43 @@ static int msm_lane_prepare(zk_ctx* ctx, int lane) {
     return ZK_OK;
 }
 #ifndef ZK_MSM_TU_G2  // (G1 translation unit only)
+// zk_arena_plan_import: an idle asynchronous lane's arenas grown to the given sizes
+int msm_lanes_reserve(zk_ctx* ctx, int lane, const uint64_t* caps10, uint64_t pinned_cap) {
+    if (lane < 1 || lane >= zk_ctx::kLanes) return fail(ctx, ZK_ERR_INVALID, "arena plan: lane out of range");
+    zk_ctx::MsmLane& L = ctx->lanes[lane];
+    if (L.busy) return fail(ctx, ZK_ERR_INVALID, "arena plan: an MSM job is in flight on lane %d", lane);
+    bool any = pinned_cap != 0;
+    for (int i = 0; i < 10; i++) any = any || caps10[i] != 0;
+    if (!any) return ZK_OK;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        const int rc = msm_lane_prepare(ctx, lane);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < 10; i++) {
+        zk_ctx::Arena& a = L.mem[i];
+        if (a.cap >= caps10[i]) continue;
+        if (a.p) hipFree(a.p);
+        a.p = nullptr, a.cap = 0;
+        const hipError_t e = device_alloc(ctx, &a.p, (size_t)caps10[i]);
+        if (e != hipSuccess) {
+            a.p = nullptr;
+            return hip_fail(ctx, e, "hipMalloc(arena plan, msm lane)");
+        }
+        a.cap = (size_t)caps10[i];
+    }
+    if (L.pinned_cap < pinned_cap) {
+        if (L.pinned) hipHostFree(L.pinned);
+        L.pinned = nullptr, L.pinned_cap = 0;
+        const hipError_t e = hipHostMalloc(&L.pinned, (size_t)pinned_cap, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            L.pinned = nullptr;
+            return hip_fail(ctx, e, "hipHostMalloc(arena plan, msm lane)");
+        }
+        L.pinned_cap = (size_t)pinned_cap;
+    }
+    return ZK_OK;
+}
 void msm_lanes_destroy(zk_ctx* ctx) {
     for (int i = 0; i < zk_ctx::kLanes; i++) {
         zk_ctx::MsmLane& L = ctx->lanes[i];

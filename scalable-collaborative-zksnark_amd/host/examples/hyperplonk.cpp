@@ -3,7 +3,7 @@
 // run the collaborative proof on the GPU(s), print the reference's timer labels and its `Comm: (up, down)` line (:564).
 //
 //   hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2]
-//              [--digest] [--dump PREFIX] [--check] [--tamper] [--serial-rep]
+//              [--digest] [--dump PREFIX] [--check] [--tamper] [--serial-rep] [--arena-plan FILE]
 //     leader   party 0 on the no-`comm` echo net (the reference's `-F leader` build: one party's full work; default)
 //     threads  all 8 l parties as threads of this process, one ctx each, exchanges through host memory (LocalTestNet); the
 //              parties share the visible GPUs round-robin
@@ -19,6 +19,9 @@
 //     --dump PREFIX  EVERY party writes the transcript of its last repetition to PREFIX.party<p>.bin (raw limbs behind u64 counts, in
 //              the reference's order): tests/test_protocol_oracle.py compares it position by position with the oracle's straight-line
 //              statement of the reference's call sequence
+//     --arena-plan FILE  (leader mode) the ctx's arena plan (zk_arena_plan_export / _import): imported after the setup when FILE exists -- the
+//              first proof then allocates nothing --, written after the repetitions.  Keep it beside the proving key: it depends on
+//              (n, l, which) only
 //     --serial-rep  after the timed repetitions, one more proof with every MSM pass run to completion inside the step that owns
 //              it (`End(serial):` lines): the per-step timers of the timed repetitions are OVERLAPPED sections
 #include <algorithm>
@@ -36,7 +39,7 @@ using namespace zkhost;
 
 struct Args {
     size_t l = 1, n = 12, reps = 3, table_max = 25;
-    std::string mode = "leader", which = "dhyperplonk", dump;
+    std::string mode = "leader", which = "dhyperplonk", dump, arena_plan;
     bool tables = true, digest = false, check = false, tamper = false, serial_rep = false, marks = false, share_gpus = false;
 };
 
@@ -169,6 +172,17 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
         size_t fr = 0, tot = 0;
         if (!zk_mem_info(be.handle(), &fr, &tot)) std::printf("setup %.3f s; HBM after setup: %.1f GiB free of %.1f GiB\n", setup, fr / 1073741824.0, tot / 1073741824.0);
     }
+    if (!a.arena_plan.empty() && net.n_parties > 0 && a.mode == "leader") {
+        uint64_t plan[ZK_ARENA_PLAN_WORDS];
+        if (std::FILE *f = std::fopen(a.arena_plan.c_str(), "rb")) {
+            bool ok = std::fread(plan, 8, ZK_ARENA_PLAN_WORDS, f) == ZK_ARENA_PLAN_WORDS;
+            std::fclose(f);
+            auto t1 = std::chrono::steady_clock::now();
+            if (ok) be.check(zk_arena_plan_import(be.handle(), plan));
+            be.sync();
+            std::printf("arena plan %s: %s (%.3f s)\n", a.arena_plan.c_str(), ok ? "imported" : "unreadable, ignored", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+        }
+    }
     std::vector<std::string> digests;
     std::vector<double> totals;
     for (size_t r = 0; r < a.reps; ++r) {
@@ -194,6 +208,14 @@ static void party(const Args &a, const PackedSharingParams &pp, Ctx &be, Net &ne
         // with one party per GPU -- `--mode rccl` on an 8-GPU node -- that footprint is the per-GPU figure of the configuration)
         size_t fr = 0, tot = 0;
         if (a.reps && !zk_mem_info(be.handle(), &fr, &tot)) std::printf("HBM after the proofs: %.1f GiB free of %.1f GiB (tables, parameter set and arenas resident: %.1f GiB in use on this device)\n", fr / 1073741824.0, tot / 1073741824.0, (tot - fr) / 1073741824.0);
+    }
+    if (!a.arena_plan.empty() && a.mode == "leader" && a.reps) {
+        uint64_t plan[ZK_ARENA_PLAN_WORDS];
+        be.check(zk_arena_plan_export(be.handle(), plan));
+        if (std::FILE *f = std::fopen(a.arena_plan.c_str(), "wb")) {
+            std::fwrite(plan, 8, ZK_ARENA_PLAN_WORDS, f);
+            std::fclose(f);
+        }
     }
     if (net.is_leader() && totals.size() >= 3) {
         // (the first proof of a process also sizes the library's arenas: left out)
@@ -239,6 +261,7 @@ int main(int argc, char **argv) {
         else if (k == "--no-tables") a.tables = false;
         else if (k == "--digest") a.digest = true;
         else if (k == "--dump") a.dump = val();
+        else if (k == "--arena-plan") a.arena_plan = val();
         else if (k == "--check") a.check = true;
         else if (k == "--serial-rep") a.serial_rep = true;
         else if (k == "--marks") a.marks = true;  // diagnostics: host time stamps of the calls inside a proof
@@ -247,7 +270,7 @@ int main(int argc, char **argv) {
         else if (k == "--table-max") a.table_max = std::strtoull(val(), nullptr, 10);
         else if (k == "--table-rec") setenv("ZKHOST_TABLE_REC", val(), 1);  // 128: one G1 table record per cache line (4/3 of the table memory)
         else {
-            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--table-rec 96|128] [--digest] [--dump PREFIX] [--check] [--tamper] [--serial-rep]\n");
+            std::fprintf(stderr, "usage: hyperplonk --l L --n N [--mode leader|threads|rccl] [--which dhyperplonk|data-parallel|dpermcheck|cpermcheck] [--reps R] [--no-tables] [--table-max LOG2] [--table-rec 96|128] [--digest] [--dump PREFIX] [--check] [--tamper] [--serial-rep] [--arena-plan FILE]\n");
             return 64;
         }
     }

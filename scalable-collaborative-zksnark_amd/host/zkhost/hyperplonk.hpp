@@ -102,7 +102,7 @@ struct PackedProvingParameters {
     }
     // the folds of V and the synthetic SRS (random points in the reference as well); window_tables: build the MSM window
     // table of every level up to 2^table_max_log2 points (setup work like generating the level; results are bit-identical
-    // with and without); a level is skipped when its table would leave less than 40 % of the device free (the rule is below)
+    // with and without); a level is skipped when its table would leave less than half of the device free (the rule is below)
     // window_bits(len): width of a level's table (0 = the library's pick for a single MSM of that length)
     void finish_setup(Ctx &be, const PackedSharingParams &pp, uint64_t seed, bool window_tables = true, size_t table_max_log2 = 25,
                       const std::function<int(size_t)> &window_bits = nullptr) {
@@ -122,8 +122,9 @@ struct PackedProvingParameters {
         // Record layout per level (round 6; the Python host applies the same rule, zkhip/hyperplonk.py `_synthetic_srs`).  A G1 table record is
         // 96 B packed or 128 B -- one per cache line: the accumulation's gathers move 1 line instead of 1.67, k_accum_tiles -7 .. -10 %
         // (profiles/r05zb_table_rec_ab.txt) for 4/3 of the table memory.  The levels are built smallest first and each takes what the device
-        // can spare at that moment: 128-B records while that leaves >= 60 % of the device free, packed records while that leaves >= 40 %
-        // (the MSM arenas of an n = 24 proof want ~80 GB), no table -- the table-less path -- below that.  A GPU shared by several parties
+        // can spare at that moment: 128-B records while that leaves >= 60 % of the device free, packed records while that leaves >= 50 %
+        // (the pass arenas of an n = 24 proof grow to ~110 GB, its self-checked / serial-steps forms to more: profiles/r06n_n24_classes.txt),
+        // no table -- the table-less path -- below that.  A GPU shared by several parties
         // (threads mode) fills up as the parties build their sets, and the later / larger levels fall back by themselves.
         // ZKHOST_TABLE_REC=96 / 128 forces one layout for every level (A/B runs).
         static const int table_rec = [] {
@@ -140,10 +141,10 @@ struct PackedProvingParameters {
             int rec = 96;
             if (table_rec == 96 || table_rec == 128) {
                 rec = table_rec;
-                if (left_after(rec) < 0.4) break;
+                if (left_after(rec) < 0.5) break;
             } else if (left_after(128.0) >= 0.6) {
                 rec = 128;
-            } else if (left_after(96.0) < 0.4) {
+            } else if (left_after(96.0) < 0.5) {
                 break;
             }
             int rc = zk_srs_precompute_layout(be.handle(), lv->handle(), window_bits ? window_bits(len) : 0, rec);

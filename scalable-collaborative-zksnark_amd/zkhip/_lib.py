@@ -84,6 +84,8 @@ SYMBOLS = [
     ("zk_gather", _i, [_vp, _vp, _sz, _i, _vp]),
     ("zk_scatter", _i, [_vp, _vp, _sz, _i, _vp]),
     ("zk_d_msm", _i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("zk_arena_plan_export", _i, [_vp, _vp]),
+    ("zk_arena_plan_import", _i, [_vp, _vp]),
 ]
 
 # include/zkhip_test.h: the zk_dbg_* test hooks -- not part of the ABI, resolved only when a test / tool asks (test_hooks())

@@ -254,6 +254,18 @@ class Ctx:
         self._check(self.lib.zk_mem_info(self.h, ctypes.byref(f), ctypes.byref(t)))
         return f.value, t.value
 
+    def arena_plan_export(self) -> np.ndarray:
+        """the sizes this ctx's scratch arenas have grown to (zk_arena_plan_export): 48 u64 -- keep them beside the proving key"""
+        plan = np.zeros(48, dtype=np.uint64)
+        self._check(self.lib.zk_arena_plan_export(self.h, _h(plan)))
+        return plan
+
+    def arena_plan_import(self, plan):
+        """grow the arenas to a plan exported after an earlier proof of the same shape: the first proof then allocates nothing"""
+        plan = np.ascontiguousarray(plan, dtype=np.uint64).reshape(-1)
+        assert plan.size == 48
+        self._check(self.lib.zk_arena_plan_import(self.h, _h(plan)))
+
     def trim(self) -> int:
         """hand every parked zk_free block back to the driver; returns the bytes released"""
         f = ctypes.c_size_t(0)

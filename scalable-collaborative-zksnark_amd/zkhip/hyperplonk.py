@@ -63,9 +63,9 @@ class PackedProvingParameters:
         for all parties, mpc-net/src/multi.rs:344); pass the same chal_seed to parties with different table seeds.
         window_tables: build the MSM window table of every SRS level up to 2^table_max_log2 points (zk_srs_precompute: setup work
         like generating the level, 13-16 x its memory; results are bit-identical with and without).  The tables only take
-        memory the proof does not need: a level is skipped when building its table would leave less than 40 % of the device
-        free (the MSM arenas of an n = 24 proof want ~80 GB); at n = 24 on a 288-GB MI355X the levels up to 2^24 points get
-        theirs (n = 24 proof 0.99 -> 0.93 s), the 2^25 / 2^26-point levels of the c-SRS run table-less.
+        memory the proof does not need: a level is skipped when building its table would leave less than half of the device
+        free (the pass arenas of an n = 24 proof grow to ~110 GB); at n = 24 on a 288-GB MI355X the levels up to 2^24 points get
+        theirs, the 2^25 / 2^26-point levels of the c-SRS run table-less (a 2^25-point table is built where the memory allows: n <= 23).
         """
         l, npar = pp.l, pp.n
         M = 1 << n
@@ -137,7 +137,7 @@ class PackedProvingParameters:
         if window_tables:
             # Largest levels last; each takes what the device can spare at that moment (the rule of zkhost/hyperplonk.hpp finish_setup): 128-B
             # records -- one per cache line, k_accum_tiles -7 .. -10 % for 4/3 of the memory -- while that leaves >= 60 % of the device free,
-            # packed 96-B records while that leaves >= 40 % (the MSM arenas of an n = 24 proof want ~80 GB), no table below that: the level
+            # packed 96-B records while that leaves >= 50 % (the pass arenas of an n = 24 proof grow to ~110 GB), no table below that: the level
             # then runs the table-less path.  A GPU shared by several parties fills up and the later / larger levels fall back by themselves.
             for lv in sorted(pk.c_commitment + pk.d_commitment, key=len):
                 if hasattr(lv, "precompute") and 64 <= len(lv) <= (1 << table_max_log2):
@@ -146,11 +146,11 @@ class PackedProvingParameters:
                         free, total = be.mem_info()
                         left_after = lambda rec_bytes: (free - 16 * rec_bytes * len(lv)) / total
                         if TABLE_REC in (96, 128):
-                            if left_after(TABLE_REC) < 0.4:
+                            if left_after(TABLE_REC) < 0.5:
                                 break
                         elif left_after(128) >= 0.6:
                             rec = 128
-                        elif left_after(96) < 0.4:
+                        elif left_after(96) < 0.5:
                             break
                         else:
                             rec = 96

@@ -337,3 +337,42 @@ def test_async_jobs_match_blocking_calls(ctx, co):
     with pytest.raises(zkhip.MsmLengthError):
         ctx.msm_g1_batch_async([srs[1]], [dsc[0]], [sizes[0]])
     assert (ctx.msm_g1_batch_async(srs, dsc, sizes).wait() == want).all()
+
+
+def test_arena_plan_round_trip_makes_the_first_pass_allocation_free():
+    """
+    zk_arena_plan_export / zk_arena_plan_import (include/zkhip.h): a ctx that imports the plan another ctx exported after a batch of
+    MSMs and sumchecks runs the same work without growing an arena (export before == export after), with the same results; a
+    buffer that is not a plan is refused.
+    """
+    import zkhip
+
+    def work(c):
+        n = 1 << 14
+        srs = c.srs_generate(5, 7, n)
+        srs.precompute(0)
+        sc = c.to_device(rand_fr(n, 3))
+        out = [c.msm_g1(srs, sc, n)]
+        job = c.msm_g1_batch_async([srs, srs], [sc, sc], [n, n // 2])
+        out.append(job.wait())
+        f, g = c.to_device(rand_fr(1 << 15, 1)), c.to_device(rand_fr(1 << 15, 2))
+        out.append(c.sumcheck_product(f, g, 1 << 15, rand_fr(15, 9))[0])
+        return out
+
+    a = zkhip.Ctx(0)
+    ref = work(a)
+    plan = a.arena_plan_export()
+    assert plan[0] == 0x31304E414C504B5A and plan[2:].any()
+    a.close()
+    b = zkhip.Ctx(0)
+    assert not b.arena_plan_export()[2:].any()
+    b.arena_plan_import(plan)
+    before = b.arena_plan_export()
+    assert (before >= plan).all()
+    got = work(b)
+    assert (b.arena_plan_export() == before).all(), "the work grew an arena although the plan was imported"
+    for x, y in zip(ref, got):
+        assert (np.asarray(x) == np.asarray(y)).all()
+    with pytest.raises(zkhip.ZkError):
+        b.arena_plan_import(np.zeros(48, dtype=np.uint64))
+    b.close()
