@@ -300,6 +300,11 @@ int zk_comm_init(zk_ctx *ctx, int rank, int world, const uint8_t h_id[ZK_COMM_ID
  * communicator from a single thread deadlocks in the first exchange that returns host results (e.g. zk_d_msm). */
 int zk_comm_init_all(zk_ctx *const *ctxs, int world);
 int zk_comm_destroy(zk_ctx *ctx); /* also done by zk_ctx_destroy */
+/* A party that cannot go on for a reason of its own (an out-of-memory arena, a failed kernel: anything outside the exchanges, which carry
+ * their own status words) aborts its communicator (ncclCommAbort) so that its peers' pending and later collectives end with
+ * ZK_ERR_COMM instead of waiting for it -- the library's form of the reference's `unwrap()` panic taking the job down
+ * (mpc-net/src/multi.rs:330-352).  The ctx is left without a communicator. */
+int zk_comm_abort(zk_ctx *ctx);
 int zk_comm_rank(const zk_ctx *ctx);
 int zk_comm_size(const zk_ctx *ctx);
 /* d_recv[p * bytes ..] = party p's d_send, for every p, on every party */

@@ -205,6 +205,14 @@ int zk_comm_init_all(zk_ctx* const* ctxs, int world) {
     return rc;
 }
 
+int zk_comm_abort(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_INVALID;
+    if (!ctx->comm) return ZK_OK;
+    Rccl* r = rccl();
+    if (r) comm_abort(ctx, r);
+    return ZK_OK;
+}
+
 int zk_comm_destroy(zk_ctx* ctx) {
     if (!ctx) return ZK_ERR_INVALID;
     if (!ctx->comm) return ZK_OK;

@@ -301,8 +301,15 @@ int main(int argc, char **argv) {
             ctxs[0]->check(zk_comm_init_all(raw.data(), (int)pp.n));
             // every party on its own host thread (the collectives block until all parties have entered them)
             LocalTestNet::simulate_network_round(pp.n, [&](size_t p, LocalTestNet &) {
-                RcclNet net(*ctxs[p]);
-                party(a, pp, *ctxs[p], net);
+                try {
+                    RcclNet net(*ctxs[p]);
+                    party(a, pp, *ctxs[p], net);
+                } catch (...) {
+                    // a party that fails outside zk_d_msm (which carries its own status words) -- an out-of-memory arena, say -- must not
+                    // leave its peers waiting inside a collective (include/zkhip.h, zk_comm_abort)
+                    zk_comm_abort(ctxs[p]->handle());
+                    throw;
+                }
             });
         } else {
             throw std::invalid_argument("unknown --mode " + a.mode);

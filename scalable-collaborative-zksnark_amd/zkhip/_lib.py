@@ -77,6 +77,7 @@ SYMBOLS = [
     ("zk_comm_init", _i, [_vp, _i, _i, _vp]),
     ("zk_comm_init_all", _i, [_vp, _i]),
     ("zk_comm_destroy", _i, [_vp]),
+    ("zk_comm_abort", _i, [_vp]),
     ("zk_comm_rank", _i, [_vp]),
     ("zk_comm_size", _i, [_vp]),
     ("zk_allgather", _i, [_vp, _vp, _sz, _vp]),
