@@ -63,7 +63,7 @@ def transcript_sha256(res) -> str:
 
 
 def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = False, serial_rep: bool = False, timeout: int = 900, mode: str = "leader",
-                 share_gpus: bool = False, env: dict = None, which: str = "dhyperplonk"):
+                 share_gpus: bool = False, env: dict = None, which: str = "dhyperplonk", arena_plan: str = None):
     """
     The same proof driven by the COMPILED host (scalable-collaborative-zksnark_amd/host: zkhost/hyperplonk.hpp, the C++ mirror of the
     reference's Rust crates above the C ABI) in its own process: leader mode, the SplitMix64 parameter set of the e2e leg (seed 100,
@@ -81,6 +81,7 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = F
     try:
         cmd = [exe, "--l", "1", "--n", str(n), "--reps", str(reps), "--digest"] + (["--check"] if check else []) + (["--serial-rep"] if serial_rep else [])
         cmd += (["--mode", mode] if mode != "leader" else []) + (["--share-gpus"] if share_gpus else []) + (["--which", which] if which != "dhyperplonk" else [])
+        cmd += ["--arena-plan", arena_plan] if arena_plan else []  # (imported after the setup when the file exists, written after the repetitions)
         TOT = {"dhyperplonk": "Distributed HyperPlonk", "data-parallel": "Distributed HyperPlonk", "dpermcheck": "Distributed Permcheck", "cpermcheck": "Collaborative Permcheck"}[which]
         parties = 1 if mode == "leader" else 8
         t0 = time.perf_counter()
@@ -88,10 +89,12 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = F
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": f"rc {r.returncode}: {(r.stdout[-400:] + r.stderr[-300:])}"}
-        runs, comm, digests, serial, checks, setup = [], None, set(), {}, [], None
+        runs, comm, digests, serial, checks, setup, plan_note = [], None, set(), {}, [], None, None
         for line in r.stdout.splitlines():
             w = line.split()
-            if line.startswith("rep "):
+            if line.startswith("arena plan "):
+                plan_note = line
+            elif line.startswith("rep "):
                 runs.append({})
                 setup = float(w[3])
             elif line.startswith("  End(serial):"):
@@ -110,9 +113,11 @@ def cpp_host_e2e(n: int, reps: int = 4, want_digest: str = None, check: bool = F
                "timers_note": "'Commit' / 'Wire identity' / 'Open' of timers_s are OVERLAPPED sections (a step's MSM pass is started asynchronously and collected later; the kernel phase of "
                               "the Open step runs inside 'Wire identity'): they are not the reference's phases of the same name, only 'Distributed HyperPlonk' is comparable. "
                               "timers_s_serial_steps (when present) runs every pass to completion inside its own step",
-               "first_proof_note": "the first proof of a process also allocates the library's MSM arenas and job lanes (sized by demand); later proofs reuse them",
+               "first_proof_note": "the first proof of a process also allocates the library's MSM arenas and job lanes (sized by demand); later proofs reuse them; a process that imports the arena plan of an earlier one (zk_arena_plan_import) skips that: second_process_with_arena_plan",
                "what": "the same call sequence on the same parameter set from the compiled C++ host (zkhost/hyperplonk.hpp) in its own process, "
                        + ("leader mode" if mode == "leader" else f"--mode {mode}: 8 parties = 8 host threads of one process, party p on GPU p, exchanges over RCCL")}
+        if arena_plan:
+            out["arena_plan"] = plan_note or "none found: this run sized its arenas on demand and wrote the plan"
         if mode != "leader":
             out["stderr_tail"] = r.stderr[-300:]
         if which not in ("dhyperplonk", "data-parallel"):
@@ -615,7 +620,18 @@ def run_rank(args, grp, gpu: int, ctx, net):
             if free_b < need_b:
                 extra["e2e_n24"] = {"skipped": f"{free_b >> 30} GiB of HBM free, the n = 24 parameter set with its window tables and pass arenas wants ~{need_b >> 30} GiB"}
             else:
-                r24 = cpp_host_e2e(24, reps=2, check=True, serial_rep=True, timeout=1500)
+                plan24 = os.path.join(ROOT, "gpurun_out", ".arena_plan_n24.bin")
+                os.makedirs(os.path.dirname(plan24), exist_ok=True)
+                if os.path.exists(plan24):
+                    os.remove(plan24)
+                r24 = cpp_host_e2e(24, reps=2, check=True, serial_rep=True, timeout=1500, arena_plan=plan24)
+                # a second process of the same prover with the arena plan the first one left (zk_arena_plan_import right after the setup):
+                # its FIRST proof allocates nothing -- what a deployment that keeps the plan beside its proving key sees
+                if "error" not in r24 and os.path.exists(plan24):
+                    again = cpp_host_e2e(24, reps=2, timeout=900, arena_plan=plan24)
+                    t_first, t_best = again.get("first_proof_s"), (again.get("timers_s") or {}).get("Distributed HyperPlonk")
+                    r24["second_process_with_arena_plan"] = {"first_proof_s": t_first, "steady_proof_s": t_best, "first_over_steady": (t_first / t_best) if t_first and t_best else None,
+                                                             "arena_plan": again.get("arena_plan"), "error": again.get("error")}
                 # the driver returns the child's ~200 GiB of HBM asynchronously after its exit: wait until this process sees them again
                 # (an allocation of the next leg right behind the child's exit was refused once the tables grew to 128-B records)
                 t_w = time.perf_counter()

@@ -108,6 +108,7 @@ struct Tuning {
     long msm_split = 1;       // staggered parts of the largest class
     long msm_np = 0;          // sort partitions per row (0: auto)
     long msm_fused_min = 0;   // window-table rows of >= 2^k entries are partitioned straight from the scalars (0: k = 23; -1: never -- the round-5 path)
+    long msm_idx_ahead = 1;   // k_accum_tiles: the sorted index of the entry after next is fetched one iteration early (0: the round-5 loop)
     long msm_tab_spt = 0;     // fused level 1: 1 forces one scalar per thread (A/B)
     long msm_l2_tiled = 0;    // level 2 in LDS-staged tiles for partitions of >= this many entries (0: 8192, rows of >= 2^23 entries; -1: never)
     long msm_debug = 0;       // class geometry on stderr

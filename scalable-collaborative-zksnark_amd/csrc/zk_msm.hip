@@ -1068,7 +1068,7 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
                                                     const u32* __restrict__ sorted, const uint2* __restrict__ oc_all,
                                                     const u32* __restrict__ tile_b, size_t ns, u32 nsi, int nsi_shift, size_t nb, u32 T,
                                                     size_t tiles_per_w, size_t total_tiles, void* __restrict__ buckets,
-                                                    void* __restrict__ heads, void* __restrict__ tails) {
+                                                    void* __restrict__ heads, void* __restrict__ tails, int idx_ahead) {
   // one tile per lane; with a capped grid (tuning knob msm_share: a pass that leaves workgroup slots to other kernels) a lane
   // takes every gridDim.x * kBlk-th tile
   for (size_t g = (size_t)blockIdx.x * kBlk + threadIdx.x; g < total_tiles; g += (size_t)gridDim.x * kBlk) {
@@ -1097,6 +1097,9 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
     typename Cv::Xyzz acc;
     Cv::set_inf(acc);
     u32 v = run[e0];
+    // the index of the entry after next is fetched one iteration early: the gather of the next point then leaves at the top of the
+    // iteration instead of behind the round trip of its own index (two dependent loads in a row were a stall of the whole wave)
+    u32 vn = (idx_ahead && e0 + 1 < e1) ? run[e0 + 1] : 0u;
     typename Cv::Aff p = Cv::aff_load_rec(bases, pidx(v), it.rec);
     for (u32 e = e0; e < e1; e++) {
         if (e == bend) {  // run finished: flush and move to the next non-empty bucket
@@ -1114,7 +1117,12 @@ static __global__ void __launch_bounds__(kBlk) k_accum_tiles(const ItemDesc* __r
         const bool neg = (v >> 31) != 0;
         typename Cv::Aff cur = p;
         if (e + 1 < e1) {  // prefetch the next point while this one is being added
-            v = run[e + 1];
+            if (idx_ahead) {
+                v = vn;
+                if (e + 2 < e1) vn = run[e + 2];
+            } else {
+                v = run[e + 1];
+            }
             p = Cv::aff_load_rec(bases, pidx(v), it.rec);
         }
         Cv::madd(acc, cur, neg);
@@ -2046,7 +2054,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         const size_t accum_wgs = run.accum_wg_cap ? std::min<size_t>(accum_wgs_full, run.accum_wg_cap) : accum_wgs_full;
         hipLaunchKernelGGL((k_accum_tiles<Cv>), dim3((unsigned)accum_wgs), dim3(kBlk), 0, st,
                            (const ItemDesc*)d_items, cl.rpi, (const u32*)sorted, (const uint2*)oc, (const u32*)tile_b, cl.row_len,
-                           (u32)ns, ((ns & (ns - 1)) == 0) ? (int)__builtin_ctzll(ns) : -1, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails);
+                           (u32)ns, ((ns & (ns - 1)) == 0) ? (int)__builtin_ctzll(ns) : -1, nb, cl.T, cl.tiles_per_w, cl.total_tiles, bufA, heads, tails, (int)tn.msm_idx_ahead);
         if (cl.nparts > 1 && cl.part + 1 < cl.nparts) hipEventRecord(L.ev_part[cl.part % zk_ctx::kParts], st);
         if (t_last) hipEventRecord(ctx->ev[4], st);
         const NarrowRows nrw{cl.rpi, cl.w0, cl.narrow_from};

@@ -137,7 +137,7 @@ def test_a_swapped_challenge_slice_or_output_position_is_caught(monkeypatch):
 
 
 # ---------------------------------------------------------------- GPU: the same comparisons through libzkhip.so
-GPU_CASES = CASES + [("dpermcheck", 6, 2), ("data-parallel", 6, 2)]
+GPU_CASES = CASES + [("dpermcheck", 6, 2), ("data-parallel", 6, 2), ("dhyperplonk", 8, 4)]
 
 
 @pytest.mark.gpu
@@ -205,7 +205,9 @@ def _cpp_run(tmp_path, which, n, l, mode, env=None):
 @pytest.mark.gpu
 @pytest.mark.parametrize("which,n,l,mode", [("dhyperplonk", 5, 1, "threads"), ("dhyperplonk", 6, 1, "threads"), ("data-parallel", 5, 1, "threads"), ("dpermcheck", 5, 1, "threads"),
                                             ("cpermcheck", 5, 1, "threads"), ("dhyperplonk", 6, 2, "threads"), ("cpermcheck", 6, 2, "threads"),
-                                            ("dhyperplonk", 6, 1, "leader"), ("cpermcheck", 5, 1, "leader"), ("cpermcheck", 6, 2, "leader")])
+                                            ("dhyperplonk", 6, 1, "leader"), ("cpermcheck", 5, 1, "leader"), ("cpermcheck", 6, 2, "leader"),
+                                            # 32 real parties (l = 4 needs n >= 8: the leader tree of 32 parties wants SRS level 5) and the leader of 64
+                                            ("dhyperplonk", 8, 4, "threads"), ("cpermcheck", 8, 4, "threads"), ("dhyperplonk", 10, 8, "leader")])
 def test_compiled_host_equals_the_straight_line_oracle(tmp_path, which, n, l, mode):
     """host/bin/hyperplonk (zkhost/hyperplonk.hpp): every party's dumped transcript against the oracle driver on the same SplitMix64
     parameter set (PackedProvingParameters::make = PackedProvingParameters.new_splitmix: seed 100 + p, challenges 4242)"""

@@ -11,7 +11,7 @@ for MODE in r06 r05; do
     rm -rf /tmp/ps_$C
     ZKHIP_TUNE=$T ZK_ONLY_TABLE=1 rocprofv3 --pmc $C -f csv -d /tmp/ps_$C -o pmc -- python $REPO/tools/msm_time.py $N > /dev/null 2>/tmp/ps_$C.err
   done
-  echo "# $MODE: window-table MSM of 2^$N points" >> $OUT/${TAG}_sort_pmc_hbm_traffic.csv
-  python $REPO/tools/pmc_summary.py $(find /tmp/ps_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/ps_WRITE_SIZE -name '*counter_collection.csv' | head -1) | grep -E "counter|k_digits|k_part|k_tab|k_l2" >> $OUT/${TAG}_sort_pmc_hbm_traffic.csv
+  echo "# $MODE: window-table MSM of 2^$N points" >> $OUT/${TAG}_sort_phase_pmc.csv
+  python $REPO/tools/pmc_summary.py $(find /tmp/ps_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/ps_WRITE_SIZE -name '*counter_collection.csv' | head -1) | grep -E "counter|k_digits|k_part|k_tab|k_l2" >> $OUT/${TAG}_sort_phase_pmc.csv
 done
-cat $OUT/${TAG}_sort_pmc_hbm_traffic.csv
+cat $OUT/${TAG}_sort_phase_pmc.csv
