@@ -16,7 +16,7 @@ struct TuneKey {
     long Tuning::*field;
 };
 static const TuneKey kTuneKeys[] = {
-    {"sc_pass_wg", &Tuning::sc_pass_wg}, {"sc_local_g", &Tuning::sc_local_g}, {"sc_ts", &Tuning::sc_ts}, {"sc_xcd", &Tuning::sc_xcd},
+    {"sc_pass_wg", &Tuning::sc_pass_wg}, {"sc_local_g", &Tuning::sc_local_g}, {"sc_local_threads", &Tuning::sc_local_threads}, {"sc_ts", &Tuning::sc_ts}, {"sc_xcd", &Tuning::sc_xcd},
     {"sc_kf", &Tuning::sc_kf}, {"sc_plain_flat", &Tuning::sc_plain_flat}, {"sc_kp", &Tuning::sc_kp}, {"sc_k0", &Tuning::sc_k0},
     {"sc_flat_wg", &Tuning::sc_flat_wg}, {"sc_plain_wg", &Tuning::sc_plain_wg}, {"sc_pre", &Tuning::sc_pre},
     {"sc_pinned_out", &Tuning::sc_pinned_out}, {"sc_t1_device", &Tuning::sc_t1_device}, {"sc_handover", &Tuning::sc_handover},

@@ -85,6 +85,7 @@ struct Tuning {
     // sumcheck family (zk_fr.hip)
     long sc_pass_wg = 0;      // workgroups per CU of the HBM passes (0: 2 product / 4 others)
     long sc_local_g = 256;    // workgroups of a local stage
+    long sc_local_threads = 1024;  // threads of a local-stage workgroup (256: fits beside two accumulation workgroups of an MSM pass -- EXPERIMENT, profiles/r06q)
     long sc_ts = 0;           // 1: in-kernel stage timestamps of the local launches on stderr, 2: host-side phases, 3: HIP events (zk_sumcheck_last_timing)
     long sc_xcd = 1;          // XCD-aware slice map of the local stages
     long sc_kf = 4;           // rounds per flat fold pass (0: round-by-round passes)

@@ -416,19 +416,20 @@ __device__ __forceinline__ Fr fr_shfl_down32(const Fr& v, int off) {
     return o;
 }
 
-// one output sum of an earlier stage: block `ob` of the reduce part of the launch (1024 threads)
+// one output sum of an earlier stage: block `ob` of the reduce part of the launch (blockDim.x = 1024 or 256 threads)
 __device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __restrict__ out, void* __restrict__ wout, unsigned ob,
                                                 uint4* lds) {
     int p = 0;
     while (p + 1 < plan.n && ob >= plan.first[p + 1]) p++;
     const size_t s = ob - plan.first[p], nb = plan.nb[p];
     const int tid = threadIdx.x, grp = tid >> 5, l32 = tid & 31;
+    const unsigned nt = blockDim.x, ngrp = nt >> 5;
     if (plan.wide[p]) {
         Wide v;
 #pragma unroll
         for (int i = 0; i < 17; i++) v.l[i] = 0;
         if (plan.wide[p] == 2) {
-            for (size_t i = tid; i < nb; i += kLocalThreads) {
+            for (size_t i = tid; i < nb; i += nt) {
                 const uint4* q4 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(plan.partials[p]) + (s * nb + i) * kW9Bytes);
                 const uint4 a = q4[0], b = q4[1];
                 Wide t;
@@ -438,14 +439,19 @@ __device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __
                 wide_add(v, t);
             }
         } else {
-            for (size_t i = tid; i < nb; i += kLocalThreads) wide_add(v, wide_load(plan.partials[p], s * nb + i));
+            for (size_t i = tid; i < nb; i += nt) wide_add(v, wide_load(plan.partials[p], s * nb + i));
         }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) wide_add(v, wide_shfl_down(v, o, 32));
         if (l32 == 0) wide_store(lds, grp, v);
         __syncthreads();
         if (grp == 0) {
-            v = wide_load(lds, l32);
+            if ((unsigned)l32 < ngrp) {
+                v = wide_load(lds, l32);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 17; i++) v.l[i] = 0;
+            }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) wide_add(v, wide_shfl_down(v, o, 32));
             if (l32 == 0) wide_store(wout, plan.obase[p] + s, v);
@@ -453,13 +459,13 @@ __device__ __forceinline__ void reduce_all_body(const ReducePlan& plan, void* __
         return;
     }
     Fr v = fp_zero<FrCfg>();
-    for (size_t i = tid; i < nb; i += kLocalThreads) v = fr_add(v, fr_load(plan.partials[p], s * nb + i));
+    for (size_t i = tid; i < nb; i += nt) v = fr_add(v, fr_load(plan.partials[p], s * nb + i));
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
     if (l32 == 0) fr_store(lds, grp, v);
     __syncthreads();
     if (grp == 0) {
-        v = fr_load(lds, l32);
+        v = (unsigned)l32 < ngrp ? fr_load(lds, l32) : fp_zero<FrCfg>();
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) v = fr_add(v, fr_shfl_down32(v, o));
         if (l32 == 0) fr_store(out, plan.obase[p] + s, v);
@@ -487,7 +493,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         const unsigned x = w & 7, y = w >> 3;  // XCD, slot on it
         w = 4 * (x + 8 * (y >> 2)) + (y & 3);
     }
-    const unsigned tid = threadIdx.x;
+    const unsigned tid = threadIdx.x, nt = blockDim.x, ngrp = nt >> 5;  // 1 024 threads, or 256 (knob sc_local_threads: a workgroup that fits beside two accumulation workgroups)
     int tsn = 0;
 #define ZK_TS()                                                            \
     do {                                                                   \
@@ -509,52 +515,58 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
     uint4* presc = park + (MODE == 1 ? 6 * (size_t)(E - (E >> rounds)) : 0);  // 64 Fr: group partials of the pre-round
     if (pre) {
         const Fr r = fr_load(chal.c, 0);
-        Fr pa = fp_zero<FrCfg>(), pb = fp_zero<FrCfg>();
-        if (TWO) {
-            const unsigned role = tid >> elog, p = tid & (E - 1);  // role 0: f and t0 (t1), role 1: g and t2
-            if (role < 2) {
-                const Fr flo = fr_load(f, ZK_SLICE(p)), fhi = fr_load(f, ZK_SLICE(p + E));
-                const Fr glo = fr_load(g, ZK_SLICE(p)), ghi = fr_load(g, ZK_SLICE(p + E));
-                if (role == 0) {
-                    fr_store(tf, p, fr_add(flo, fr_mul(r, fr_sub(fhi, flo))));
-                    pa = fr_mul(flo, glo);
-                    if (t1mode != 0) pb = fr_mul(fhi, ghi);
-                } else {
-                    const Fr df = fr_sub(fhi, flo), dg = fr_sub(ghi, glo);
-                    fr_store(tg, p, fr_add(glo, fr_mul(r, dg)));
-                    pa = fr_mul(fr_add(fhi, df), fr_add(ghi, dg));  // (2 f_hi - f_lo)(2 g_hi - g_lo)      dsumcheck.rs:55-72
+        // one pair per VIRTUAL lane vt (2E of them with two tables: role 0 = f and t0 / t1, role 1 = g and t2; E with one); a workgroup
+        // of fewer threads walks them in steps of its size -- the 32-lane groups and their partials keep their virtual numbers
+        const unsigned nvt = TWO ? 2 * E : E;
+        for (unsigned vt = tid; vt < ((nvt + 31u) & ~31u); vt += nt) {
+            const unsigned vgrp = vt >> 5;
+            Fr pa = fp_zero<FrCfg>(), pb = fp_zero<FrCfg>();
+            if (TWO) {
+                const unsigned role = vt >> elog, p = vt & (E - 1);
+                if (role < 2) {
+                    const Fr flo = fr_load(f, ZK_SLICE(p)), fhi = fr_load(f, ZK_SLICE(p + E));
+                    const Fr glo = fr_load(g, ZK_SLICE(p)), ghi = fr_load(g, ZK_SLICE(p + E));
+                    if (role == 0) {
+                        fr_store(tf, p, fr_add(flo, fr_mul(r, fr_sub(fhi, flo))));
+                        pa = fr_mul(flo, glo);
+                        if (t1mode != 0) pb = fr_mul(fhi, ghi);
+                    } else {
+                        const Fr df = fr_sub(fhi, flo), dg = fr_sub(ghi, glo);
+                        fr_store(tg, p, fr_add(glo, fr_mul(r, dg)));
+                        pa = fr_mul(fr_add(fhi, df), fr_add(ghi, dg));  // (2 f_hi - f_lo)(2 g_hi - g_lo)      dsumcheck.rs:55-72
+                    }
                 }
+            } else if (vt < E) {
+                const Fr lo = fr_load(f, ZK_SLICE(vt)), hi = fr_load(f, ZK_SLICE(vt + E));
+                const Fr d = fr_sub(hi, lo);
+                if (MODE == 3) fr_store(qbase, w + (size_t)G * vt, d);
+                fr_store(tf, vt, fr_add(lo, fr_mul(r, d)));
+                pa = lo, pb = hi;
             }
-        } else if (tid < E) {
-            const Fr lo = fr_load(f, ZK_SLICE(tid)), hi = fr_load(f, ZK_SLICE(tid + E));
-            const Fr d = fr_sub(hi, lo);
-            if (MODE == 3) fr_store(qbase, w + (size_t)G * tid, d);
-            fr_store(tf, tid, fr_add(lo, fr_mul(r, d)));
-            pa = lo, pb = hi;
-        }
-        if (W != 0) {
-            const bool need_b = MODE == 0 || t1mode != 0;
+            if (W != 0) {
+                const bool need_b = MODE == 0 || t1mode != 0;
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                pa = fr_add(pa, fr_shfl_down32(pa, o));
-                if (need_b) pb = fr_add(pb, fr_shfl_down32(pb, o));
-            }
-            if (l32 == 0) {
-                fr_store(presc, grp, pa);
-                if (need_b) fr_store(presc, 32 + grp, pb);
+                for (int o = 16; o > 0; o >>= 1) {
+                    pa = fr_add(pa, fr_shfl_down32(pa, o));
+                    if (need_b) pb = fr_add(pb, fr_shfl_down32(pb, o));
+                }
+                if (l32 == 0 && vgrp < 32) {
+                    fr_store(presc, vgrp, pa);
+                    if (need_b) fr_store(presc, 32 + vgrp, pb);
+                }
             }
         }
     } else {
-        for (unsigned t = tid; t < E; t += kLocalThreads) {
+        for (unsigned t = tid; t < E; t += nt) {
             fr_store(tf, t, fr_load(f, ZK_SLICE(t)));
             if (TWO) fr_store(tg, t, fr_load(g, ZK_SLICE(t)));
         }
     }
     __syncthreads();
     ZK_TS();
-    if (pre && W != 0 && grp >= 29) {  // the sums of the pre-round, on the last wave (the fold chain below runs on the first)
-        const unsigned ng = E >> 5;    // groups per role
-        const int ws = 31 - grp;       // 0: t0 | plain lo, 1: t1 | plain hi, 2: t2
+    if (pre && W != 0 && (unsigned)grp + 3 >= ngrp) {  // the sums of the pre-round, on the last wave (the fold chain below runs on the first)
+        const unsigned ng = E >> 5;              // groups per role
+        const int ws = (int)ngrp - 1 - grp;      // 0: t0 | plain lo, 1: t1 | plain hi, 2: t2
         if (ws < W && !(MODE == 1 && ws == 1 && t1mode == 0)) {
             const unsigned src = (ws == 1) ? 32 : (ws == 2 ? ng : 0);
             Fr v = (unsigned)l32 < ng ? fr_load(presc, src + l32) : fp_zero<FrCfg>();
@@ -576,7 +588,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
             const bool solo = items <= 64;  // this round and every later one fit the first wave
             if (!solo || tid < 64) {
                 const Fr r = fr_load(chal.c, r0 + k);
-                for (unsigned it = tid; it < items; it += kLocalThreads) {
+                for (unsigned it = tid; it < items; it += nt) {
                     const bool isg = TWO && it >= h;
                     const unsigned t = isg ? it - h : it;
                     uint4* T = isg ? tg : tf;
@@ -597,7 +609,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
     }
     ZK_TS();
     const unsigned Lf = E >> rounds;
-    for (unsigned t = tid; t < Lf; t += kLocalThreads) {
+    for (unsigned t = tid; t < Lf; t += nt) {
         fr_store(fo, w + (size_t)G * t, fr_load(tf, lvl_off(E, rounds) + t));
         if (TWO) fr_store(go, w + (size_t)G * t, fr_load(tg, lvl_off(E, rounds) + t));
     }
@@ -605,7 +617,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
     // ---- phase B: the sums of every round ----
     const unsigned P = E - Lf;  // pairs over all rounds: round k holds E/2^(k+1) of them, from index E - E/2^k
     if (MODE == 1) {
-        for (unsigned it = tid; it < 3 * P; it += kLocalThreads) {
+        for (unsigned it = tid; it < 3 * P; it += nt) {
             const unsigned ws = it / P, p = it - ws * P;
             const unsigned u = E - p;  // in (E/2^(k+1), E/2^k]
             const int k = elog - (32 - __clz(u - 1));
@@ -628,7 +640,7 @@ __global__ void __launch_bounds__(kLocalThreads) k_local(const void* __restrict_
         __syncthreads();
     }
     ZK_TS();
-    for (int vid = grp; vid < rounds * W; vid += kLocalThreads / 32) {
+    for (int vid = grp; vid < rounds * W; vid += (int)ngrp) {
         const int k = vid / W, ws = vid - k * W;
         if (MODE == 1 && ws == 1 && !(t1mode == 2 || (t1mode == 1 && r0 + k == 0))) continue;
         const unsigned cnt = E >> (k + 1);
@@ -951,7 +963,8 @@ static int launch_local(zk_ctx* ctx, hipStream_t st, const void* f, const void* 
     while ((1u << elog) < E) elog++;
     // per call: the attribute belongs to the CURRENT device, and one process may hold a ctx per GPU
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_local<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(kLocalThreads), lds, st, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
+    const unsigned nthreads = tuning().sc_local_threads == 256 ? 256u : (unsigned)kLocalThreads;
+    hipLaunchKernelGGL((k_local<MODE>), dim3(G + extra), dim3(nthreads), lds, st, f, g, G, E, elog, rl, tc, sums, qb, fo, go,
                        rp ? *rp : none, red_out, red_wide, t1mode, sc_xcd_map(), pre, tr, want_ts ? sc_ts_next() : nullptr);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
