@@ -663,8 +663,9 @@ def run_rank(args, grp, gpu: int, ctx, net):
                     s_srs.precompute(0, record_bytes=args.table_rec)  # (setup, like the headline's)
                 s_sc = device_table(ctx, max(lg - (world.bit_length() - 1), 0), 77 + rank)
                 fn = (lambda: ctx.msm_g1(s_srs, s_sc, per)) if world == 1 else (lambda: sh.sharded_msm(ctx, s_srs, s_sc, per, net))
-                fn()
-                tt = timed(fn, 5 if lg <= 20 else 2, barrier)
+                for _ in range(3 if lg <= 20 else 1):  # (like the headline's warm-up: the first calls on a new level also size the arenas)
+                    fn()
+                tt = timed(fn, 10 if lg <= 20 else 2, barrier)
                 strong[f"msm_2p{lg}"] = {"ms": tt * 1e3, "scalar_muls_per_s": (1 << lg) / tt, "points_per_rank": per, "srs_window_table_bits": s_srs.table_window}
                 if lg == big and lg != args.log2n and rank == 0:
                     # roofline of the dominant kernel at the north-star size (2^24 points; this rank's chunk at N > 1), same model as the headline's

@@ -51,6 +51,7 @@ struct zk_ctx {
         hipStream_t aux[kAux] = {};
         hipEvent_t ev_fork = nullptr, ev_join[kAux] = {}, ev_part[kParts] = {};
         std::vector<hipEvent_t> ev_cls;  // completion event per MSM window class of a batch
+        std::vector<hipEvent_t> ev_sort;  // end of the sort phase per class: the classes of a batch share ONE level-1 scratch region (zk_msm.hip)
         bool ready = false;
         // async lanes: growable arenas and pinned staging of their own (kept between jobs, like the ctx's scratch), and
         // whether a job currently owns the lane
@@ -109,6 +110,7 @@ struct Tuning {
     long msm_split = 1;       // staggered parts of the largest class
     long msm_np = 0;          // sort partitions per row (0: auto)
     long msm_fused_min = 0;   // window-table rows of >= 2^k entries are partitioned straight from the scalars (0: k = 23; -1: never -- the round-5 path)
+    long msm_share_l1 = 1;    // the classes of a batch share one level-1 sort scratch (their sort phases run in sequence; 0: a region per class)
     long msm_idx_ahead = 1;   // k_accum_tiles: the sorted index of the entry after next is fetched one iteration early (0: the round-5 loop)
     long msm_tab_spt = 0;     // fused level 1: 1 forces one scalar per thread (A/B)
     long msm_l2_tiled = 0;    // level 2 in LDS-staged tiles for partitions of >= this many entries (0: 8192, rows of >= 2^23 entries; -1: never)

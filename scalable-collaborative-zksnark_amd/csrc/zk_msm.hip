@@ -1671,6 +1671,8 @@ void msm_lanes_destroy(zk_ctx* ctx) {
             if (e) hipEventDestroy(e);
         for (auto& e : L.ev_cls)
             if (e) hipEventDestroy(e);
+        for (auto& e : L.ev_sort)
+            if (e) hipEventDestroy(e);
         for (auto& a : L.mem)
             if (a.p) hipFree(a.p);
         if (L.pinned) hipHostFree(L.pinned);
@@ -1780,6 +1782,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
     }
     // ---- geometry per class, scratch high-water marks ----
     size_t need[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pinned_bytes = 0;
+    const bool share_l1 = tn.msm_share_l1 != 0;
     for (auto& cl : classes) {
         const int W = cl.wc;
         const size_t nitems = cl.idx.size();
@@ -1860,8 +1863,14 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
                                    2 * tiles64 * Cv::kXyzzBytes, (cl.total_tiles / kLongSpan + 64 + 1) * 4, nitems * sizeof(ItemDesc),
                                    cl.cc_elems * 4, cl.rows * cl.row_len * 2};
         for (int i = 0; i < 10; i++) {
-            cl.off[i] = need[i];
-            need[i] += (want_b[i] + 255) & ~(size_t)255;
+            // the level-1 entries (part_idx, part_low: 6 of the ~10 bytes per entry) are dead once a class is sorted, long before its
+            // accumulation ends: ONE region serves every class of the batch, and the sort phases run one after the other (event chain
+            // below; they are bandwidth-bound and would share the memory system anyway) while the accumulations overlap as before.
+            // n = 24 proof: 112 -> ~85 GB of pass arenas.
+            const bool shared_scratch = share_l1 && (i == 1 || i == 9);
+            cl.off[i] = shared_scratch ? 0 : need[i];
+            if (shared_scratch) need[i] = std::max(need[i], (want_b[i] + 255) & ~(size_t)255);
+            else need[i] += (want_b[i] + 255) & ~(size_t)255;
         }
         cl.pinned_off = pinned_bytes;
         pinned_bytes += ((cl.rows * (size_t)cl.npair * Cv::kJacBytes + 255) & ~(size_t)255) + ((nitems * sizeof(ItemDesc) + 255) & ~(size_t)255);
@@ -2000,6 +2009,14 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
         if (t_first) hipEventRecord(ctx->ev[0], st);
         ZK_HIP_INFLIGHT(ctx, hipMemcpyAsync(d_items, h_items, nitems * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
         ZK_HIP_INFLIGHT(ctx, hipMemsetAsync(longs, 0, 4, st));
+        if (share_l1) {
+            while (L.ev_sort.size() <= cls_i) {
+                hipEvent_t e = nullptr;
+                ZK_HIP_INFLIGHT(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                L.ev_sort.push_back(e);
+            }
+            if (cls_i > 0) hipStreamWaitEvent(st, L.ev_sort[cls_i - 1], 0);  // the shared level-1 scratch is free again
+        }
         if (!cl.fused_tab)
             hipLaunchKernelGGL(k_digits, dim3((unsigned)((ns + kBlk - 1) / kBlk), (unsigned)nitems), dim3(kBlk), 0, st,
                                (const ItemDesc*)d_items, ns, cl.L, cl.w0, cl.wc, (cl.shared || !Cv::kEndo) ? 0 : 1, digits);
@@ -2047,6 +2064,7 @@ static int msm_enqueue(zk_ctx* ctx, MsmRun& run) {
             hipLaunchKernelGGL(k_part_sort, g_parts, dim3(cl.row_len / cl.np >= 4096 ? kSortThreads : 256), 0, st, (const u32*)part_idx, (const unsigned short*)part_low, cl.row_len,
                                cl.np, cl.low_bits, cl.idx_bits, nb, (const u32*)pbase, (const u32*)rowtot, oc, cl.T, cl.tiles_per_w, tile_b, sorted);
         }
+        if (share_l1) hipEventRecord(L.ev_sort[cls_i], st);
         if (t_first) hipEventRecord(ctx->ev[1], st);
         if (cl.part > 0) hipStreamWaitEvent(st, L.ev_part[(cl.part - 1) % zk_ctx::kParts], 0);  // after the previous part's accumulation
         // (a pass with a share below 100 % leaves workgroup slots free for the kernels of other streams: knob msm_share)
