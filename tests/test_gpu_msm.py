@@ -376,3 +376,33 @@ def test_arena_plan_round_trip_makes_the_first_pass_allocation_free():
     with pytest.raises(zkhip.ZkError):
         b.arena_plan_import(np.zeros(48, dtype=np.uint64))
     b.close()
+
+
+def test_round6_sort_kernels_on_small_ragged_batches(ctx, co):
+    """
+    k_tab_hist / k_tab_scatter (level 1 straight from the scalars) and k_l2_* (level 2 in LDS-staged tiles) normally serve rows of
+    >= 2^23 entries (test_gpu_bigsizes.py, test_gpu_fullsize.py); here the knobs force them onto small, ragged window-table batches --
+    items of very different lengths in one class, offsets, table widths with and without a compile-time layout, skewed scalars -- and
+    onto a table-less MSM (tiled level 2 only), against the C oracle.
+    """
+    n_max = 1 << 13
+    bases, _ = synthetic_bases(n_max, 99)
+    knobs = {"msm_fused_min": 10, "msm_l2_tiled": 64, "msm_np": 1024}
+    try:
+        for k, v in knobs.items():
+            ctx.dbg_tune(k, v)
+        srs = ctx.srs_register(bases)
+        sc_tl = rand_fr(n_max, 5)
+        assert (jac_norm_to_affine(ctx.msm_g1(srs, ctx.to_device(sc_tl), n_max)) == co.msm_g1(bases, sc_tl)).all()  # table-less, tiled level 2
+        for width in (0, 13, 16, 19):  # 0: the library's pick (14 bits, run-time layout); 16, 19: compile-time layouts; 13: run-time
+            srs.precompute(width)
+            ns = [n_max, 5000, 1024, 777, 64, 3, 1]
+            offs = [0, 100, 7000, 1, 8000, 8189, 8191]
+            scs = [rand_fr(n, 300 + 10 * width + j) for j, n in enumerate(ns)]
+            scs[1] = scs[1][np.zeros(ns[1], dtype=np.int64)]  # one scalar 5 000 times: a single bucket per window
+            got = ctx.msm_g1_batch([srs] * len(ns), [ctx.to_device(s) for s in scs], ns, offsets=offs)
+            for j, n in enumerate(ns):
+                assert (jac_norm_to_affine(got[j]) == co.msm_g1(bases[offs[j] : offs[j] + n], scs[j])).all(), (width, n)
+    finally:
+        for k in knobs:
+            ctx.dbg_tune(k, 0)
