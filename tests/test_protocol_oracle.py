@@ -209,6 +209,8 @@ def _cpp_run(tmp_path, which, n, l, mode, env=None):
                                             # 32 real parties (l = 4 needs n >= 8: the leader tree of 32 parties wants SRS level 5) and the leader of 64
                                             ("dhyperplonk", 8, 4, "threads"), ("cpermcheck", 8, 4, "threads"), ("dhyperplonk", 10, 8, "leader")])
 def test_compiled_host_equals_the_straight_line_oracle(tmp_path, which, n, l, mode):
+    if (which, n, l) in (("cpermcheck", 8, 4), ("dhyperplonk", 10, 8)) and os.environ.get("ZK_SLOW_TESTS") != "1":
+        pytest.skip("the oracle side of this case takes 70-85 s of python big-ints: ZK_SLOW_TESTS=1 runs it (passed in profiles/r06z_pytest_gpu.txt)")
     """host/bin/hyperplonk (zkhost/hyperplonk.hpp): every party's dumped transcript against the oracle driver on the same SplitMix64
     parameter set (PackedProvingParameters::make = PackedProvingParameters.new_splitmix: seed 100 + p, challenges 4242)"""
     got = _cpp_run(tmp_path, which, n, l, mode)
