@@ -622,6 +622,10 @@ class Ctx:
     def comm_destroy(self):
         self._check(self.lib.zk_comm_destroy(self.h))
 
+    def comm_abort(self):
+        """this party cannot go on: its peers' pending and later collectives end with ZK_ERR_COMM instead of waiting for it (zk_comm_abort)"""
+        self._check(self.lib.zk_comm_abort(self.h))
+
     @property
     def comm_rank(self) -> int:
         return self.lib.zk_comm_rank(self.h)

@@ -420,3 +420,47 @@ def test_cpp_host_rccl_mode_rejects_a_flipped_limb_on_every_party():
     r = _hyperplonk(["--l", "1", "--n", "10", "--mode", "rccl", "--share-gpus", "--reps", "1", "--tamper"], _fake_env())
     checks = [l for l in r.stdout.splitlines() if l.startswith("check: party ")]
     assert r.returncode == 3 and len(checks) == 8 and all("FAILED [gate[3]]" in l for l in checks), (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_comm_abort_takes_the_peers_out_of_their_collective_over_the_rccl_test_double():
+    """
+    zk_comm_abort (include/zkhip.h): a party that fails for a reason of its own -- out of memory, a failed kernel -- must not leave the others
+    waiting inside an exchange.  Four parties over the test double; three enter an all-gather, the fourth aborts its communicator
+    instead: the three return ZK_ERR_COMM (nobody hangs), and the aborted ctx has no communicator left.
+    """
+    code = r"""
+import sys, threading, time
+import numpy as np
+import zkhip
+from zkhip._lib import ZK_ERR_COMM
+from zkhip.net import RcclNet
+assert 'torch' not in sys.modules
+W = 4
+ctxs = [zkhip.Ctx(0) for _ in range(W)]
+RcclNet.from_init_all(ctxs)
+res = [None] * W
+def run(p):
+    c = ctxs[p]
+    if p == W - 1:
+        time.sleep(0.5)   # the others are inside the collective by now
+        c.comm_abort()
+        res[p] = ('aborted', c.comm_size)
+        return
+    try:
+        d = c.to_device(np.full((4, 4), p, dtype=np.uint64))
+        c.allgather(d, 128)
+        c.sync()
+        res[p] = ('returned', 0)
+    except zkhip.ZkError as e:
+        res[p] = ('error', e.code)
+th = [threading.Thread(target=run, args=(p,)) for p in range(W)]
+[t.start() for t in th]
+[t.join(timeout=120) for t in th]
+assert not any(t.is_alive() for t in th), 'a party is still blocked in the exchange'
+print('RES', res)
+assert res[W - 1][0] == 'aborted'
+assert all(r == ('error', ZK_ERR_COMM) for r in res[:W - 1]), res
+print('ABORT_OK')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=_fake_env(), cwd=os.path.join(ROOT, "tests"))
+    assert r.returncode == 0 and "ABORT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
