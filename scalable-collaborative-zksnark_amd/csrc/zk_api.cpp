@@ -22,7 +22,7 @@ static const TuneKey kTuneKeys[] = {
     {"sc_pinned_out", &Tuning::sc_pinned_out}, {"sc_t1_device", &Tuning::sc_t1_device}, {"sc_handover", &Tuning::sc_handover},
     {"msm_table_dc", &Tuning::msm_table_dc}, {"msm_qstep", &Tuning::msm_qstep}, {"msm_tile", &Tuning::msm_tile}, {"msm_pair", &Tuning::msm_pair},
     {"msm_fixq", &Tuning::msm_fixq}, {"msm_quad", &Tuning::msm_quad}, {"msm_stage", &Tuning::msm_stage}, {"msm_split", &Tuning::msm_split},
-    {"msm_np", &Tuning::msm_np}, {"msm_fused_min", &Tuning::msm_fused_min}, {"msm_l2_tiled", &Tuning::msm_l2_tiled}, {"msm_tab_spt", &Tuning::msm_tab_spt}, {"msm_idx_ahead", &Tuning::msm_idx_ahead}, {"msm_share_l1", &Tuning::msm_share_l1}, {"msm_debug", &Tuning::msm_debug}, {"msm_serial", &Tuning::msm_serial}, {"msm_size_classes", &Tuning::msm_size_classes},
+    {"msm_np", &Tuning::msm_np}, {"msm_fused_min", &Tuning::msm_fused_min}, {"msm_l2_tiled", &Tuning::msm_l2_tiled}, {"msm_tab_spt", &Tuning::msm_tab_spt}, {"msm_idx_ahead", &Tuning::msm_idx_ahead}, {"msm_share_l1", &Tuning::msm_share_l1}, {"srs_table_batched", &Tuning::srs_table_batched}, {"msm_debug", &Tuning::msm_debug}, {"msm_serial", &Tuning::msm_serial}, {"msm_size_classes", &Tuning::msm_size_classes},
     {"g1_map_by_column", &Tuning::g1_map_by_column}, {"msm_share", &Tuning::msm_share}, {"srs_table_rec", &Tuning::srs_table_rec}, {"msm_size_class_min", &Tuning::msm_size_class_min}, {"msm_small_table_widths", &Tuning::msm_small_table_widths},
 };
 static Tuning g_tuning;

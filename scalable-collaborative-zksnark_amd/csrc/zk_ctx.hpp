@@ -117,6 +117,7 @@ struct Tuning {
     long msm_debug = 0;       // class geometry on stderr
     long msm_serial = 0;      // all classes on the ctx stream
     long msm_size_classes = 1;  // window-table items: one class per power-of-two length
+    long srs_table_batched = 1;  // G1 window tables: normalise with Montgomery's trick (one inversion per 64 records; 0: one per record, the round-5 kernel)
     long srs_table_rec = 0;   // G1 window tables built from now on: bytes per record (0: by free memory, see srs_precompute | 96: packed | 128: one record per 128-B line -- faster gathers, +33 % table memory)
     long msm_size_class_min = 16;  // window-table items of up to 2^k points (and one table width) share one size class: fewer launch chains for the short items of a batch
     long msm_small_table_widths = 1;  // zk_srs_precompute's own pick: 12 bits up to 2^10 points, 14 bits for 2^11 .. 2^14 (0: log2 n + 2)

@@ -1344,6 +1344,87 @@ static __global__ void __launch_bounds__(Cv::kEndo ? kBlk : 64) k_precompute(con
     }
 }
 
+#ifndef ZK_MSM_TU_G2
+// G1 tables, round 6: k_precompute above normalises every copy of every point with an inversion of its own -- 14 Fermat inversions
+// (~570 multiplications each) beside 255 doublings (~2 000): 80 % of a table's build time.  The two kernels below split the work:
+// the chain kernel stores the XYZZ form of every copy of a CHUNK of points ([W][cn_pad], the blocked XYZZ layout), the
+// normalisation runs Montgomery's trick per lane over 64 strided entries of that array (one inversion per 64 records) and writes
+// the records where the table wants them.  Same canonical coordinates, hence the same table bytes.
+static __global__ void __launch_bounds__(kBlk) k_table_chain(const void* __restrict__ bases, size_t c0, size_t cn, size_t cn_pad, WinLayout L,
+                                                    void* __restrict__ xyzz) {
+    const size_t j = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (j >= cn) return;
+    const Aff30 p = aff30_load(bases, c0 + j);
+    Xyzz30 acc;
+    xyzz30_set_inf(acc);
+    xyzz30_madd(acc, p, false);
+    for (int w = 0; w < L.W; w++) {
+        if (w > 0)
+            for (int k = 0; k < L.width(w - 1); k++) acc = xyzz30_dbl(acc);
+        xyzz30_store(xyzz, (size_t)w * cn_pad + j, acc);
+    }
+}
+// lane t owns the entries {t + i T} of the [W][cn_pad] array; entry idx = w * cn_pad + j becomes record (w * nsr + c0 + j) of the table
+static __global__ void __launch_bounds__(kBlk) k_table_normalise(const void* __restrict__ in, size_t total, size_t T, void* __restrict__ prefix, size_t c0, size_t cn,
+                                                        size_t cn_pad, size_t nsr, void* __restrict__ table, u32 rec) {
+    const size_t t = (size_t)blockIdx.x * kBlk + threadIdx.x;
+    if (t >= T || t >= total) return;
+    const size_t cnt = (total - t + T - 1) / T;
+    Fq30 p = f30_one();
+    for (size_t i = 0; i < cnt; i++) {
+        const size_t idx = t + i * T;
+        f30_store(prefix, idx * 48, p);  // product of the ZZZ before this entry
+        const Fq30 zzz = f30_load_chunks(in, idx, 9);
+        if (!f30_all_zero(zzz)) p = f30_mul(p, zzz);
+    }
+    Fq30 inv = f30_inv(p);
+    for (size_t i = cnt; i-- > 0;) {
+        const size_t idx = t + i * T;
+        const Fq30 zzz = f30_load_chunks(in, idx, 9);
+        Fq30 x = f30_zero(), y = f30_zero();
+        if (!f30_all_zero(zzz)) {
+            const Fq30 i3 = f30_mul(inv, f30_load(prefix, idx * 48));  // 1 / ZZZ
+            inv = f30_mul(inv, zzz);
+            const Fq30 iz = f30_mul(f30_load_chunks(in, idx, 6), i3);  // ZZ / ZZZ = 1 / Z
+            x = f30_canon8(f30_mul(f30_load_chunks(in, idx, 0), f30_sqr(iz)));
+            y = f30_canon8(f30_mul(f30_load_chunks(in, idx, 3), i3));
+        }
+        const size_t w = idx / cn_pad, j = idx - w * cn_pad;
+        if (j < cn) {  // (the padding of a chunk belongs to no record)
+            f30_store(table, (w * nsr + c0 + j) * rec, x);
+            f30_store(table, (w * nsr + c0 + j) * rec + 48, y);
+        }
+    }
+}
+// -> ZK_OK, or an error after which the caller falls back to k_precompute (no memory for the transient arrays)
+static int precompute_table_g1_batched(zk_ctx* ctx, const zk_srs* srs, const WinLayout& L, size_t nsr, void* d_table, u32 rec) {
+    const size_t chunk = std::min<size_t>(srs->n, (size_t)1 << 20);
+    const size_t pad = (chunk + 63) & ~(size_t)63, total_max = (size_t)L.W * pad;
+    void *d_x = nullptr, *d_pref = nullptr;
+    hipError_t e = device_alloc(ctx, &d_x, total_max * 192);
+    if (e == hipSuccess) e = device_alloc(ctx, &d_pref, total_max * 48);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (d_x) hipFree(d_x);
+        return ZK_ERR_OOM;
+    }
+    for (size_t c0 = 0; c0 < srs->n && e == hipSuccess; c0 += chunk) {
+        const size_t cn = std::min(chunk, srs->n - c0), cn_pad = (cn + 63) & ~(size_t)63, total = (size_t)L.W * cn_pad;
+        e = hipMemsetAsync(d_x, 0, total * 192, ctx->stream);  // padding entries: ZZZ = 0 = infinity
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_table_chain, dim3((unsigned)((cn + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)srs->d_bases, c0, cn, cn_pad, L, d_x);
+        const size_t T = std::max<size_t>(1, (total + 63) / 64);
+        hipLaunchKernelGGL(k_table_normalise, dim3((unsigned)((T + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)d_x, total, T, d_pref, c0, cn, cn_pad, nsr,
+                           d_table, rec);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_x);
+    hipFree(d_pref);
+    return e == hipSuccess ? ZK_OK : hip_fail(ctx, e, "window table (batched normalisation)");
+}
+#endif
+
 // SRS format conversion: reference Montgomery form (x * 2^384) <-> internal (x * 2^390), in place or copy
 static __global__ void __launch_bounds__(kBlk) k_srs_convert(const void* __restrict__ in, void* __restrict__ out, size_t ncoord, int to_internal) {
     for (size_t i = (size_t)blockIdx.x * kBlk + threadIdx.x; i < ncoord; i += (size_t)gridDim.x * kBlk) {
@@ -2443,8 +2524,12 @@ int srs_precompute(zk_ctx* ctx, zk_srs* srs, int c, int record_bytes) {
         const int rc = srs_precompute_table_g2(ctx, srs, c, nsr, srs->d_table);  // (the other translation unit)
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL((k_precompute<CvG1>), dim3((unsigned)((srs->n + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr,
-                           L, srs->d_table, (u32)rec);
+        // (tables of >= 2^10 points: the batched normalisation; below, and when its transient arrays do not fit, one inversion per record)
+        int rc = (srs->n >= 1024 && tuning().srs_table_batched != 0) ? precompute_table_g1_batched(ctx, srs, L, nsr, srs->d_table, (u32)rec) : ZK_ERR_OOM;
+        if (rc != ZK_OK && rc != ZK_ERR_OOM) return rc;
+        if (rc == ZK_ERR_OOM)
+            hipLaunchKernelGGL((k_precompute<CvG1>), dim3((unsigned)((srs->n + kBlk - 1) / kBlk)), dim3(kBlk), 0, ctx->stream, (const void*)srs->d_bases, srs->n, nsr,
+                               L, srs->d_table, (u32)rec);
     }
     ZK_HIP(ctx, hipGetLastError());
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
