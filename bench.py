@@ -165,6 +165,25 @@ def pmc_traffic(kernel: str, pick: str = "most_dispatches"):
     return (tot or None), os.path.relpath(files[-1], ROOT)
 
 
+def sort_phase_traffic():
+    """FETCH_SIZE x 2 + WRITE_SIZE over the kernels of the round-6 sort phase at 2^24 points, from the newest committed profiles/*sort_phase_pmc.csv
+    (its first block = the round-6 kernels; the block behind the `# r05` line = the round-5 kernels, not counted)"""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sort_phase_pmc.csv")))
+    if not files:
+        return None, None
+    tot = 0.0
+    for line in open(files[-1]):
+        if line.startswith("# r05"):
+            break
+        row = next(csv.reader([line]))
+        if len(row) >= 5 and row[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+            tot += float(row[-1]) * 1024.0 * (2.0 if row[0] == "FETCH_SIZE" else 1.0)
+    return (tot or None), os.path.relpath(files[-1], ROOT)
+
+
 METRIC = "G1 scalar-muls/sec (d_msm) + Fr field-ops/sec (d_sumcheck), 2^20 shares, 1/2/4/8 GPU"
 MAD_PEAK_ARCH = 256 * 128 * 2.4e9 / 2  # architectural ceiling: 256 CUs x 128 lanes/clk x 2.4 GHz, v_mad_u64_u32 at half rate = 39.3 T/s
 
@@ -683,6 +702,20 @@ def run_rank(args, grp, gpu: int, ctx, net):
                         "traffic": tr24, "traffic_source": src24,
                         "hbm": {"bound": "hbm", "achieved": 128.0 * per / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": 128.0 * per / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else 0.0, "algorithmic_bytes_per_launch": 128.0 * per}}
+                    if tcb:
+                        # the HBM-bound phase of the MSM: signed digits + the two-level counting sort (round 6: k_tab_hist, k_tab_scatter, k_l2_*).
+                        # Algorithmic bytes: 32 B per scalar in, 4 B per sorted entry out; live time = HIP events around the phase
+                        # (zk_msm_last_timing[0]); traffic = FETCH_SIZE x 2 + WRITE_SIZE of the phase's kernels from the committed PMC passes
+                        s_ms = float(ctx.msm_last_timing()[0])
+                        alg = 32.0 * per + 4.0 * md
+                        tr_s, src_s = sort_phase_traffic() if (world == 1 and lg == 24) else (None, None)
+                        extra[f"roofline_msm_2p{lg}"]["sort_phase"] = {
+                            "kernels": "k_tab_hist, k_part_scan, k_part_bases, k_tab_scatter, k_l2_tiles, k_l2_hist, k_l2_scan, k_l2_scatter", "bound": "hbm", "phase_ms": s_ms,
+                            "algorithmic_bytes": alg, "achieved": alg / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if s_ms > 0 else 0.0, "traffic": tr_s, "traffic_source": src_s,
+                            "traffic_GBps": (tr_s / (s_ms * 1e-3) / 1e9) if (tr_s and s_ms > 0) else None,
+                            "note": "every kernel of the phase moves its own algorithmic bytes (profiles/r06z_sort_phase_pmc.csv); the phase as a whole moves ~4x the compulsory "
+                                    "bytes because the scalars are read twice and the 6-byte level-1 entries make one round trip (DESIGN.md section 4)"}
                 s_srs.free()
                 del s_sc
             per = (1 << big) // world
